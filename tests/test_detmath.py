@@ -1,0 +1,43 @@
+"""The restated sinf/cosf/powf (oracle om_*) against the host libm, exhaustively over every
+argument the renderer can produce.  Meaningful where the host libm is glibc 2.35 with the FMA
+variants (this image); elsewhere the comparison is skipped, the HIP-vs-oracle tests still hold."""
+import platform
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+import _oracle as O
+
+
+def _glibc_235():
+    return platform.libc_ver() == ("glibc", "2.35")
+
+
+@pytest.mark.skipif(not _glibc_235(), reason="restates glibc 2.35's libm")
+def test_sincos_all_renderer_arguments():
+    # x = (2*pi)_f32 * k/2^23 for every 23-bit k: every value GetRandom can return
+    assert O.oracle().orc_math_mismatches(0, 0, 1 << 23) == 0
+
+
+@pytest.mark.skipif(not _glibc_235(), reason="restates glibc 2.35's libm")
+def test_gamma_pow_every_float_in_unit_interval():
+    n = 0x3F800001            # bit patterns of [0, 1]
+    parts = 32
+    step = (n + parts - 1) // parts
+    with ThreadPoolExecutor(8) as ex:
+        bad = list(ex.map(lambda i: O.oracle().orc_math_mismatches(1, i * step, min(n, (i + 1) * step)),
+                          range(parts)))
+    assert sum(bad) == 0
+
+
+def test_special_values():
+    lib = O.oracle()
+    assert lib.om_gammaf(0.0) == 0.0
+    assert lib.om_gammaf(1.0) == 1.0
+    assert lib.om_sinf(0.0) == 0.0
+    assert lib.om_cosf(0.0) == 1.0
+    assert lib.orc_to_int(0.0) == 0
+    assert lib.orc_to_int(1.0) == 255
+    assert lib.orc_to_int(7.5) == 255
+    assert lib.orc_to_int(-3.0) == 0
+    assert lib.orc_to_int(float("nan")) == 0
