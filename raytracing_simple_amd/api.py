@@ -1,0 +1,241 @@
+"""ctypes binding of include/rt_api.h (one Python method per C entry point)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SPHERE_DT = np.dtype([("rad", "<f4"), ("p", "<f4", 3), ("e", "<f4", 3), ("c", "<f4", 3),
+                      ("refl", "<i4")])           # include/rt_api.h rt_sphere, 44 bytes
+CAMERA_FLOATS = 15                                # rt_camera: orig,target,dir,x,y
+
+RT_MODE_PARITY, RT_MODE_FAST = 0, 1
+DIFF, SPEC, REFR = 0, 1, 2
+
+# every symbol include/rt_api.h declares (tests/test_abi.py checks the export table)
+SYMBOLS = ["rt_render", "rt_create", "rt_create_sharded", "rt_destroy", "rt_set_scene",
+           "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
+           "rt_device_pixels", "rt_local_rows", "rt_current_sample", "rt_read_colors",
+           "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_compute_camera",
+           "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_debug_eval"]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"rt status {code}: {text}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("rng_draws", C.c_uint64), ("launches", C.c_uint64),
+                ("last_kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class _Scene(C.Structure):
+    _fields_ = [("spheres", C.c_void_p), ("count", C.c_uint32)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "librt_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load librt_hip.so (built in-tree by raytracing_simple_amd._build).  Raises if absent:
+    the HIP library IS the product, there is nothing to fall back to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RtError(-2, f"{path} is not built; run `python -m raytracing_simple_amd._build` "
+                          "(needs hipcc) -- there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, i32, u32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+    sig = {
+        "rt_render": (i32, [vp, vp, vp, i32, i32, i32]),
+        "rt_create": (i32, [C.POINTER(vp), i32, i32]),
+        "rt_create_sharded": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, i32]),
+        "rt_destroy": (None, [vp]),
+        "rt_set_scene": (i32, [vp, vp, u32]),
+        "rt_set_camera": (i32, [vp, vp]),
+        "rt_set_mode": (i32, [vp, i32]),
+        "rt_reset": (i32, [vp]),
+        "rt_reset_async": (i32, [vp, vp]),
+        "rt_render_pass": (i32, [vp, vp, i32]),
+        "rt_render_async": (i32, [vp, i32, vp]),
+        "rt_device_pixels": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "rt_local_rows": (i32, [vp]),
+        "rt_current_sample": (i32, [vp]),
+        "rt_read_colors": (i32, [vp, vp]),
+        "rt_read_seeds": (i32, [vp, vp]),
+        "rt_get_stats": (i32, [vp, C.POINTER(Stats)]),
+        "rt_last_error": (C.c_char_p, []),
+        "rt_compute_camera": (None, [vp, i32, i32]),
+        "rt_default_seeds": (None, [vp, sz]),
+        "rt_demo_scene": (i32, [vp, u32]),
+        "rt_read_scene": (i32, [C.c_char_p, vp, u32, C.POINTER(u32), vp, vp, i32]),
+        "rt_debug_eval": (i32, [i32, vp, vp, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(rc, load_library().rt_last_error().decode(errors="replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_spheres(spheres):
+    a = np.ascontiguousarray(spheres)
+    if a.dtype != SPHERE_DT:
+        a = a.view(np.uint8).reshape(-1).view(SPHERE_DT)
+    return a
+
+
+def as_camera(cam):
+    a = np.ascontiguousarray(cam, dtype=np.float32).reshape(-1)
+    if a.size != CAMERA_FLOATS:
+        raise ValueError("camera = 15 floats: orig, target, dir, x, y")
+    return a
+
+
+def render(spheres, cam, w, h, spp):
+    """rt_render: the one-shot headline call.  Returns uint32[h*w] (row 0 = bottom)."""
+    lib = load_library()
+    sph = as_spheres(spheres)
+    cam = as_camera(cam)
+    out = np.zeros(w * h, np.uint32)
+    scene = _Scene(sph.ctypes.data, len(sph))
+    _check(lib.rt_render(C.addressof(scene), _ptr(cam), _ptr(out), w, h, spp))
+    return out
+
+
+class RtContext:
+    """One rt_ctx (= one OpenCLConfigBuffer of the reference)."""
+
+    def __init__(self, w, h, device=0, rank=0, nranks=1, tile_rows=8):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.w, self.h = w, h
+        self.rank, self.nranks, self.tile_rows = rank, nranks, tile_rows
+        _check(self._lib.rt_create_sharded(C.byref(self._h), w, h, device, rank, nranks, tile_rows))
+
+    def close(self):
+        if self._h:
+            self._lib.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # --- state ---------------------------------------------------------------------------
+    def set_scene(self, spheres):
+        sph = as_spheres(spheres)
+        _check(self._lib.rt_set_scene(self._h, _ptr(sph), len(sph)))
+
+    def set_camera(self, cam):
+        cam = as_camera(cam)
+        _check(self._lib.rt_set_camera(self._h, _ptr(cam)))
+
+    def set_mode(self, mode):
+        _check(self._lib.rt_set_mode(self._h, mode))
+
+    def reset(self):
+        _check(self._lib.rt_reset(self._h))
+
+    @property
+    def local_rows(self):
+        return self._lib.rt_local_rows(self._h)
+
+    @property
+    def current_sample(self):
+        return self._lib.rt_current_sample(self._h)
+
+    # --- rendering ----------------------------------------------------------------------
+    def render_pass(self, n_samples, copy=True):
+        """n_samples reference passes in one launch; returns the local pixel rows (uint32)."""
+        out = np.zeros(self.local_rows * self.w, np.uint32) if copy else None
+        _check(self._lib.rt_render_pass(self._h, _ptr(out) if copy else None, n_samples))
+        return out
+
+    def reset_async(self, stream=None):
+        _check(self._lib.rt_reset_async(self._h, C.c_void_p(stream or 0)))
+
+    def render_async(self, n_samples, stream=None):
+        _check(self._lib.rt_render_async(self._h, n_samples, C.c_void_p(stream or 0)))
+
+    def device_pixels(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self._lib.rt_device_pixels(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def device_pixels_array(self):
+        """The local pixel rows as a zero-copy __cuda_array_interface__ object (int32 [rows, w]),
+        for torch.as_tensor(..., device='cuda') in the multi-GPU gather."""
+        ptr, n = self.device_pixels()
+
+        class _View:
+            pass
+
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (n // self.w, self.w), "typestr": "<i4",
+                                      "data": (ptr, False), "version": 2, "strides": None}
+        v._owner = self
+        return v
+
+    def read_colors(self):
+        out = np.zeros(3 * self.w * self.h, np.float32)
+        _check(self._lib.rt_read_colors(self._h, _ptr(out)))
+        return out
+
+    def read_seeds(self):
+        out = np.zeros(2 * self.w * self.h, np.uint32)
+        _check(self._lib.rt_read_seeds(self._h, _ptr(out)))
+        return out
+
+    def stats(self):
+        st = Stats()
+        _check(self._lib.rt_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    # --- sharding helpers ---------------------------------------------------------------
+    def local_row_map(self):
+        """global row index of every local row, in local order."""
+        return local_rows_of(self.h, self.rank, self.nranks, self.tile_rows)
+
+
+def local_rows_of(h, rank, nranks, tile_rows):
+    rows = []
+    n_tiles = (h + tile_rows - 1) // tile_rows
+    for t in range(rank, n_tiles, nranks):
+        rows.extend(range(t * tile_rows, min(h, (t + 1) * tile_rows)))
+    return np.asarray(rows, dtype=np.int64)
+
+
+def debug_eval(op, values):
+    lib = load_library()
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.zeros_like(v)
+    _check(lib.rt_debug_eval(op, _ptr(v), _ptr(out), v.size))
+    return out

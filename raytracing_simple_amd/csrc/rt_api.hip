@@ -1,0 +1,396 @@
+// rt_api.hip -- the C ABI of include/rt_api.h: context = the reference's OpenCLConfigBuffer
+// (SimpleRT/src/OpenCLConfig.cpp:398-747) re-done for one MI355X: device buffers, scene
+// tables, launch geometry, row-tile sharding, counters.  No CPU fallback: without a HIP
+// device every entry point fails with RT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rt_device.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int w = 0, h = 0;
+    int rank = 0, nranks = 1, tile_rows = 8, local_rows = 0;
+    uint32_t *d_seeds = nullptr;
+    uint32_t *d_seeds0 = nullptr;  // pristine default stream, for device-side resets
+    float *d_colors = nullptr;
+    uint32_t *d_pixels = nullptr;
+    unsigned long long *d_counters = nullptr;
+    float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
+    size_t tables_cap = 0;        // in float4
+    rt::SceneTables scene{};
+    rt_camera cam{};
+    bool have_scene = false, have_cam = false;
+    int mode = RT_MODE_PARITY;
+    int current_sample = 0;
+    uint64_t launches = 0;
+    double last_ms = 0.0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int select_device(const rt_ctx *c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return RT_OK;
+}
+
+int upload_default_seeds(rt_ctx *c) {
+    const size_t count = 2 * (size_t)c->w * (size_t)c->h;
+    std::vector<uint32_t> host(count);
+    rt_default_seeds(host.data(), count);
+    HIP_TRY(hipMemcpy(c->d_seeds0, host.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_seeds, c->d_seeds0, count * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemset(c->d_colors, 0, 3 * (size_t)c->w * (size_t)c->h * sizeof(float)));
+    HIP_TRY(hipMemset(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
+    return RT_OK;
+}
+
+int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
+    if (!c->have_scene || !c->have_cam)
+        return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
+    if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
+    if (n_samples == 0 || c->local_rows == 0) return RT_OK;
+
+    rt::LaunchParams p{};
+    p.scene = c->scene;
+    p.cam = c->cam;
+    p.seeds = c->d_seeds;
+    p.colors = c->d_colors;
+    p.pixels = c->d_pixels;
+    p.counters = c->d_counters;
+    p.w = c->w;
+    p.h = c->h;
+    p.first_sample = c->current_sample;
+    p.n_samples = n_samples;
+    p.rank = c->rank;
+    p.nranks = c->nranks;
+    p.tile_rows = c->tile_rows;
+    p.local_rows = c->local_rows;
+    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true);
+    p.mat_in_lds = lds_all <= 64 * 1024;
+    const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0);
+
+    dim3 grid((unsigned)((c->w + rt::kTileW - 1) / rt::kTileW),
+              (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
+    hipError_t e = (c->mode == RT_MODE_FAST) ? rt::launch_fast(p, grid, lds, stream)
+                                             : rt::launch_parity(p, grid, lds, stream);
+    if (e != hipSuccess)
+        return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
+                    hipGetErrorString(e), grid.x, grid.y, lds);
+    c->current_sample += n_samples;
+    c->launches += 1;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err; }
+
+// used by rt_host.cpp (not part of the public header)
+void rt_host_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
+
+int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nranks,
+                      int tile_rows) {
+    if (!out) return fail(RT_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (w <= 0 || h <= 0) return fail(RT_ERR_ARG, "image size %dx%d", w, h);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(RT_ERR_ARG, "rank %d of %d", rank, nranks);
+    if (tile_rows <= 0 || tile_rows % rt::kTileH != 0)
+        return fail(RT_ERR_ARG, "tile_rows must be a positive multiple of %d", rt::kTileH);
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n_dev) return fail(RT_ERR_ARG, "device %d of %d", device, n_dev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device,
+                    prop.gcnArchName);
+
+    rt_ctx *c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(RT_ERR_ALLOC, "host allocation failed");
+    c->device = device;
+    c->w = w;
+    c->h = h;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->tile_rows = tile_rows;
+    const int n_tiles = (h + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int t = rank; t < n_tiles; t += nranks) {
+        const int r0 = t * tile_rows;
+        rows += (r0 + tile_rows <= h) ? tile_rows : (h - r0);
+    }
+    c->local_rows = rows;
+
+    int rc = select_device(c);
+    const size_t px = (size_t)w * (size_t)h;
+    auto alloc_all = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipMalloc(&c->d_seeds, 2 * px * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_seeds0, 2 * px * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_colors, 3 * px * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)));
+        HIP_TRY(rt::prepare_parity());
+        HIP_TRY(rt::prepare_fast());
+        return upload_default_seeds(c);
+    };
+    if (rc == RT_OK) rc = alloc_all();
+    if (rc != RT_OK) {
+        rt_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_create(rt_ctx **out, int w, int h) { return rt_create_sharded(out, w, h, 0, 0, 1, rt::kTileH); }
+
+void rt_destroy(rt_ctx *c) {
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(c->d_seeds);
+        (void)hipFree(c->d_seeds0);
+        (void)hipFree(c->d_colors);
+        (void)hipFree(c->d_pixels);
+        (void)hipFree(c->d_counters);
+        (void)hipFree(c->d_tables);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (count > 0 && !spheres) return fail(RT_ERR_ARG, "spheres is null");
+    if (count > RT_MAX_SPHERES) return fail(RT_ERR_ARG, "%u spheres > RT_MAX_SPHERES (%u)", count, RT_MAX_SPHERES);
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+
+    // host-side table build: strict binary32 (this file is compiled -ffp-contract=off)
+    std::vector<float4> geom(count), emis(count), colr(count), la, lb;
+    for (uint32_t i = 0; i < count; ++i) {
+        const rt_sphere &s = spheres[i];
+        geom[i] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);                     // .cl:184
+        float refl_bits;
+        int32_t refl = s.refl;
+        memcpy(&refl_bits, &refl, 4);
+        emis[i] = make_float4(s.e.x, s.e.y, s.e.z, refl_bits);
+        colr[i] = make_float4(s.c.x, s.c.y, s.c.z, s.rad);
+        if (!((s.e.x == 0.f) && (s.e.z == 0.f))) {                                     // .cl:135-138,266
+            la.push_back(make_float4(s.p.x, s.p.y, s.p.z, s.rad));
+            lb.push_back(make_float4(s.e.x, s.e.y, s.e.z,
+                                     4.f * 3.14159265358979323846f * s.rad * s.rad));  // .cl:297
+        }
+    }
+    const uint32_t nl = (uint32_t)la.size();
+    const size_t need = 3 * (size_t)count + 2 * (size_t)nl + 1;
+    // ordered after any launch still reading the old tables
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    if (need > c->tables_cap) {
+        (void)hipFree(c->d_tables);
+        c->d_tables = nullptr;
+        c->tables_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_tables, need * sizeof(float4)));
+        c->tables_cap = need;
+    }
+    float4 *base = c->d_tables;
+    float4 *d_geom = base, *d_emis = base + count, *d_colr = base + 2 * (size_t)count;
+    float4 *d_la = base + 3 * (size_t)count, *d_lb = d_la + nl;
+    if (count) {
+        HIP_TRY(hipMemcpy(d_geom, geom.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_emis, emis.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_colr, colr.data(), count * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    if (nl) {
+        HIP_TRY(hipMemcpy(d_la, la.data(), nl * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_lb, lb.data(), nl * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, count, nl };
+    if (rt::lds_bytes(count, nl, false) > 160 * 1024)
+        return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 160 KiB)", rt::lds_bytes(count, nl, false));
+    c->have_scene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
+    if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
+    c->cam = *cam;
+    c->have_cam = true;
+    return RT_OK;
+}
+
+int rt_set_mode(rt_ctx *c, int mode) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (mode != RT_MODE_PARITY && mode != RT_MODE_FAST) return fail(RT_ERR_ARG, "mode %d", mode);
+    c->mode = mode;
+    return RT_OK;
+}
+
+int rt_reset(rt_ctx *c) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipDeviceSynchronize());
+    c->current_sample = 0;
+    c->launches = 0;
+    c->last_ms = 0.0;
+    return upload_default_seeds(c);
+}
+
+int rt_reset_async(rt_ctx *c, void *hip_stream) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
+                           hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), st));
+    c->current_sample = 0;
+    return RT_OK;
+}
+
+int rt_render_async(rt_ctx *c, int n_samples, void *hip_stream) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    return launch(c, n_samples, (hipStream_t)hip_stream);
+}
+
+int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    rc = launch(c, n_samples, c->stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (out_host && c->local_rows > 0)
+        HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels, (size_t)c->local_rows * c->w * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms = ms;
+    return RT_OK;
+}
+
+int rt_device_pixels(rt_ctx *c, void **dptr, size_t *count) {
+    if (!c || !dptr || !count) return fail(RT_ERR_ARG, "null argument");
+    *dptr = c->d_pixels;
+    *count = (size_t)c->local_rows * (size_t)c->w;
+    return RT_OK;
+}
+
+int rt_local_rows(const rt_ctx *c) { return c ? c->local_rows : RT_ERR_ARG; }
+int rt_current_sample(const rt_ctx *c) { return c ? c->current_sample : RT_ERR_ARG; }
+
+int rt_read_colors(rt_ctx *c, float *out_host) {
+    if (!c || !out_host) return fail(RT_ERR_ARG, "null argument");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
+    HIP_TRY(hipMemcpy(out_host, c->d_colors, 3 * (size_t)c->w * c->h * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_read_seeds(rt_ctx *c, uint32_t *out_host) {
+    if (!c || !out_host) return fail(RT_ERR_ARG, "null argument");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
+    HIP_TRY(hipMemcpy(out_host, c->d_seeds, 2 * (size_t)c->w * c->h * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *c, rt_stats *out) {
+    if (!c || !out) return fail(RT_ERR_ARG, "null argument");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    unsigned long long v[8];
+    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
+    HIP_TRY(hipMemcpy(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost));
+    out->samples = v[0];
+    out->closest_rays = v[1];
+    out->shadow_rays = v[2];
+    out->sphere_tests = v[3];
+    out->rng_draws = v[4];
+    out->launches = c->launches;
+    out->last_kernel_ms = c->last_ms;
+    return RT_OK;
+}
+
+int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w, int h, int spp) {
+    if (!scene || !cam || !out) return fail(RT_ERR_ARG, "null argument");
+    if (spp < 0) return fail(RT_ERR_ARG, "spp < 0");
+    rt_ctx *c = nullptr;
+    int rc = rt_create(&c, w, h);
+    if (rc == RT_OK) rc = rt_set_scene(c, scene->spheres, scene->count);
+    if (rc == RT_OK) rc = rt_set_camera(c, cam);
+    if (rc == RT_OK) rc = rt_render_pass(c, out, spp);
+    rt_destroy(c);
+    return rc;
+}
+
+int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
+    if ((!in_host || !out_host) && n) return fail(RT_ERR_ARG, "null argument");
+    if (op < 0 || op > 5) return fail(RT_ERR_ARG, "op %d", op);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
+    if (n == 0) return RT_OK;
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipSetDevice(0));
+    HIP_TRY(hipMalloc(&d_in, n * sizeof(float)));
+    hipError_t e = hipMalloc(&d_out, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, in_host, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt::launch_eval_parity(op, d_in, d_out, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_eval: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// rt_device.h -- launch parameters shared by the host shim (rt_api.hip) and the two kernel
+// translation units (parity: no contraction; fast: contraction + hardware transcendentals).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_api.h"
+
+namespace rt {
+
+constexpr int kBlockThreads = 256;  // 4 wavefronts
+constexpr int kTileW = 32;          // block tile: 32 x 8 pixels, one 8x8 sub-tile per wavefront
+constexpr int kTileH = 8;
+constexpr int kMaxDepth = 8;        // .cl:320 (depth > 7 ends the path)
+
+// Sphere tables in HBM, written once by rt_set_scene and staged into LDS by every workgroup.
+//   geom[i] = { p.x, p.y, p.z, rad*rad }      closest-hit / any-hit loops read only this
+//   emis[i] = { e.x, e.y, e.z, bits(refl) }   read once per hit, for the sphere that was hit
+//   colr[i] = { c.x, c.y, c.z, rad }
+//   lightA[j] = { p.x, p.y, p.z, rad }         the j-th sphere, in scene order, whose emission
+//   lightB[j] = { e.x, e.y, e.z, 4*pi*rad*rad } passes the reference's zero test (.cl:135-138
+//                                              looks at x and z only): the light list that
+//                                              SampleLights (.cl:249-303) walks
+struct SceneTables {
+    const float4 *geom;
+    const float4 *emis;
+    const float4 *colr;
+    const float4 *lightA;
+    const float4 *lightB;
+    uint32_t n_spheres;
+    uint32_t n_lights;
+};
+
+struct LaunchParams {
+    SceneTables scene;
+    rt_camera cam;
+    uint32_t *seeds;        // [2*w*h], pair per pixel at gid = y*w + x        (.cl:570-571)
+    float *colors;          // [3*w*h], running average at (h-1-y)*w + x       (.cl:579)
+    uint32_t *pixels;       // [local_rows*w], packed RGBX of this rank's rows (.cl:594)
+    unsigned long long *counters;  // 5 x u64: samples, closest, shadow, tests, draws
+    int w, h;
+    int first_sample, n_samples;
+    int rank, nranks, tile_rows, local_rows;
+    int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
+};
+
+// LDS bytes the kernels need for a scene
+inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds) {
+    size_t b = (size_t)n_spheres * 16 + (size_t)n_lights * 32;
+    if (mat_in_lds) b += (size_t)n_spheres * 32;
+    return b;
+}
+
+hipError_t launch_parity(const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_fast(const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);
+hipError_t prepare_parity();    // raise the dynamic-LDS limit (called once per context)
+hipError_t prepare_fast();
+
+}  // namespace rt

@@ -1,0 +1,419 @@
+// rt_trace.inc.h -- the per-pixel path-trace kernel, included once per arithmetic mode.
+//
+//   RT_FAST = 0  (rt_kernel_parity.hip, -ffp-contract=off): every product, sum, quotient and
+//                square root is a separately rounded binary32 operation in the association
+//                order of the reference expression (RayTracing_Kernel.cl, cited ".cl:LINE");
+//                sin/cos/pow are the restated-libm set of rt_detmath.h.  Output is bit-equal
+//                to the reference kernel compiled as host C++.
+//   RT_FAST = 1  (rt_kernel_fast.hip, -ffp-contract=fast): same algorithm, fused multiply-
+//                adds, v_rcp/v_rsq/v_sqrt/v_sin/v_cos/v_exp/v_log.
+//
+// Mapping: one wavefront lane = one pixel; a 256-thread workgroup covers a 32x8 pixel tile,
+// each of its 4 wavefronts an 8x8 sub-tile (coherent primary rays, 32-byte store segments).
+// The sphere geometry table {centre, radius^2} is staged into LDS once per workgroup and read
+// back as wave-uniform (broadcast) ds_read_b128 in the closest-hit and any-hit loops.
+// The whole spp loop runs inside the launch: the seed pair, the running-average colour and
+// the path state stay in registers; HBM sees one seed read, one seed write, one colour write
+// and one packed-pixel write per pixel per launch (32 B/pixel).
+//
+// Lane-level path regeneration: lanes do not wait for each other at sample boundaries.  A
+// lane whose path ends accumulates its sample and starts its next camera ray in the very next
+// trip of the loop, so a wavefront only idles at the tail of the spp loop.  Each pixel still
+// consumes its own RNG stream in the reference order, so results do not depend on this.
+#include <hip/hip_runtime.h>
+
+#include "rt_detmath.h"
+#include "rt_device.h"
+
+#ifndef RT_FAST
+#error "define RT_FAST to 0 or 1"
+#endif
+
+namespace rt {
+namespace RT_NS {
+
+#define RT_EPS 0.01f                    /* .cl:68 */
+#define RT_PI 3.14159265358979323846f   /* .cl:69 */
+
+struct V3 {
+    float x, y, z;
+};
+
+RT_DEV V3 mk(float x, float y, float z) { return V3{ x, y, z }; }
+RT_DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 scale(V3 a, float k) { return mk(a.x * k, a.y * k, a.z * k); }
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // .cl:117-120
+RT_DEV V3 cross(V3 a, V3 b) {                                                        // .cl:128-131
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+RT_DEV float rt_sqrt(float x) {
+#if RT_FAST
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);       // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+#endif
+}
+RT_DEV float rt_rcp(float x) {
+#if RT_FAST
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f / x;
+#endif
+}
+RT_DEV float rt_div(float a, float b) {
+#if RT_FAST
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+RT_DEV V3 unit(V3 a) {                                                               // .cl:122-126
+#if RT_FAST
+    return scale(a, __builtin_amdgcn_rsqf(dot(a, a)));
+#else
+    return scale(a, 1.f / sqrtf(dot(a, a)));
+#endif
+}
+
+// .cl:354 sign(): +-1, zero keeps its sign, NaN -> 0
+RT_DEV float cl_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : (x != x ? 0.f : x)); }
+
+// .cl:143-169
+RT_DEV float next_random(uint32_t &s0, uint32_t &s1) {
+    s0 = 36969u * (s0 & 65535u) + (s0 >> 16);
+    s1 = 18000u * (s1 & 65535u) + (s1 >> 16);
+    uint32_t word = (s0 << 16) + s1;
+    float f = __uint_as_float((word & 0x007fffffu) | 0x40000000u);
+    return (f - 2.f) / 2.f;
+}
+
+// .cl:173-201.  g = {centre, radius^2}.  A negative discriminant makes sq NaN and every
+// comparison below false, which yields the reference's 0.
+RT_DEV float hit_distance(float4 g, V3 o, V3 d) {
+    V3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);
+    float b = dot(op, d);
+    float det = b * b - dot(op, op) + g.w;
+    float sq = rt_sqrt(det);
+    float t1 = b - sq;
+    float t2 = b + sq;
+    float t = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
+    return det < 0.f ? 0.f : t;
+}
+
+// .cl:34
+RT_DEV int to_int(float v) {
+    float c = fminf(fmaxf(v, 0.f), 1.f);
+#if RT_FAST
+    float g = fm_powf(c, 1.f / 2.2f);
+#else
+    float g = dm_powf(c, 1.f / 2.2f);
+#endif
+    return (int)(g * 255.f + .5f);
+}
+
+RT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const LaunchParams P) {
+    extern __shared__ float4 lds[];
+    const uint32_t n = P.scene.n_spheres;
+    const uint32_t n_lights = P.scene.n_lights;
+    float4 *s_geom = lds;
+    float4 *s_lightA = s_geom + n;           // {centre, radius}
+    float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
+    float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
+    float4 *s_colr = s_emis + n;             // {colour, radius}
+
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
+    for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
+        s_lightA[i] = P.scene.lightA[i];
+        s_lightB[i] = P.scene.lightB[i];
+    }
+    if (P.mat_in_lds) {
+        for (uint32_t i = tid; i < n; i += kBlockThreads) {
+            s_emis[i] = P.scene.emis[i];
+            s_colr[i] = P.scene.colr[i];
+        }
+    }
+    __syncthreads();
+    const float4 *m_emis = P.mat_in_lds ? s_emis : P.scene.emis;
+    const float4 *m_colr = P.mat_in_lds ? s_colr : P.scene.colr;
+
+    // ---- pixel of this lane ---------------------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63;
+    const int x = blockIdx.x * kTileW + wave * 8 + (lane & 7);
+    const int lrow = blockIdx.y * kTileH + (lane >> 3);
+    const int tile = lrow / P.tile_rows;
+    const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
+    const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
+
+    const size_t gid = (size_t)y * (size_t)P.w + (size_t)x;                 // .cl:560-563
+    const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;      // .cl:579
+
+    uint32_t s0 = 0, s1 = 0;
+    V3 acc = mk(0.f, 0.f, 0.f);
+    int s = P.first_sample;
+    const int s_end = valid ? P.first_sample + P.n_samples : P.first_sample;
+    if (valid) {
+        s0 = P.seeds[2 * gid];
+        s1 = P.seeds[2 * gid + 1];
+        if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
+    }
+
+    const float inv_w = rt_rcp((float)P.w);                                  // .cl:503-504
+    const float inv_h = rt_rcp((float)P.h);
+    const V3 cam_o = mk(P.cam.orig.x, P.cam.orig.y, P.cam.orig.z);
+    const V3 cam_d = mk(P.cam.dir.x, P.cam.dir.y, P.cam.dir.z);
+    const V3 cam_x = mk(P.cam.x.x, P.cam.x.y, P.cam.x.z);
+    const V3 cam_y = mk(P.cam.y.x, P.cam.y.y, P.cam.y.z);
+
+    uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
+    unsigned long long c_tests = 0;   // per-ray additions only (never inside a sphere loop)
+
+    // ---- path state -----------------------------------------------------------------
+    V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
+    V3 thr = mk(1.f, 1.f, 1.f), rad = mk(0.f, 0.f, 0.f);
+    int depth = 0;
+    bool after_specular = true;
+    bool need_ray = true;
+
+    for (;;) {
+        if (need_ray) {
+            if (s >= s_end) break;
+            // ---- camera ray, .cl:494-549 ----
+            float j1 = next_random(s0, s1) - 0.5f;
+            float j2 = next_random(s0, s1) - 0.5f;
+            c_draws += 2;
+            float kcx = ((float)x + j1) * inv_w - 0.5f;
+            float kcy = ((float)y + j2) * inv_h - 0.5f;
+            V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x,
+                       cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
+                       cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
+            o = add(scale(rd, 0.1f), cam_o);
+            d = unit(rd);
+            thr = mk(1.f, 1.f, 1.f);
+            rad = mk(0.f, 0.f, 0.f);
+            depth = 0;
+            after_specular = true;
+            need_ray = false;
+        }
+
+        // ---- closest hit, .cl:215-232: wave-uniform sweep, LDS broadcast reads ----
+        float t = 1e20f;
+        uint32_t id = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            float hdist = hit_distance(s_geom[i], o, d);
+            if (hdist != 0.f && hdist < t) {
+                t = hdist;
+                id = i;
+            }
+        }
+        c_closest += 1;
+        c_tests += n;
+
+        bool path_done = false;
+        if (!(t < 1e20f)) {
+            path_done = true;                                              // miss, .cl:327-330
+        } else {
+            const float4 ge = s_geom[id];
+            const float4 em4 = m_emis[id];
+            const float4 co4 = m_colr[id];
+            const V3 em = mk(em4.x, em4.y, em4.z);
+            const V3 col = mk(co4.x, co4.y, co4.z);
+            const int refl = __float_as_int(em4.w);
+
+            V3 hp = add(o, scale(d, t));                                   // .cl:338-340
+            V3 nrm = unit(sub(hp, mk(ge.x, ge.y, ge.z)));                  // .cl:345-347
+            float dp = dot(nrm, d);
+            V3 nl = scale(nrm, -1.f * cl_sign(dp));                        // .cl:354-355
+
+            if (!((em.x == 0.f) && (em.z == 0.f))) {                       // .cl:358-368
+                if (after_specular) rad = add(rad, mul(thr, scale(em, fabsf(dp))));
+                path_done = true;
+            } else if (refl == RT_DIFF) {                                  // .cl:370-412
+                after_specular = false;
+                thr = mul(thr, col);
+
+                // ---- next-event estimation, .cl:249-303 ----
+                V3 ld = mk(0.f, 0.f, 0.f);
+                for (uint32_t j = 0; j < n_lights; ++j) {
+                    const float4 la = s_lightA[j];
+                    const float4 lb = s_lightB[j];
+                    float u1 = next_random(s0, s1);
+                    float u2 = next_random(s0, s1);
+                    c_draws += 2;
+                    float zc = 1.f - 2.f * u1;                             // .cl:203-213
+                    float ring = rt_sqrt(fmaxf(0.f, 1.f - zc * zc));
+                    float sphi, cphi;
+#if RT_FAST
+                    fm_sincos_turns(u2, sphi, cphi);
+#else
+                    dm_sincosf((2.f * RT_PI) * u2, sphi, cphi);
+#endif
+                    V3 us = mk(ring * cphi, ring * sphi, zc);
+                    V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
+                    V3 sd = sub(on_light, hp);
+                    float len = rt_sqrt(dot(sd, sd));
+                    sd = scale(sd, rt_rcp(len));
+                    float wo = dot(sd, us);
+                    if (wo > 0.f) continue;                                // far side of the light
+                    wo = -wo;
+                    float wi = dot(sd, nl);
+                    if (wi > 0.f) {
+                        // ---- shadow ray, any hit, .cl:234-247 ----
+                        const float max_t = len - RT_EPS;
+                        bool blocked = false;
+                        c_shadow += 1;
+                        uint32_t i = 0;
+                        for (; i < n; ++i) {
+                            float hdist = hit_distance(s_geom[i], hp, sd);
+                            if (hdist != 0.f && hdist < max_t) {
+                                blocked = true;
+                                break;
+                            }
+                        }
+                        c_tests += blocked ? i + 1 : n;
+                        if (!blocked) {
+                            float k = rt_div(lb.w * wi * wo, len * len);   // .cl:297
+                            ld = add(ld, scale(mk(lb.x, lb.y, lb.z), k));
+                        }
+                    }
+                }
+                rad = add(rad, mul(thr, ld));                              // .cl:377-378
+
+                // ---- cosine-weighted bounce, .cl:383-411 ----
+                float u = next_random(s0, s1);
+                float r2 = next_random(s0, s1);
+                c_draws += 2;
+                float r2s = rt_sqrt(r2);
+                V3 w = nl;
+                V3 a = (fabsf(w.x) > .1f) ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
+                V3 uu = unit(cross(a, w));
+                V3 vv = cross(w, uu);
+                float s1v, c1v;
+#if RT_FAST
+                fm_sincos_turns(u, s1v, c1v);
+#else
+                dm_sincosf((2.f * RT_PI) * u, s1v, c1v);
+#endif
+                V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
+                nd = add(nd, scale(w, rt_sqrt(1 - r2)));
+                o = hp;
+                d = nd;
+            } else {
+                // reflection direction shared by SPEC and REFR, .cl:416-419 / 428-431
+                V3 rfl = sub(d, scale(nrm, 2.f * dot(nrm, d)));
+                after_specular = true;
+                if (refl == RT_SPEC) {                                     // .cl:413-424
+                    thr = mul(thr, col);
+                    o = hp;
+                    d = rfl;
+                } else {                                                   // .cl:425-489
+                    bool into = dot(nrm, nl) > 0.f;
+                    const float nc = 1.f, nt = 1.52f;
+                    float nnt = into ? nc / nt : nt / nc;
+                    float ddn = dot(d, nl);
+                    float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
+                    if (cos2t < 0.f) {                                     // total internal reflection
+                        thr = mul(thr, col);
+                        o = hp;
+                        d = rfl;
+                    } else {
+                        float kk = (into ? 1.f : -1.f) * (ddn * nnt + rt_sqrt(cos2t));
+                        V3 td = unit(sub(scale(d, nnt), scale(nrm, kk)));
+                        const float fa = nt - nc, fb = nt + nc;
+                        const float R0 = fa * fa / (fb * fb);
+                        float c = 1 - (into ? -ddn : dot(td, nrm));
+                        float Re = R0 + (1 - R0) * c * c * c * c * c;
+                        float Tr = 1.f - Re;
+                        float Pr = .25f + .5f * Re;
+                        float RP = rt_div(Re, Pr);
+                        float TP = rt_div(Tr, 1.f - Pr);
+                        float pick = next_random(s0, s1);
+                        c_draws += 1;
+                        if (pick < Pr) {
+                            thr = mul(scale(thr, RP), col);
+                            d = rfl;
+                        } else {
+                            thr = mul(scale(thr, TP), col);
+                            d = td;
+                        }
+                        o = hp;
+                    }
+                }
+            }
+            depth += 1;
+            if (depth >= kMaxDepth) path_done = true;                      // .cl:320
+        }
+
+        if (path_done) {
+            // ---- running average, .cl:580-589 ----
+            if (s == 0) {
+                acc = rad;
+            } else {
+                float k1 = (float)s;
+                float k2 = rt_rcp((float)s + 1.f);
+                acc = mk((acc.x * k1 + rad.x) * k2, (acc.y * k1 + rad.y) * k2,
+                         (acc.z * k1 + rad.z) * k2);
+            }
+            s += 1;
+            need_ray = true;
+        }
+    }
+
+    if (valid && P.n_samples > 0) {
+        P.colors[3 * ci] = acc.x;
+        P.colors[3 * ci + 1] = acc.y;
+        P.colors[3 * ci + 2] = acc.z;
+        P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =                  // .cl:594-596
+            (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+        P.seeds[2 * gid] = s0;                                             // .cl:598-599
+        P.seeds[2 * gid + 1] = s1;
+    }
+
+    // ---- exact work counters: one atomic per counter per wavefront ----
+    uint32_t n_done = valid ? (uint32_t)P.n_samples : 0u;
+    uint32_t t_samples = wave_sum(n_done);
+    uint32_t t_closest = wave_sum(c_closest);
+    uint32_t t_shadow = wave_sum(c_shadow);
+    uint32_t t_draws = wave_sum(c_draws);
+    unsigned long long tests64 = c_tests;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
+    if (lane == 0) {
+        atomicAdd(&P.counters[0], (unsigned long long)t_samples);
+        atomicAdd(&P.counters[1], (unsigned long long)t_closest);
+        atomicAdd(&P.counters[2], (unsigned long long)t_shadow);
+        atomicAdd(&P.counters[3], tests64);
+        atomicAdd(&P.counters[4], (unsigned long long)t_draws);
+    }
+}
+
+#if !RT_FAST
+// scalar building blocks, for rt_debug_eval
+extern "C" __global__ void rt_eval_kernel(int op, const float *in, float *out, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float v = in[i], r = 0.f, t;
+    switch (op) {
+        case 0: dm_sincosf(v, r, t); break;
+        case 1: dm_sincosf(v, t, r); break;
+        case 2: r = dm_powf(v, 1.f / 2.2f); break;
+        case 3: r = 1.f / v; break;
+        case 4: r = sqrtf(v); break;
+        case 5: r = (float)to_int(v); break;
+        default: break;
+    }
+    out[i] = r;
+}
+#endif
+
+}  // namespace RT_NS
+}  // namespace rt

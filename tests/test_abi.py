@@ -1,0 +1,130 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/rt_api.h
+declares, validates arguments, fails loudly without a GPU, and its host helpers agree with the
+oracle and with the reference-generated pins.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from raytracing_simple_amd import api, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpu_present():
+    return os.path.exists("/dev/kfd")
+
+
+def test_library_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "rt_api.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+    assert declared == sorted(api.SYMBOLS)
+    lib = api.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_reference_sizes():
+    assert api.SPHERE_DT.itemsize == 44          # Sphere.hpp:11-15
+    assert api.CAMERA_FLOATS * 4 == 60           # Camera.hpp:7-14
+    assert C.sizeof(api.Stats) == 7 * 8
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-device failure path")
+def test_fails_loudly_without_device():
+    with pytest.raises(api.RtError) as e:
+        api.RtContext(64, 64)
+    assert e.value.code == -2
+    with pytest.raises(api.RtError):
+        api.render(host.demo_scene(), host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 8, 8), 8, 8, 1)
+    with pytest.raises(api.RtError):
+        api.debug_eval(0, np.zeros(4, np.float32))
+
+
+def test_argument_validation_needs_no_device():
+    lib = api.load_library()
+    h = C.c_void_p()
+    assert lib.rt_create(C.byref(h), 0, 10) == -1
+    assert lib.rt_create_sharded(C.byref(h), 16, 16, 0, 2, 2, 8) == -1       # rank >= nranks
+    assert lib.rt_create_sharded(C.byref(h), 16, 16, 0, 0, 2, 12) == -1      # tile_rows % 8
+    assert b"tile_rows" in lib.rt_last_error()
+    assert lib.rt_render(None, None, None, 4, 4, 1) == -1
+    assert lib.rt_set_scene(None, None, 0) == -1
+    assert lib.rt_local_rows(None) == -1
+
+
+def test_default_seeds_equal_oracle_and_pins(golden_dir):
+    pins = np.load(os.path.join(golden_dir, "host_pins.npz"))
+    mine = host.default_seeds(2 * 64 * 64)
+    assert np.array_equal(mine, pins["seeds_first_8192"])
+    assert np.array_equal(host.default_seeds(2 * 800 * 600), O.seeds(800, 600))
+
+
+def test_compute_camera_equals_oracle_and_pins(golden_dir):
+    pins = np.load(os.path.join(golden_dir, "host_pins.npz"))
+    for (w, h) in [(256, 256), (800, 600), (1920, 1080), (3840, 2160)]:
+        cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+        assert np.array_equal(cam.view(np.uint32), pins[f"camera_{w}x{h}"].view(np.uint32))
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        o, t = rng.normal(size=3) * 50, rng.normal(size=3) * 50
+        w, h = int(rng.integers(1, 4000)), int(rng.integers(1, 3000))
+        a = host.compute_camera(o, t, w, h)
+        b = O.camera(o.astype(np.float32), t.astype(np.float32), w, h)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_demo_scene_bytes(golden_dir):
+    z = np.load(os.path.join(golden_dir, "c1_demo_256x256_1spp.npz"))
+    assert host.demo_scene().tobytes() == z["spheres"].tobytes()
+
+
+def test_scene_reader_roundtrip_and_doubling(tmp_path):
+    sph = O.demo_spheres()
+    p = tmp_path / "t.scn"
+    host.write_scene(p, sph, (1.5, 2, 3), (4, 5, 6.25))
+    got, o, t = host.read_scene(p, reference_doubling=False)
+    assert got.tobytes() == sph.view(api.SPHERE_DT).tobytes() and o == (1.5, 2.0, 3.0) and t == (4.0, 5.0, 6.25)
+    dbl, _, _ = host.read_scene(p, reference_doubling=True)
+    assert len(dbl) == 12 and dbl[:6].tobytes() == bytes(6 * 44) and dbl[6:].tobytes() == got.tobytes()
+
+
+def test_scene_reader_errors(tmp_path):
+    with pytest.raises(api.RtError, match="Failed to open"):
+        host.read_scene(tmp_path / "missing.scn")
+    p = tmp_path / "bad.scn"
+    p.write_text("camera 1 2 3 4 5\nsize 1\n")
+    with pytest.raises(api.RtError, match="camera"):
+        host.read_scene(p)
+    p.write_text("camera 1 2 3 4 5 6\nsize 1\nsphere 1  0 0 0  0 0 0  1 1 1  7\n")
+    with pytest.raises(api.RtError, match="material"):
+        host.read_scene(p)
+    p.write_text("camera 1 2 3 4 5 6\nsize 2\nsphere 1  0 0 0  0 0 0  1 1 1  0\n")
+    with pytest.raises(api.RtError, match="sphere #1"):
+        host.read_scene(p)
+    p.write_text("camera 1 2 3 4 5 6\nsize 0\n")
+    got, _, _ = host.read_scene(p)
+    assert len(got) == 0
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="reference loader exists only in the build container")
+def test_scene_reader_equals_reference_loader_on_shipped_scenes():
+    d = os.path.join(O.REF_ROOT, "SimpleRT", "Scene")
+    for name in sorted(os.listdir(d)):
+        want, wo, wt = O.ref_read_scene(os.path.join(d, name), cap=16384)
+        got, go, gt = host.read_scene(os.path.join(d, name), reference_doubling=True)
+        assert got.tobytes() == want.tobytes(), name
+        assert go == wo and gt == wt
+
+
+def test_ppm_writer_flips_rows(tmp_path):
+    px = np.arange(6, dtype=np.uint32).reshape(3, 2)      # row 0 = bottom
+    host.write_ppm(tmp_path / "a.ppm", px, 2, 3)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n2 3\n255\n")
+    body = np.frombuffer(raw[len(b"P6\n2 3\n255\n"):], np.uint8).reshape(3, 2, 3)
+    assert body[0, 0, 0] == 4 and body[2, 1, 0] == 1       # top row of the file = buffer row 2

@@ -1,0 +1,256 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and against the committed
+reference outputs.  Integer results (pixels, seeds, counters) and the binary32 colour plane
+must be BIT-EXACT in parity mode; fast mode is gated by PSNR >= 50 dB (north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from raytracing_simple_amd import api, host, scenes
+from raytracing_simple_amd import dist as rdist
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+               if not p.endswith("host_pins.npz"))
+
+
+def _gpu(spheres, cam, w, h, spp, mode=api.RT_MODE_PARITY, **kw):
+    with api.RtContext(w, h, **kw) as ctx:
+        ctx.set_scene(spheres)
+        ctx.set_camera(cam)
+        ctx.set_mode(mode)
+        px = ctx.render_pass(spp)
+        return {"pixels": px, "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+
+
+def _assert_same(got, want, stats=True):
+    assert np.array_equal(got["pixels"], want["pixels"])
+    assert np.array_equal(got["colors"].view(np.uint32), want["colors"].view(np.uint32))
+    assert np.array_equal(got["seeds"], want["seeds"])
+    if stats:
+        g, o = got["stats"], want["stats"]
+        assert (g["samples"], g["closest_rays"], g["shadow_rays"], g["sphere_tests"], g["rng_draws"]) == \
+               (o["samples"], o["closest_calls"], o["shadow_calls"], o["sphere_tests"], o["rng_draws"])
+
+
+# ---- C1 and every reference-generated fixture ------------------------------------------------
+def test_c1_headline_call_is_bit_exact():
+    """BASELINE config 1: Demo scene, 256x256, 1 spp, default seeds, through rt_render()."""
+    z = np.load(os.path.join(GOLDEN, "c1_demo_256x256_1spp.npz"))
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 256, 256)
+    px = api.render(host.demo_scene(), cam, 256, 256, 1)
+    assert np.array_equal(px, z["pixels"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_fixture_bit_exact(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    w, h, spp = int(z["w"]), int(z["h"]), int(z["spp"])
+    got = _gpu(z["spheres"], z["camera"], w, h, spp)
+    assert np.array_equal(got["pixels"], z["pixels"])
+    assert np.array_equal(got["colors"].view(np.uint32), z["colors"].view(np.uint32))
+    assert O.fnv(got["seeds"]) == str(z["fnv_seeds"])
+
+
+# ---- seeded inputs against the oracle ---------------------------------------------------------
+@pytest.mark.parametrize("maker,w,h,spp", [
+    (lambda: scenes.random_spheres(96), 96, 64, 4),
+    (lambda: scenes.demo_plus(16), 120, 72, 6),
+    (lambda: scenes.mirror_box(64), 64, 64, 4),
+    (lambda: scenes.random_spheres(1024), 64, 40, 2),
+])
+def test_synthetic_scenes_bit_exact_vs_oracle(maker, w, h, spp):
+    sph, orig, target = maker()
+    cam = host.compute_camera(orig, target, w, h)
+    _assert_same(_gpu(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp))
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (33, 17), (64, 9), (31, 8)])
+def test_ragged_sizes(w, h):
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    _assert_same(_gpu(sph, cam, w, h, 3), O.render(sph, cam, w, h, 3))
+
+
+def test_empty_scene_and_zero_samples():
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 40, 24)
+    empty = np.zeros(0, api.SPHERE_DT)
+    _assert_same(_gpu(empty, cam, 40, 24, 2), O.render(empty, cam, 40, 24, 2))
+    with api.RtContext(40, 24) as ctx:
+        ctx.set_scene(host.demo_scene())
+        ctx.set_camera(cam)
+        px = ctx.render_pass(0)
+        assert not px.any() and ctx.current_sample == 0
+        assert np.array_equal(ctx.read_seeds(), O.seeds(40, 24))
+
+
+def test_zero_radius_phantom_spheres():
+    """What readScene's doubling produces: N zeroed spheres in front of the real ones."""
+    sph = np.concatenate([np.zeros(6, api.SPHERE_DT), host.demo_scene()])
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 80, 60)
+    _assert_same(_gpu(sph, cam, 80, 60, 4), O.render(sph, cam, 80, 60, 4))
+
+
+def test_large_scene_materials_outside_lds():
+    """> 1365 spheres: the material tables no longer fit 64 KiB of LDS and are read from HBM."""
+    sph, orig, target = scenes.random_spheres(1600)
+    cam = host.compute_camera(orig, target, 48, 32)
+    _assert_same(_gpu(sph, cam, 48, 32, 1), O.render(sph, cam, 48, 32, 1))
+
+
+def test_many_lights():
+    sph, orig, target = scenes.demo_plus(24)
+    sph = sph.copy()
+    sph["e"][8:16] = (3.0, 2.0, 1.0)          # eight more emitters
+    sph["e"][16] = (0.0, 5.0, 0.0)            # emission the reference's zero test ignores (x == z == 0)
+    cam = host.compute_camera(orig, target, 72, 48)
+    _assert_same(_gpu(sph, cam, 72, 48, 3), O.render(sph, cam, 72, 48, 3))
+
+
+# ---- pass semantics ------------------------------------------------------------------------------
+def test_progressive_passes_equal_one_launch():
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64)
+    want = O.render(sph, cam, 96, 64, 9)
+    with api.RtContext(96, 64) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        for n in (1, 1, 3, 4):
+            px = ctx.render_pass(n)
+        assert ctx.current_sample == 9
+        got = {"pixels": px, "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        _assert_same(got, want)
+        ctx.reset()
+        assert ctx.current_sample == 0
+        px2 = ctx.render_pass(9)
+        assert np.array_equal(px2, want["pixels"])
+
+
+def test_config_mirror_runs_reference_pass_loop():
+    from raytracing_simple_amd import SupportType, createConfig, selectType
+    cfg = createConfig(64, 48, selectType(2))
+    assert selectType(0) is SupportType.OpenCL and selectType(7) is SupportType.Default
+    cfg.sceneSetup(host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET)
+    cfg.updateCamera()
+    pixels = cfg.getPixels()
+    for _ in range(3):
+        text = cfg.updateRendering()
+    assert "pass 3" in text and cfg.mCurrentSample == 3
+    assert cfg.getPixels() is pixels                       # stable buffer, as SetupGL.cpp:85 needs
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 64, 48)
+    assert np.array_equal(pixels, O.render(host.demo_scene(), cam, 64, 48, 3)["pixels"])
+    cfg.close()
+    with pytest.raises(RuntimeError, match="Unsupported Framework Type"):
+        createConfig(8, 8, selectType(0))
+
+
+# ---- sharding ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nranks,tile_rows", [(2, 8), (3, 8), (4, 16), (8, 8)])
+def test_row_tile_shards_reassemble_to_the_unsharded_image(nranks, tile_rows):
+    w, h, spp = 72, 100, 3
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    parts, total = [], {}
+    for r in range(nranks):
+        with api.RtContext(w, h, rank=r, nranks=nranks, tile_rows=tile_rows) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            parts.append(ctx.render_pass(spp))
+            assert ctx.local_rows == len(api.local_rows_of(h, r, nranks, tile_rows))
+            for k, v in ctx.stats().items():
+                total[k] = total.get(k, 0) + v
+    assert np.array_equal(rdist.assemble_numpy(parts, h, w, nranks, tile_rows), want["pixels"])
+    assert total["sphere_tests"] == want["stats"]["sphere_tests"]
+    assert total["shadow_rays"] == want["stats"]["shadow_calls"]
+
+
+# ---- scalar building blocks ----------------------------------------------------------------------
+def test_device_scalar_ops_bit_exact():
+    lib = O.oracle()
+    rng = np.random.default_rng(11)
+    u = (rng.integers(0, 1 << 23, 200000).astype(np.float32) * np.float32(2.0 ** -23))
+    x = np.float32(2.0 * np.float32(3.14159265358979323846)) * u
+    x = np.concatenate([x, np.float32([0, 1e-5, 2e-4, 0.7853981, 0.7853982, 1.5707964, 3.1415927, 6.2831855])])
+    want_s = np.array([lib.om_sinf(float(v)) for v in x], np.float32)
+    want_c = np.array([lib.om_cosf(float(v)) for v in x], np.float32)
+    assert np.array_equal(api.debug_eval(0, x).view(np.uint32), want_s.view(np.uint32))
+    assert np.array_equal(api.debug_eval(1, x).view(np.uint32), want_c.view(np.uint32))
+
+    b = np.concatenate([rng.random(200000, dtype=np.float32), (rng.random(50000) ** 12).astype(np.float32),
+                        np.float32([0, 1, 1e-45, 1e-39, 1e-38, 0.5, 0.99999994])])
+    want_p = np.array([lib.om_gammaf(float(v)) for v in b], np.float32)
+    assert np.array_equal(api.debug_eval(2, b).view(np.uint32), want_p.view(np.uint32))
+
+    # IEEE division and square root, denormals included
+    v = np.concatenate([rng.random(200000, dtype=np.float32) * np.float32(1e6),
+                        (rng.random(100000) * 1e-38).astype(np.float32),
+                        np.float32([1e-45, 1e-40, 3e38, 1.0, 2.0, 1e20])])
+    with np.errstate(all="ignore"):
+        assert np.array_equal(api.debug_eval(3, v).view(np.uint32), (np.float32(1) / v).view(np.uint32))
+        assert np.array_equal(api.debug_eval(4, v).view(np.uint32), np.sqrt(v).view(np.uint32))
+    c = np.concatenate([rng.random(100000, dtype=np.float32) * np.float32(1.2) - np.float32(0.1),
+                        np.float32([np.nan, -1, 0, 1, 2, 12])])
+    want_i = np.array([lib.orc_to_int(float(t)) for t in c], np.float32)
+    assert np.array_equal(api.debug_eval(5, c), want_i)
+
+
+# ---- fast mode -----------------------------------------------------------------------------------
+def test_fast_mode_psnr_gate():
+    w = h = 256
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    ref = O.render(sph, cam, w, h, 64)["pixels"]
+    fast = _gpu(sph, cam, w, h, 64, mode=api.RT_MODE_FAST)["pixels"]
+    assert host.psnr(fast, ref) >= 50.0            # north_star: PSNR >= 50 dB for multi-spp
+
+
+# ---- full BASELINE size, size-independent properties --------------------------------------------
+def test_full_size_1080p_64spp_properties():
+    """Config C2.  The oracle would need minutes here, so: determinism, shard-union == whole,
+    exact counter identities, and the 1-spp prefix against the oracle on a row band."""
+    w, h, spp = 1920, 1080, 64
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        a = ctx.render_pass(spp)
+        st = ctx.stats()
+        seeds_a = ctx.read_seeds()
+        ctx.reset()
+        b = ctx.render_pass(spp)
+        assert np.array_equal(a, b)                                   # idempotent
+    assert st["samples"] == w * h * spp
+    assert st["closest_rays"] >= st["samples"] and st["sphere_tests"] >= 6 * st["closest_rays"]
+    # 1.939 closest-hit + 0.334 shadow rays per sample at 1080p
+    assert abs(st["closest_rays"] / st["samples"] - 1.939) < 0.01
+    assert abs(st["shadow_rays"] / st["samples"] - 0.334) < 0.01
+    parts = []
+    for r in range(2):
+        with api.RtContext(w, h, rank=r, nranks=2, tile_rows=8) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            parts.append(ctx.render_pass(spp))
+    assert np.array_equal(rdist.assemble_numpy(parts, h, w, 2, 8), a)  # partition-invariant
+    # every seed pair advanced, none collapsed to the generator's fixed point
+    assert (seeds_a != O.seeds(w, h)).mean() > 0.999
+    # fast mode against parity mode at full size
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_mode(api.RT_MODE_FAST)
+        f = ctx.render_pass(spp)
+    assert host.psnr(f, a) >= 50.0
+
+
+def test_full_size_single_pass_vs_oracle():
+    """1920x1080, 1 spp: the oracle finishes this in about a second on 8 threads."""
+    w, h = 1920, 1080
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    _assert_same(_gpu(sph, cam, w, h, 1), O.render(sph, cam, w, h, 1, threads=16))
