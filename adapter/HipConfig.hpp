@@ -1,0 +1,41 @@
+// HipConfig.hpp -- the reference-side binding: a `Config` backend (SimpleRT/include/Config.hpp:11-40)
+// that renders through the C ABI of include/rt_api.h instead of OpenCL.  It occupies the slot the
+// reference leaves unimplemented: SupportType::Default, framework ID 2 (Config.cpp:63-65,99-110).
+//
+// Compiled only inside a checkout of the reference (it includes the reference's own headers);
+// INTEGRATION.md lists the three edits the reference needs (factory case, CMake, link line).
+#ifndef HIP_CONFIG_HPP
+#define HIP_CONFIG_HPP
+
+#include <vector>
+
+#include "Camera.hpp"   // reference headers
+#include "Config.hpp"
+#include "Sphere.hpp"
+#include "Vec.hpp"
+
+#include "rt_api.h"
+
+class HipConfig : public Config {
+public:
+    HipConfig(int width, int height);
+    ~HipConfig() override;
+
+    void sceneSetup(const std::vector<Sphere>& spheres, Vec orig, Vec target) override;
+    void updateCamera() override;
+    unsigned* getPixels() override;
+
+private:
+    void setArguments() override;   // nothing to bind: the context holds the arguments
+    void execute() override;        // one pass = rt_render_pass(ctx, pPixels, 1)
+    void allocateBuffer() override;
+    void freeBuffer() override;
+
+    [[noreturn]] void die(const char* what) const;   // the reference's print-and-exit policy
+
+    rt_ctx* ctx = nullptr;
+    unsigned* pPixels = nullptr;    // stable for the life of the object (SetupGL.cpp:85 keeps it)
+    Camera camera{};
+};
+
+#endif

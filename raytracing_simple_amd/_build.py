@@ -61,7 +61,22 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    build_harness(cc, force, verbose)
     return OUT
+
+
+def build_harness(cc, force=False, verbose=False):
+    """tools/rt_bench: the headless C++ host (the reference's Main.cpp without the window)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tools", "rt_bench.cpp")
+    exe = os.path.join(HERE, "rt_bench")
+    if force or _stale(exe, [src, OUT, os.path.join(root, "include", "rt_api.h")]):
+        cmd = [cc, "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-o", exe,
+               "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return exe
 
 
 if __name__ == "__main__":

@@ -1,0 +1,116 @@
+// rt_bench.cpp -- headless C++ host for the HIP render path: what the reference's Main.cpp
+// does (SimpleRT/src/Main.cpp:18-113) minus the GLUT window, with an image writer instead.
+//
+//   rt_bench <framework ID> <CPU/GPU (0/1)> <mem (0/1/2)> [scene.scn]
+//            [--w W] [--h H] [--spp N] [--passes-per-launch K] [--mode parity|fast]
+//            [--no-doubling] [--out frame.ppm]
+//
+// The four positional arguments are the reference's; only framework ID 2 (the slot
+// Config.cpp:63-65 leaves empty) is served, GPU = 1, memory type 0 (Buffer).
+// Prints one JSON line with frame time and ray throughput.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_api.h"
+
+static int die(const char* what) {
+    fprintf(stderr, "%s: %s\n", what, rt_last_error());
+    return 1;
+}
+
+static bool write_ppm(const std::string& path, const std::vector<uint32_t>& px, int w, int h) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "P6\n%d %d\n255\n", w, h);
+    std::vector<unsigned char> row(static_cast<size_t>(w) * 3);
+    for (int y = h - 1; y >= 0; --y) {          // buffer row 0 is the bottom of the image
+        for (int x = 0; x < w; ++x) {
+            uint32_t p = px[static_cast<size_t>(y) * w + x];
+            row[3 * x] = p & 255;
+            row[3 * x + 1] = (p >> 8) & 255;
+            row[3 * x + 2] = (p >> 16) & 255;
+        }
+        fwrite(row.data(), 1, row.size(), f);
+    }
+    fclose(f);
+    return true;
+}
+
+int main(int argc, char** argv) {
+    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY;   // SetupGL.cpp:32-33
+    bool doubling = true;
+    std::string out, scene_path;
+    std::vector<const char*> pos;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
+        if (a == "--w") w = atoi(next());
+        else if (a == "--h") h = atoi(next());
+        else if (a == "--spp") spp = atoi(next());
+        else if (a == "--passes-per-launch") per_launch = atoi(next());
+        else if (a == "--mode") mode = strcmp(next(), "fast") == 0 ? RT_MODE_FAST : RT_MODE_PARITY;
+        else if (a == "--no-doubling") doubling = false;
+        else if (a == "--out") out = next();
+        else pos.push_back(argv[i]);
+    }
+    if (!pos.empty() && atoi(pos[0]) != 2) {
+        fprintf(stderr, "Unsupported Framework Type (this host serves framework ID 2 = HIP)\n");
+        return 1;
+    }
+    if (pos.size() >= 3 && atoi(pos[2]) != 0) {
+        fprintf(stderr, "Unsupported Memory Type\n");
+        return 1;
+    }
+    if (pos.size() >= 4) scene_path = pos[3];
+
+    std::vector<rt_sphere> spheres(16384);
+    uint32_t n = 0;
+    rt_camera cam{};
+    if (!scene_path.empty()) {
+        if (rt_read_scene(scene_path.c_str(), spheres.data(), (uint32_t)spheres.size(), &n, &cam.orig,
+                          &cam.target, doubling ? 1 : 0) != RT_OK)
+            return die("readScene");
+    } else {                                        // Main.cpp:80-86
+        n = (uint32_t)rt_demo_scene(spheres.data(), (uint32_t)spheres.size());
+        cam.orig = rt_vec3{ 20.f, 100.f, 120.f };
+        cam.target = rt_vec3{ 0.f, 25.f, 0.f };
+    }
+    rt_compute_camera(&cam, w, h);
+
+    rt_ctx* ctx = nullptr;
+    if (rt_create(&ctx, w, h) != RT_OK) return die("rt_create");
+    if (rt_set_scene(ctx, spheres.data(), n) != RT_OK) return die("rt_set_scene");
+    if (rt_set_camera(ctx, &cam) != RT_OK) return die("rt_set_camera");
+    if (rt_set_mode(ctx, mode) != RT_OK) return die("rt_set_mode");
+
+    std::vector<uint32_t> px(static_cast<size_t>(w) * h);
+    if (per_launch <= 0) per_launch = spp;
+    auto t0 = std::chrono::steady_clock::now();
+    double kernel_ms = 0.0;
+    for (int done = 0; done < spp;) {
+        int k = (spp - done < per_launch) ? spp - done : per_launch;
+        if (rt_render_pass(ctx, px.data(), k) != RT_OK) return die("rt_render_pass");
+        rt_stats st;
+        rt_get_stats(ctx, &st);
+        kernel_ms += st.last_kernel_ms;
+        done += k;
+    }
+    double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rt_stats st;
+    if (rt_get_stats(ctx, &st) != RT_OK) return die("rt_get_stats");
+    if (!out.empty() && !write_ppm(out, px, w, h)) fprintf(stderr, "cannot write %s\n", out.c_str());
+
+    const double rays = (double)(st.samples + st.shadow_rays);
+    printf("{\"spheres\": %u, \"w\": %d, \"h\": %d, \"spp\": %d, \"launches\": %llu, \"kernel_ms\": %.4f, "
+           "\"wall_ms_with_readback\": %.4f, \"samples\": %llu, \"closest_rays\": %llu, \"shadow_rays\": %llu, "
+           "\"sphere_tests\": %llu, \"Mray_s_primary_shadow\": %.1f, \"Msample_s\": %.1f}\n",
+           n, w, h, spp, (unsigned long long)st.launches, kernel_ms, wall_ms, (unsigned long long)st.samples,
+           (unsigned long long)st.closest_rays, (unsigned long long)st.shadow_rays,
+           (unsigned long long)st.sphere_tests, rays / (kernel_ms * 1e3), (double)st.samples / (kernel_ms * 1e3));
+    rt_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/TAG (written by tools/profile_gpu.sh) into profiles/: the kernel-trace
+stats table and per-launch PMC averages for the render kernel, with the gfx950 corrections of
+MI355X_MICROARCH.md (FETCH_SIZE counts half the bytes of wide coalesced reads; its unit and
+WRITE_SIZE's are KiB)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, pat):
+    hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    tag, mode, out_name = sys.argv[1], sys.argv[2], sys.argv[3]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "gpurun_out", tag)
+    kern = "rt_trace_" + mode
+    summary = {"mode": mode, "kernel": kern, "source": f"gpurun_out/{tag} (tools/profile_gpu.sh)"}
+    stats = find(os.path.join(src, "trace"), "*kernel_stats.csv")
+    lines = []
+    if stats:
+        with open(stats) as f:
+            rows = list(csv.DictReader(f))
+        lines.append("| kernel | calls | avg ns | min ns | max ns | % |")
+        lines.append("|---|---|---|---|---|---|")
+        for r in rows:
+            lines.append(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
+            if r["Name"] == kern:
+                summary["avg_kernel_ns"] = float(r["AverageNs"])
+                summary["calls"] = int(r["Calls"])
+    trace = find(os.path.join(src, "trace"), "*kernel_trace.csv")
+    if trace:
+        with open(trace) as f:
+            for r in csv.DictReader(f):
+                if r["Kernel_Name"] == kern:
+                    summary["launch"] = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
+                                                           "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X", "Grid_Size_Y")}
+                    break
+    counters = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        f = find(d, "*counter_collection.csv")
+        if not f:
+            continue
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Kernel_Name") != kern:
+                    continue
+                counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    avg = {k: sum(v) / len(v) for k, v in counters.items()}
+    summary["pmc_per_launch_avg"] = avg
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        fetch_b = avg["FETCH_SIZE"] * 1024.0
+        write_b = avg["WRITE_SIZE"] * 1024.0
+        summary["hbm_fetch_bytes_raw"] = fetch_b
+        summary["hbm_write_bytes"] = write_b
+        # guide: FETCH_SIZE reads exactly 1/2 of a wide coalesced stream on gfx950 -> upper bound 2x
+        summary["hbm_bytes_per_launch"] = fetch_b + write_b
+        summary["hbm_bytes_per_launch_fetch_x2"] = 2 * fetch_b + write_b
+    if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
+        summary["l2_hit_rate"] = avg["TCC_HIT_sum"] / max(avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"], 1.0)
+    if "SQ_ACTIVE_INST_VALU" in avg and "SQ_THREAD_CYCLES_VALU" in avg:
+        # lanes active per issued VALU cycle (64 = no divergence)
+        summary["valu_active_lanes_avg"] = avg["SQ_THREAD_CYCLES_VALU"] / max(avg["SQ_ACTIVE_INST_VALU"], 1.0) / 4.0 \
+            if False else None
+    os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+    with open(os.path.join(root, "profiles", out_name + ".json"), "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+    with open(os.path.join(root, "profiles", out_name + ".md"), "w") as f:
+        f.write(f"# {out_name}: rocprofv3 summary, bench.py --mode {mode} (C2: Demo, 1920x1080, 64 spp)\n\n")
+        f.write("## --kernel-trace --stats\n\n" + "\n".join(lines) + "\n\n")
+        f.write("## launch\n\n```\n" + json.dumps(summary.get("launch", {}), indent=1) + "\n```\n\n")
+        f.write("## PMC, average per launch of the render kernel (separate passes)\n\n| counter | value |\n|---|---|\n")
+        for k in sorted(avg):
+            f.write(f"| {k} | {avg[k]:.6g} |\n")
+        f.write("\n## derived\n\n```\n" + json.dumps({k: v for k, v in summary.items()
+                                                       if k not in ("pmc_per_launch_avg", "launch")}, indent=1) + "\n```\n")
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
