@@ -102,8 +102,11 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
 
     dim3 grid((unsigned)((c->w + rt::kTileW - 1) / rt::kTileW),
               (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
-    hipError_t e = (c->mode == RT_MODE_FAST) ? rt::launch_fast(p, grid, lds, stream)
-                                             : rt::launch_parity(p, grid, lds, stream);
+    hipError_t e;
+    if (c->mode == RT_MODE_FAST) e = rt::launch_fast(0, p, grid, lds, stream);
+    else if (c->mode >= 200) e = rt::launch_fast(c->mode - 200, p, grid, lds, stream);
+    else if (c->mode >= 100) e = rt::launch_parity(c->mode - 100, p, grid, lds, stream);
+    else e = rt::launch_parity(0, p, grid, lds, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
                     hipGetErrorString(e), grid.x, grid.y, lds);
@@ -263,7 +266,10 @@ int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
 
 int rt_set_mode(rt_ctx *c, int mode) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
-    if (mode != RT_MODE_PARITY && mode != RT_MODE_FAST) return fail(RT_ERR_ARG, "mode %d", mode);
+    // 100+k / 200+k: A/B instances of the parity / fast arithmetic (not part of the contract)
+    const bool ab = (mode >= 100 && mode < 100 + rt::parity_variant_count()) ||
+                    (mode >= 200 && mode < 200 + rt::fast_variant_count());
+    if (mode != RT_MODE_PARITY && mode != RT_MODE_FAST && !ab) return fail(RT_ERR_ARG, "mode %d", mode);
     c->mode = mode;
     return RT_OK;
 }

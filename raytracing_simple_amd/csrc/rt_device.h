@@ -52,8 +52,11 @@ inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds) 
     return b;
 }
 
-hipError_t launch_parity(const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
-hipError_t launch_fast(const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
+// variant 0 = the shipped instance; higher indices are A/B shapes (mode 100+k / 200+k)
+hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
+int parity_variant_count();
+int fast_variant_count();
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);
 hipError_t prepare_parity();    // raise the dynamic-LDS limit (called once per context)
 hipError_t prepare_fast();

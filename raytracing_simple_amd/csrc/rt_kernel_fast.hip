@@ -1,21 +1,49 @@
-// rt_kernel_fast.hip -- fused-arithmetic instance of the path-trace kernel
+// rt_kernel_fast.hip -- fused-arithmetic instances of the path-trace kernel
 // (-ffp-contract=fast, hardware rcp/rsq/sqrt/sin/cos/exp2/log2).  Gated by PSNR >= 50 dB
 // against the parity instance at equal spp (tests/test_gpu_parity.py).
 #define RT_FAST 1
+
 #define RT_NS fast
 #define RT_KERNEL_NAME rt_trace_fast
 #include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+
+#define RT_VARIANT_KERNEL 1
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
+
+#define RT_NS fast_a1
+#define RT_KERNEL_NAME rt_trace_fast_a1
+#define RT_OPT_UNROLL 1
+#define RT_OPT_SKIPNEG 0
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
 
 namespace rt {
 
-hipError_t launch_fast(const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL(fast::rt_trace_fast, grid, dim3(kBlockThreads), lds, stream, p);
+using KernelFn = void (*)(const LaunchParams);
+static KernelFn const kFastKernels[] = { fast::rt_trace_fast, fast_a1::rt_trace_fast_a1 };
+constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
+
+int fast_variant_count() { return kFastCount; }
+
+hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
+    if (variant < 0 || variant >= kFastCount) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kFastKernels[variant], grid, dim3(kBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t prepare_fast() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(fast::rt_trace_fast),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (KernelFn k : kFastKernels) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace rt

@@ -1,15 +1,74 @@
-// rt_kernel_parity.hip -- strict-arithmetic instance of the path-trace kernel.
+// rt_kernel_parity.hip -- strict-arithmetic instances of the path-trace kernel.
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
+// Instance 0 is the shipped one (RT_MODE_PARITY); the others are A/B shapes of the same
+// arithmetic, selectable as mode 100+k for in-process comparisons (tools/ab_bench.py).
 #pragma clang fp contract(off)
 #define RT_FAST 0
+
 #define RT_NS parity
 #define RT_KERNEL_NAME rt_trace_parity
 #include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+
+#define RT_VARIANT_KERNEL 1
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
+
+#define RT_NS parity_a1
+#define RT_KERNEL_NAME rt_trace_parity_a1
+#define RT_OPT_UNROLL 1
+#define RT_OPT_SKIPNEG 0
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
+
+#define RT_NS parity_a2
+#define RT_KERNEL_NAME rt_trace_parity_a2
+#define RT_OPT_UNROLL 1
+#define RT_OPT_SKIPNEG 1
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
+
+#define RT_NS parity_a3
+#define RT_KERNEL_NAME rt_trace_parity_a3
+#define RT_OPT_UNROLL 2
+#define RT_OPT_SKIPNEG 0
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
+
+#define RT_NS parity_a4
+#define RT_KERNEL_NAME rt_trace_parity_a4
+#define RT_OPT_UNROLL 4
+#define RT_OPT_SKIPNEG 1
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
 
 namespace rt {
 
-hipError_t launch_parity(const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL(parity::rt_trace_parity, grid, dim3(kBlockThreads), lds, stream, p);
+using KernelFn = void (*)(const LaunchParams);
+static KernelFn const kParityKernels[] = {
+    parity::rt_trace_parity, parity_a1::rt_trace_parity_a1, parity_a2::rt_trace_parity_a2,
+    parity_a3::rt_trace_parity_a3, parity_a4::rt_trace_parity_a4,
+};
+constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
+
+int parity_variant_count() { return kParityCount; }
+
+hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
+    if (variant < 0 || variant >= kParityCount) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kParityKernels[variant], grid, dim3(kBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -21,8 +80,12 @@ hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hip
 }
 
 hipError_t prepare_parity() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(parity::rt_trace_parity),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (KernelFn k : kParityKernels) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace rt

@@ -28,6 +28,17 @@
 #ifndef RT_FAST
 #error "define RT_FAST to 0 or 1"
 #endif
+// Sweep shape (closest-hit / any-hit loops over the LDS geometry table):
+//   RT_OPT_UNROLL   spheres per loop trip (1, 2 or 4): independent tests interleave, LDS reads
+//                   are issued ahead of use, compare->select hazards get filled
+//   RT_OPT_SKIPNEG  skip the square-root half of a test when NO lane of the wavefront has a
+//                   non-negative discriminant (wave ballot): a miss then costs 16 VALU ops
+#ifndef RT_OPT_UNROLL
+#define RT_OPT_UNROLL 2
+#endif
+#ifndef RT_OPT_SKIPNEG
+#define RT_OPT_SKIPNEG 1
+#endif
 
 namespace rt {
 namespace RT_NS {
@@ -101,6 +112,102 @@ RT_DEV float hit_distance(float4 g, V3 o, V3 d) {
     float t2 = b + sq;
     float t = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
     return det < 0.f ? 0.f : t;
+}
+
+// The same test in two halves: discriminant first, roots second.
+struct HitPre {
+    float b, det;
+};
+RT_DEV HitPre hit_pre(float4 g, V3 o, V3 d) {
+    V3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);
+    float b = dot(op, d);
+    return HitPre{ b, b * b - dot(op, op) + g.w };
+}
+RT_DEV float hit_post(HitPre p) {
+    float sq = rt_sqrt(p.det);
+    float t1 = p.b - sq;
+    float t2 = p.b + sq;
+    float t = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
+    return p.det < 0.f ? 0.f : t;
+}
+// true when some active lane needs the roots (NaN discriminants never hit: .cl:185-200)
+RT_DEV bool wave_any_nonneg(float det) {
+#if RT_OPT_SKIPNEG
+    return __builtin_amdgcn_ballot_w64(det >= 0.f) != 0ull;
+#else
+    (void)det;
+    return true;
+#endif
+}
+
+// closest hit over spheres [0, n): .cl:215-232
+RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id) {
+    uint32_t i = 0;
+#if RT_OPT_UNROLL >= 4
+    for (; i + 4 <= n; i += 4) {
+        const float4 g0 = s_geom[i], g1 = s_geom[i + 1], g2 = s_geom[i + 2], g3 = s_geom[i + 3];
+        const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d), p2 = hit_pre(g2, o, d),
+                     p3 = hit_pre(g3, o, d);
+        if (wave_any_nonneg(fmaxf(fmaxf(p0.det, p1.det), fmaxf(p2.det, p3.det)))) {
+            const float h0 = hit_post(p0), h1 = hit_post(p1), h2 = hit_post(p2), h3 = hit_post(p3);
+            if (h0 != 0.f && h0 < t) { t = h0; id = i; }
+            if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
+            if (h2 != 0.f && h2 < t) { t = h2; id = i + 2; }
+            if (h3 != 0.f && h3 < t) { t = h3; id = i + 3; }
+        }
+    }
+#endif
+#if RT_OPT_UNROLL >= 2
+    for (; i + 2 <= n; i += 2) {
+        const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
+        const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
+        if (wave_any_nonneg(p0.det)) {
+            const float h0 = hit_post(p0);
+            if (h0 != 0.f && h0 < t) { t = h0; id = i; }
+        }
+        if (wave_any_nonneg(p1.det)) {
+            const float h1 = hit_post(p1);
+            if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
+        }
+    }
+#endif
+    for (; i < n; ++i) {
+        const HitPre p0 = hit_pre(s_geom[i], o, d);
+        if (wave_any_nonneg(p0.det)) {
+            const float h0 = hit_post(p0);
+            if (h0 != 0.f && h0 < t) { t = h0; id = i; }
+        }
+    }
+}
+
+// any hit closer than max_t, .cl:234-247.  Returns the index of the first blocking sphere, or n.
+// A lane stops looking at its first hit; the wavefront leaves when every active lane has one.
+RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float max_t) {
+    uint32_t first = n;
+    uint32_t i = 0;
+#if RT_OPT_UNROLL >= 2
+    for (; i + 2 <= n; i += 2) {
+        const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
+        const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
+        if (wave_any_nonneg(fmaxf(p0.det, p1.det))) {
+            const float h0 = hit_post(p0), h1 = hit_post(p1);
+            const bool b0 = (h0 != 0.f && h0 < max_t), b1 = (h1 != 0.f && h1 < max_t);
+            const uint32_t cand = b0 ? i : (b1 ? i + 1 : n);
+            first = first < cand ? first : cand;
+            if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
+        }
+    }
+#endif
+    for (; i < n; ++i) {
+        const HitPre p0 = hit_pre(s_geom[i], o, d);
+        if (wave_any_nonneg(p0.det)) {
+            const float h0 = hit_post(p0);
+            const uint32_t cand = (h0 != 0.f && h0 < max_t) ? i : n;
+            first = first < cand ? first : cand;
+            if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
+        }
+    }
+    return first;
 }
 
 // .cl:34
@@ -208,13 +315,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
         // ---- closest hit, .cl:215-232: wave-uniform sweep, LDS broadcast reads ----
         float t = 1e20f;
         uint32_t id = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            float hdist = hit_distance(s_geom[i], o, d);
-            if (hdist != 0.f && hdist < t) {
-                t = hdist;
-                id = i;
-            }
-        }
+        sweep_closest(s_geom, n, o, d, t, id);
         c_closest += 1;
         c_tests += n;
 
@@ -269,17 +370,10 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
                     if (wi > 0.f) {
                         // ---- shadow ray, any hit, .cl:234-247 ----
                         const float max_t = len - RT_EPS;
-                        bool blocked = false;
                         c_shadow += 1;
-                        uint32_t i = 0;
-                        for (; i < n; ++i) {
-                            float hdist = hit_distance(s_geom[i], hp, sd);
-                            if (hdist != 0.f && hdist < max_t) {
-                                blocked = true;
-                                break;
-                            }
-                        }
-                        c_tests += blocked ? i + 1 : n;
+                        const uint32_t first = sweep_any(s_geom, n, hp, sd, max_t);
+                        const bool blocked = first < n;
+                        c_tests += blocked ? first + 1 : n;
                         if (!blocked) {
                             float k = rt_div(lb.w * wi * wo, len * len);   // .cl:297
                             ld = add(ld, scale(mk(lb.x, lb.y, lb.z), k));
@@ -396,7 +490,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
     }
 }
 
-#if !RT_FAST
+#if !RT_FAST && !defined(RT_VARIANT_KERNEL)
 // scalar building blocks, for rt_debug_eval
 extern "C" __global__ void rt_eval_kernel(int op, const float *in, float *out, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

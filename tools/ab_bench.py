@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""In-process A/B of kernel instances (guide rule 24: interleaved rounds in ONE process).
+
+    python tools/ab_bench.py [--configs c2,c3,c5,c16] [--modes 0,100,101,...] [--rounds 5]
+
+Each mode renders the same frame; parity-arithmetic instances (0, 100+k) must produce the same
+pixels as mode 0, fast ones (1, 200+k) are reported with their PSNR against mode 0."""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_simple_amd import api, host, scenes  # noqa: E402
+
+CONFIGS = {
+    "c2": (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 1920, 1080, 64),
+    "c16": (lambda: scenes.demo_plus(16), 1920, 1080, 64),
+    "c3": (lambda: scenes.random_spheres(1024), 1920, 1080, 16),
+    "c5": (lambda: scenes.mirror_box(64), 1920, 1080, 64),
+    "c4": (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="c2")
+    ap.add_argument("--modes", default="0,1")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--spp", type=int, default=0)
+    args = ap.parse_args()
+    modes = [int(m) for m in args.modes.split(",")]
+    for cname in args.configs.split(","):
+        maker, w, h, spp = CONFIGS[cname]
+        if args.spp:
+            spp = args.spp
+        sph, orig, target = maker()
+        cam = host.compute_camera(orig, target, w, h)
+        with api.RtContext(w, h) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            times = {m: [] for m in modes}
+            pix, stats = {}, {}
+            for r in range(args.rounds + 1):
+                for m in modes:
+                    ctx.set_mode(m)
+                    ctx.reset()
+                    px = ctx.render_pass(spp)
+                    st = ctx.stats()
+                    if r == 0:
+                        pix[m], stats[m] = px, st            # warm-up round: keep outputs only
+                    else:
+                        times[m].append(st["last_kernel_ms"])
+            base = pix[modes[0]]
+            for m in modes:
+                st = stats[m]
+                rays = st["samples"] + st["shadow_rays"]
+                med, mn = statistics.median(times[m]), min(times[m])
+                same = bool(np.array_equal(pix[m], base))
+                print(json.dumps({"config": cname, "mode": m, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                                  "Gray_s": round(rays / med / 1e6, 2), "same_as_first": same,
+                                  "psnr_vs_first": None if same else round(host.psnr(pix[m], base), 2),
+                                  "tests_per_sample": round(st["sphere_tests"] / st["samples"], 2),
+                                  "alg_TFLOPs": round(20 * st["sphere_tests"] / med / 1e9, 3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
