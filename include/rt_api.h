@@ -159,7 +159,8 @@ int rt_read_scene(const char *path, rt_sphere *out, uint32_t cap, uint32_t *coun
                   rt_vec3 *orig, rt_vec3 *target, int reference_doubling);
 
 /* Device-side evaluation of the scalar building blocks, for unit parity tests:
- * op 0: sinf, 1: cosf, 2: pow(x, 1/2.2f), 3: 1/x, 4: sqrt(x), 5: toInt(x) (result as float). */
+ * op 0: sinf, 1: cosf, 2: pow(x, 1/2.2f), 3: 1/x, 4: sqrt(x), 5: toInt(x) (result as float),
+ * 6/7: the kernel's branch-free sinf/cosf (x >= 0).                                           */
 int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n);
 
 #ifdef __cplusplus

@@ -96,9 +96,9 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.nranks = c->nranks;
     p.tile_rows = c->tile_rows;
     p.local_rows = c->local_rows;
-    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true);
+    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     p.mat_in_lds = lds_all <= 64 * 1024;
-    const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0);
+    const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
 
     dim3 grid((unsigned)((c->w + rt::kTileW - 1) / rt::kTileW),
               (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
@@ -382,7 +382,7 @@ int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w,
 
 int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
     if ((!in_host || !out_host) && n) return fail(RT_ERR_ARG, "null argument");
-    if (op < 0 || op > 5) return fail(RT_ERR_ARG, "op %d", op);
+    if (op < 0 || op > 7) return fail(RT_ERR_ARG, "op %d", op);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
     if (n == 0) return RT_OK;

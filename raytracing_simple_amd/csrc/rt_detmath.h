@@ -76,6 +76,26 @@ RT_DEV void dm_sincosf(float y, float &sn, float &cs) {
     cs = odd ? sp : cp;
 }
 
+// The same function without the two small-argument shortcuts, for y = +0 or y in [2^-149, 120):
+// with n = 0 the reduction returns y itself, so the general path already evaluates the
+// small-argument polynomial, and below 2^-12 the polynomial value rounds to y (sin) and to 1
+// (cos).  Bit-identical to dm_sincosf over every argument the renderer forms (2*pi*k/2^23;
+// tests/test_gpu_parity.py) and free of wave divergence.
+RT_DEV void dm_sincosf_pos(float y, float &sn, float &cs) {
+    double x = (double)y;
+    double r = x * DM_HPI_INV24;
+    int n = ((int)r + 0x800000) >> 24;
+    double xr = dm_fma(-(double)n, DM_HPI, x);
+    double x2 = xr * xr;
+    double sgn = ((n + 1) & 2) ? -1.0 : 1.0;
+    float sp = dm_sin_poly(xr * sgn, x2);
+    double cd = dm_cos_poly(x2);
+    float cp = (float)((n & 2) ? -cd : cd);
+    bool odd = (n & 1) != 0;
+    sn = odd ? cp : sp;
+    cs = odd ? sp : cp;
+}
+
 // __powf_log2_data / __exp2f_data
 static __device__ __constant__ const double dm_log2_tab[16][2] = {
     { 0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2 }, { 0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2 },

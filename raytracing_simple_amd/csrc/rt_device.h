@@ -13,6 +13,7 @@ constexpr int kBlockThreads = 256;  // 4 wavefronts
 constexpr int kTileW = 32;          // block tile: 32 x 8 pixels, one 8x8 sub-tile per wavefront
 constexpr int kTileH = 8;
 constexpr int kMaxDepth = 8;        // .cl:320 (depth > 7 ends the path)
+constexpr int kMaxK2Table = 1024;   // running-average reciprocals kept in LDS up to this many passes per launch
 
 // Sphere tables in HBM, written once by rt_set_scene and staged into LDS by every workgroup.
 //   geom[i] = { p.x, p.y, p.z, rad*rad }      closest-hit / any-hit loops read only this
@@ -46,10 +47,11 @@ struct LaunchParams {
 };
 
 // LDS bytes the kernels need for a scene
-inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds) {
+inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples = 0) {
     size_t b = (size_t)n_spheres * 16 + (size_t)n_lights * 32;
     if (mat_in_lds) b += (size_t)n_spheres * 32;
-    return b;
+    if (n_samples <= kMaxK2Table) b += (size_t)(n_samples > 0 ? n_samples : 0) * 4;
+    return (b + 15) & ~(size_t)15;
 }
 
 // variant 0 = the shipped instance; higher indices are A/B shapes (mode 100+k / 200+k)

@@ -236,6 +236,10 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;             // {colour, radius}
+    // 1/(s+1) of the running average (.cl:585), one IEEE division per sample index per
+    // workgroup instead of one per lane per sample
+    float *s_k2 = reinterpret_cast<float *>(P.mat_in_lds ? s_colr + n : s_emis);
+    const bool k2_in_lds = P.n_samples <= kMaxK2Table;
 
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
@@ -249,6 +253,9 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
             s_colr[i] = P.scene.colr[i];
         }
     }
+    if (k2_in_lds)
+        for (int i = tid; i < P.n_samples; i += kBlockThreads)
+            s_k2[i] = rt_rcp((float)(P.first_sample + i) + 1.f);
     __syncthreads();
     const float4 *m_emis = P.mat_in_lds ? s_emis : P.scene.emis;
     const float4 *m_colr = P.mat_in_lds ? s_colr : P.scene.colr;
@@ -356,7 +363,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
 #if RT_FAST
                     fm_sincos_turns(u2, sphi, cphi);
 #else
-                    dm_sincosf((2.f * RT_PI) * u2, sphi, cphi);
+                    dm_sincosf_pos((2.f * RT_PI) * u2, sphi, cphi);
 #endif
                     V3 us = mk(ring * cphi, ring * sphi, zc);
                     V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
@@ -395,7 +402,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
 #if RT_FAST
                 fm_sincos_turns(u, s1v, c1v);
 #else
-                dm_sincosf((2.f * RT_PI) * u, s1v, c1v);
+                dm_sincosf_pos((2.f * RT_PI) * u, s1v, c1v);
 #endif
                 V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
                 nd = add(nd, scale(w, rt_sqrt(1 - r2)));
@@ -453,7 +460,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
                 acc = rad;
             } else {
                 float k1 = (float)s;
-                float k2 = rt_rcp((float)s + 1.f);
+                float k2 = k2_in_lds ? s_k2[s - P.first_sample] : rt_rcp((float)s + 1.f);
                 acc = mk((acc.x * k1 + rad.x) * k2, (acc.y * k1 + rad.y) * k2,
                          (acc.z * k1 + rad.z) * k2);
             }
@@ -503,6 +510,8 @@ extern "C" __global__ void rt_eval_kernel(int op, const float *in, float *out, s
         case 3: r = 1.f / v; break;
         case 4: r = sqrtf(v); break;
         case 5: r = (float)to_int(v); break;
+        case 6: dm_sincosf_pos(v, r, t); break;
+        case 7: dm_sincosf_pos(v, t, r); break;
         default: break;
     }
     out[i] = r;

@@ -181,6 +181,18 @@ def test_device_scalar_ops_bit_exact():
     assert np.array_equal(api.debug_eval(0, x).view(np.uint32), want_s.view(np.uint32))
     assert np.array_equal(api.debug_eval(1, x).view(np.uint32), want_c.view(np.uint32))
 
+    # the branch-free form the kernel uses: EVERY argument the renderer can form
+    k = np.arange(1 << 23, dtype=np.float32) * np.float32(2.0 ** -23)
+    xs = np.float32(2.0 * np.float32(3.14159265358979323846)) * k
+    sub = np.concatenate([xs[:: 97], xs[:4096], xs[-4096:]])
+    want_s = np.array([lib.om_sinf(float(v)) for v in sub], np.float32)
+    want_c = np.array([lib.om_cosf(float(v)) for v in sub], np.float32)
+    assert np.array_equal(api.debug_eval(6, sub).view(np.uint32), want_s.view(np.uint32))
+    assert np.array_equal(api.debug_eval(7, sub).view(np.uint32), want_c.view(np.uint32))
+    # ... and the whole set against the branching form on the device itself
+    assert np.array_equal(api.debug_eval(6, xs).view(np.uint32), api.debug_eval(0, xs).view(np.uint32))
+    assert np.array_equal(api.debug_eval(7, xs).view(np.uint32), api.debug_eval(1, xs).view(np.uint32))
+
     b = np.concatenate([rng.random(200000, dtype=np.float32), (rng.random(50000) ** 12).astype(np.float32),
                         np.float32([0, 1, 1e-45, 1e-39, 1e-38, 0.5, 0.99999994])])
     want_p = np.array([lib.om_gammaf(float(v)) for v in b], np.float32)
