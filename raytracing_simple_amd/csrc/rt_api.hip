@@ -52,6 +52,7 @@ struct rt_ctx {
     int current_sample = 0;
     uint64_t launches = 0;
     double last_ms = 0.0;
+    unsigned long long debug_counters[24] = {};   // diagnostic instances only
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -71,7 +72,7 @@ int upload_default_seeds(rt_ctx *c) {
     HIP_TRY(hipMemcpy(c->d_seeds, c->d_seeds0, count * sizeof(uint32_t), hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemset(c->d_colors, 0, 3 * (size_t)c->w * (size_t)c->h * sizeof(float)));
     HIP_TRY(hipMemset(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_counters, 0, 32 * sizeof(unsigned long long)));
     return RT_OK;
 }
 
@@ -170,7 +171,7 @@ int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nran
         HIP_TRY(hipMalloc(&c->d_seeds0, 2 * px * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_colors, 3 * px * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 1) * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)));
         HIP_TRY(rt::prepare_parity());
         HIP_TRY(rt::prepare_fast());
         return upload_default_seeds(c);
@@ -251,7 +252,7 @@ int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
         HIP_TRY(hipMemcpy(d_lb, lb.data(), nl * sizeof(float4), hipMemcpyHostToDevice));
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, count, nl };
-    if (rt::lds_bytes(count, nl, false) > 160 * 1024)
+    if (rt::lds_bytes(count, nl, false) > 159 * 1024)
         return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 160 KiB)", rt::lds_bytes(count, nl, false));
     c->have_scene = true;
     return RT_OK;
@@ -293,7 +294,7 @@ int rt_reset_async(rt_ctx *c, void *hip_stream) {
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
                            hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), st));
     c->current_sample = 0;
     return RT_OK;
 }
@@ -355,7 +356,7 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     if (!c || !out) return fail(RT_ERR_ARG, "null argument");
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    unsigned long long v[8];
+    unsigned long long v[32];
     HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
     HIP_TRY(hipMemcpy(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost));
     out->samples = v[0];
@@ -363,8 +364,16 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     out->shadow_rays = v[2];
     out->sphere_tests = v[3];
     out->rng_draws = v[4];
+    memcpy(c->debug_counters, v + 8, sizeof c->debug_counters);
     out->launches = c->launches;
     out->last_kernel_ms = c->last_ms;
+    return RT_OK;
+}
+
+// diagnostic: section cycle sums of a stamped instance (valid after rt_get_stats)
+int rt_debug_counters(rt_ctx *c, unsigned long long *out24) {
+    if (!c || !out24) return fail(RT_ERR_ARG, "null argument");
+    memcpy(out24, c->debug_counters, sizeof c->debug_counters);
     return RT_OK;
 }
 

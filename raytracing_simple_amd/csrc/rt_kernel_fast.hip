@@ -40,7 +40,7 @@ hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds
 hipError_t prepare_fast() {
     for (KernelFn k : kFastKernels) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -17,13 +17,11 @@
 
 #define RT_NS parity_a1
 #define RT_KERNEL_NAME rt_trace_parity_a1
-#define RT_OPT_UNROLL 1
-#define RT_OPT_SKIPNEG 0
+#define RT_OPT_TRUNC 5
 #include "rt_trace.inc.h"
 #undef RT_NS
 #undef RT_KERNEL_NAME
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
+#undef RT_OPT_TRUNC
 
 #define RT_NS parity_a2
 #define RT_KERNEL_NAME rt_trace_parity_a2
@@ -37,13 +35,11 @@
 
 #define RT_NS parity_a3
 #define RT_KERNEL_NAME rt_trace_parity_a3
-#define RT_OPT_UNROLL 2
-#define RT_OPT_SKIPNEG 0
+#define RT_OPT_TRUNC 6
 #include "rt_trace.inc.h"
 #undef RT_NS
 #undef RT_KERNEL_NAME
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
+#undef RT_OPT_TRUNC
 
 #define RT_NS parity_a4
 #define RT_KERNEL_NAME rt_trace_parity_a4
@@ -55,12 +51,20 @@
 #undef RT_OPT_UNROLL
 #undef RT_OPT_SKIPNEG
 
+#define RT_NS parity_a5
+#define RT_KERNEL_NAME rt_trace_parity_a5
+#define RT_OPT_STAMPS 1
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_STAMPS
+
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
 static KernelFn const kParityKernels[] = {
     parity::rt_trace_parity, parity_a1::rt_trace_parity_a1, parity_a2::rt_trace_parity_a2,
-    parity_a3::rt_trace_parity_a3, parity_a4::rt_trace_parity_a4,
+    parity_a3::rt_trace_parity_a3, parity_a4::rt_trace_parity_a4, parity_a5::rt_trace_parity_a5,
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
@@ -82,7 +86,7 @@ hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hip
 hipError_t prepare_parity() {
     for (KernelFn k : kParityKernels) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

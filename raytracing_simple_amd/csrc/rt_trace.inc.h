@@ -39,6 +39,34 @@
 #ifndef RT_OPT_SKIPNEG
 #define RT_OPT_SKIPNEG 1
 #endif
+// RT_OPT_STAMPS: diagnostic instance only -- s_memtime at section boundaries, summed per
+// wavefront into counters[8..17] (never in a timed or shipped instance).
+#ifndef RT_OPT_STAMPS
+#define RT_OPT_STAMPS 0
+#endif
+#undef RT_STAMP
+#undef RT_STAMP_ROOTS
+#if RT_OPT_STAMPS
+// census: executions of each section per wavefront and active lanes in them.  The first active
+// lane of the wavefront adds to a workgroup counter in LDS (a per-lane sum would only see the
+// entries its own lane took part in).
+#define RT_STAMP(k)                                                                          \
+    do {                                                                                     \
+        asm volatile("; @@SEC " #k);                                                          \
+        const unsigned long long b_ = __builtin_amdgcn_ballot_w64(true);                     \
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)b_) - 1))                    \
+            atomicAdd(&s_census[k], (1ull << 32) + (unsigned)__popcll(b_));                  \
+    } while (0)
+#define RT_STAMP_ROOTS(k, cnt)                                                               \
+    do {                                                                                     \
+        const unsigned long long b_ = __builtin_amdgcn_ballot_w64(true);                     \
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)b_) - 1))                    \
+            atomicAdd(&s_census[k], (unsigned long long)(cnt));                              \
+    } while (0)
+#else
+#define RT_STAMP(k)
+#define RT_STAMP_ROOTS(k, cnt)
+#endif
 
 namespace rt {
 namespace RT_NS {
@@ -141,7 +169,8 @@ RT_DEV bool wave_any_nonneg(float det) {
 }
 
 // closest hit over spheres [0, n): .cl:215-232
-RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id) {
+RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id,
+                          unsigned long long &roots) {
     uint32_t i = 0;
 #if RT_OPT_UNROLL >= 4
     for (; i + 4 <= n; i += 4) {
@@ -149,6 +178,7 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d), p2 = hit_pre(g2, o, d),
                      p3 = hit_pre(g3, o, d);
         if (wave_any_nonneg(fmaxf(fmaxf(p0.det, p1.det), fmaxf(p2.det, p3.det)))) {
+            roots += 4;
             const float h0 = hit_post(p0), h1 = hit_post(p1), h2 = hit_post(p2), h3 = hit_post(p3);
             if (h0 != 0.f && h0 < t) { t = h0; id = i; }
             if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
@@ -162,10 +192,12 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
         if (wave_any_nonneg(p0.det)) {
+            roots += 1;
             const float h0 = hit_post(p0);
             if (h0 != 0.f && h0 < t) { t = h0; id = i; }
         }
         if (wave_any_nonneg(p1.det)) {
+            roots += 1;
             const float h1 = hit_post(p1);
             if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
         }
@@ -174,6 +206,7 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
         if (wave_any_nonneg(p0.det)) {
+            roots += 1;
             const float h0 = hit_post(p0);
             if (h0 != 0.f && h0 < t) { t = h0; id = i; }
         }
@@ -182,7 +215,8 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
 
 // any hit closer than max_t, .cl:234-247.  Returns the index of the first blocking sphere, or n.
 // A lane stops looking at its first hit; the wavefront leaves when every active lane has one.
-RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float max_t) {
+RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float max_t,
+                          unsigned long long &roots) {
     uint32_t first = n;
     uint32_t i = 0;
 #if RT_OPT_UNROLL >= 2
@@ -190,6 +224,7 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
         if (wave_any_nonneg(fmaxf(p0.det, p1.det))) {
+            roots += 2;
             const float h0 = hit_post(p0), h1 = hit_post(p1);
             const bool b0 = (h0 != 0.f && h0 < max_t), b1 = (h1 != 0.f && h1 < max_t);
             const uint32_t cand = b0 ? i : (b1 ? i + 1 : n);
@@ -201,6 +236,7 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
         if (wave_any_nonneg(p0.det)) {
+            roots += 1;
             const float h0 = hit_post(p0);
             const uint32_t cand = (h0 != 0.f && h0 < max_t) ? i : n;
             first = first < cand ? first : cand;
@@ -227,7 +263,10 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const LaunchParams P) {
+#ifndef RT_OPT_MINWAVES
+#define RT_OPT_MINWAVES 1
+#endif
+extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
@@ -298,9 +337,17 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
     bool after_specular = true;
     bool need_ray = true;
 
+    unsigned long long st_roots_c = 0, st_roots_s = 0;   // wave-uniform; dead unless RT_OPT_STAMPS
+#if RT_OPT_STAMPS
+    __shared__ unsigned long long s_census[12];
+    if (tid < 12) s_census[tid] = 0;
+    __syncthreads();
+#endif
     for (;;) {
+        RT_STAMP(8);
         if (need_ray) {
             if (s >= s_end) break;
+            RT_STAMP(0);
             // ---- camera ray, .cl:494-549 ----
             float j1 = next_random(s0, s1) - 0.5f;
             float j2 = next_random(s0, s1) - 0.5f;
@@ -322,14 +369,21 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
         // ---- closest hit, .cl:215-232: wave-uniform sweep, LDS broadcast reads ----
         float t = 1e20f;
         uint32_t id = 0;
-        sweep_closest(s_geom, n, o, d, t, id);
+        RT_STAMP(1);
+        st_roots_c = 0;
+        sweep_closest(s_geom, n, o, d, t, id, st_roots_c);
+        RT_STAMP_ROOTS(10, st_roots_c);
         c_closest += 1;
         c_tests += n;
 
+#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 1
+        t = 1e20f;   // diagnostic: every ray misses
+#endif
         bool path_done = false;
         if (!(t < 1e20f)) {
             path_done = true;                                              // miss, .cl:327-330
         } else {
+            RT_STAMP(2);
             const float4 ge = s_geom[id];
             const float4 em4 = m_emis[id];
             const float4 co4 = m_colr[id];
@@ -342,7 +396,11 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
             float dp = dot(nrm, d);
             V3 nl = scale(nrm, -1.f * cl_sign(dp));                        // .cl:354-355
 
+#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 2
+            if (true) {   // diagnostic: every hit ends the path like an emitter
+#else
             if (!((em.x == 0.f) && (em.z == 0.f))) {                       // .cl:358-368
+#endif
                 if (after_specular) rad = add(rad, mul(thr, scale(em, fabsf(dp))));
                 path_done = true;
             } else if (refl == RT_DIFF) {                                  // .cl:370-412
@@ -352,11 +410,16 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
                 // ---- next-event estimation, .cl:249-303 ----
                 V3 ld = mk(0.f, 0.f, 0.f);
                 for (uint32_t j = 0; j < n_lights; ++j) {
+                    RT_STAMP(3);
                     const float4 la = s_lightA[j];
                     const float4 lb = s_lightB[j];
                     float u1 = next_random(s0, s1);
                     float u2 = next_random(s0, s1);
                     c_draws += 2;
+#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 5
+                    asm volatile("" ::"v"(u1), "v"(u2));
+                    continue;   // diagnostic: draws kept (same paths), light sampling skipped
+#endif
                     float zc = 1.f - 2.f * u1;                             // .cl:203-213
                     float ring = rt_sqrt(fmaxf(0.f, 1.f - zc * zc));
                     float sphi, cphi;
@@ -378,16 +441,29 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
                         // ---- shadow ray, any hit, .cl:234-247 ----
                         const float max_t = len - RT_EPS;
                         c_shadow += 1;
-                        const uint32_t first = sweep_any(s_geom, n, hp, sd, max_t);
+                        RT_STAMP(4);
+#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 6
+                        const uint32_t first = n;   // diagnostic: shadow rays never blocked, no sweep
+                        asm volatile("" ::"v"(max_t));
+#else
+                        st_roots_s = 0;
+                        const uint32_t first = sweep_any(s_geom, n, hp, sd, max_t, st_roots_s);
+                        RT_STAMP_ROOTS(11, st_roots_s);
+#endif
                         const bool blocked = first < n;
                         c_tests += blocked ? first + 1 : n;
                         if (!blocked) {
+                            RT_STAMP(5);
                             float k = rt_div(lb.w * wi * wo, len * len);   // .cl:297
                             ld = add(ld, scale(mk(lb.x, lb.y, lb.z), k));
                         }
                     }
                 }
                 rad = add(rad, mul(thr, ld));                              // .cl:377-378
+                RT_STAMP(6);
+#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 3
+                depth = kMaxDepth;   // diagnostic: stop after direct lighting
+#else
 
                 // ---- cosine-weighted bounce, .cl:383-411 ----
                 float u = next_random(s0, s1);
@@ -408,8 +484,14 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
                 nd = add(nd, scale(w, rt_sqrt(1 - r2)));
                 o = hp;
                 d = nd;
+#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 4
+                asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z));
+                depth = kMaxDepth;   // diagnostic: stop after the first diffuse bounce is sampled
+#endif
+#endif
             } else {
                 // reflection direction shared by SPEC and REFR, .cl:416-419 / 428-431
+                RT_STAMP(7);
                 V3 rfl = sub(d, scale(nrm, 2.f * dot(nrm, d)));
                 after_specular = true;
                 if (refl == RT_SPEC) {                                     // .cl:413-424
@@ -455,6 +537,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
         }
 
         if (path_done) {
+            RT_STAMP(9);
             // ---- running average, .cl:580-589 ----
             if (s == 0) {
                 acc = rad;
@@ -495,6 +578,10 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads) RT_KERNEL_NAME(const
         atomicAdd(&P.counters[3], tests64);
         atomicAdd(&P.counters[4], (unsigned long long)t_draws);
     }
+#if RT_OPT_STAMPS
+    __syncthreads();
+    if (tid < 12) atomicAdd(&P.counters[8 + tid], s_census[tid]);
+#endif
 }
 
 #if !RT_FAST && !defined(RT_VARIANT_KERNEL)

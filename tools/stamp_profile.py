@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Section shares of the render loop from the stamped diagnostic instance (mode 105)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracing_simple_amd import api, host, scenes  # noqa: E402
+from tools.ab_bench import CONFIGS  # noqa: E402
+
+NAMES = ["camera ray", "closest sweep", "hit point/normal", "light sample", "shadow sweep", "light contrib",
+         "diffuse bounce", "spec/refr", "loop trip", "accumulate"]
+
+for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
+    maker, w, h, spp = CONFIGS[cname]
+    sph, orig, target = maker()
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 105)
+        ctx.render_pass(spp, copy=False)
+        st = ctx.stats()
+        buf = (C.c_ulonglong * 24)()
+        api.load_library().rt_debug_counters(ctx._h, buf)
+        v = list(buf)[:10]
+        print(f"{cname}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
+              f"active lanes per execution, executions per sample-wave")
+        waves_samples = st["samples"] / 64.0
+        for n, c in zip(NAMES, v):
+            execs, lanes = c >> 32, c & 0xFFFFFFFF
+            if execs:
+                print(f"  {n:18s} execs {execs:12d}  lanes/exec {lanes / execs:6.2f}  execs per 64 samples {execs / waves_samples:6.3f}")
