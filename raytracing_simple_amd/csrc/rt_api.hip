@@ -49,6 +49,7 @@ struct rt_ctx {
     rt_camera cam{};
     bool have_scene = false, have_cam = false;
     int mode = RT_MODE_PARITY;
+    int regen_gate = 0;           // 0 = choose from the scene size
     int current_sample = 0;
     uint64_t launches = 0;
     double last_ms = 0.0;
@@ -97,6 +98,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.nranks = c->nranks;
     p.tile_rows = c->tile_rows;
     p.local_rows = c->local_rows;
+    p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     p.mat_in_lds = lds_all <= 64 * 1024;
     const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
@@ -367,6 +369,13 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     memcpy(c->debug_counters, v + 8, sizeof c->debug_counters);
     out->launches = c->launches;
     out->last_kernel_ms = c->last_ms;
+    return RT_OK;
+}
+
+// tuning knob (not part of the contract): 0 = automatic, 1 = free-running, n = gate of n lanes
+int rt_debug_set_regen_gate(rt_ctx *c, int gate) {
+    if (!c || gate < 0 || gate > 64) return fail(RT_ERR_ARG, "gate %d", gate);
+    c->regen_gate = gate;
     return RT_OK;
 }
 

@@ -44,6 +44,7 @@ struct LaunchParams {
     int first_sample, n_samples;
     int rank, nranks, tile_rows, local_rows;
     int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
+    int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
 };
 
 // LDS bytes the kernels need for a scene

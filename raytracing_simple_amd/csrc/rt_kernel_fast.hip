@@ -5,9 +5,12 @@
 
 #define RT_NS fast
 #define RT_KERNEL_NAME rt_trace_fast
+#define RT_SCHED_KERNEL_NAME rt_sched_fast
 #include "rt_trace.inc.h"
+#include "rt_sched.inc.h"
 #undef RT_NS
 #undef RT_KERNEL_NAME
+#undef RT_SCHED_KERNEL_NAME
 
 #define RT_VARIANT_KERNEL 1
 #undef RT_OPT_UNROLL
@@ -26,7 +29,7 @@
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
-static KernelFn const kFastKernels[] = { fast::rt_trace_fast, fast_a1::rt_trace_fast_a1 };
+static KernelFn const kFastKernels[] = { fast::rt_trace_fast, fast_a1::rt_trace_fast_a1, fast::rt_sched_fast };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 
 int fast_variant_count() { return kFastCount; }

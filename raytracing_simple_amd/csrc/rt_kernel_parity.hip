@@ -7,64 +7,34 @@
 
 #define RT_NS parity
 #define RT_KERNEL_NAME rt_trace_parity
+#define RT_SCHED_KERNEL_NAME rt_sched_parity
 #include "rt_trace.inc.h"
+#include "rt_sched.inc.h"
 #undef RT_NS
 #undef RT_KERNEL_NAME
+#undef RT_SCHED_KERNEL_NAME
 
 #define RT_VARIANT_KERNEL 1
 #undef RT_OPT_UNROLL
 #undef RT_OPT_SKIPNEG
 
-#define RT_NS parity_a1
-#define RT_KERNEL_NAME rt_trace_parity_a1
-#define RT_OPT_TRUNC 5
-#include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_TRUNC
-
-#define RT_NS parity_a2
-#define RT_KERNEL_NAME rt_trace_parity_a2
-#define RT_OPT_UNROLL 1
-#define RT_OPT_SKIPNEG 1
-#include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
-
-#define RT_NS parity_a3
-#define RT_KERNEL_NAME rt_trace_parity_a3
-#define RT_OPT_TRUNC 6
-#include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_TRUNC
-
-#define RT_NS parity_a4
-#define RT_KERNEL_NAME rt_trace_parity_a4
-#define RT_OPT_UNROLL 4
-#define RT_OPT_SKIPNEG 1
-#include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
-
 #define RT_NS parity_a5
 #define RT_KERNEL_NAME rt_trace_parity_a5
+#define RT_SCHED_KERNEL_NAME rt_sched_parity_a5
 #define RT_OPT_STAMPS 1
 #include "rt_trace.inc.h"
+#include "rt_sched.inc.h"
 #undef RT_NS
 #undef RT_KERNEL_NAME
+#undef RT_SCHED_KERNEL_NAME
 #undef RT_OPT_STAMPS
 
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
 static KernelFn const kParityKernels[] = {
-    parity::rt_trace_parity, parity_a1::rt_trace_parity_a1, parity_a2::rt_trace_parity_a2,
-    parity_a3::rt_trace_parity_a3, parity_a4::rt_trace_parity_a4, parity_a5::rt_trace_parity_a5,
+    parity::rt_trace_parity, parity_a5::rt_trace_parity_a5,
+    parity::rt_sched_parity, parity_a5::rt_sched_parity_a5,
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 

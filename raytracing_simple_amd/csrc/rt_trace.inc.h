@@ -44,6 +44,7 @@
 #ifndef RT_OPT_STAMPS
 #define RT_OPT_STAMPS 0
 #endif
+
 #undef RT_STAMP
 #undef RT_STAMP_ROOTS
 #if RT_OPT_STAMPS
@@ -345,6 +346,19 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 #endif
     for (;;) {
         RT_STAMP(8);
+        // Gated regeneration: lanes whose path has ended wait until P.regen_gate of them can
+        // start together (or nothing else is in flight).  Free-running lanes (gate 1) drift
+        // apart in phase, so that every section of the loop runs in almost every trip for a
+        // fraction of the lanes; a small gate keeps the lanes of a coherent tile in the same
+        // phase of the bounce loop at the price of a few idle lane-trips.  Ordering within a
+        // pixel is untouched.
+        if (need_ray && s >= s_end) break;
+        if (P.regen_gate > 1) {
+            const unsigned long long bw = __builtin_amdgcn_ballot_w64(need_ray);
+            const unsigned long long ba = __builtin_amdgcn_ballot_w64(!need_ray);
+            const bool go = (__popcll(bw) >= P.regen_gate) || (ba == 0ull);
+            if (need_ray && !go) continue;
+        }
         if (need_ray) {
             if (s >= s_end) break;
             RT_STAMP(0);

@@ -22,6 +22,8 @@ CONFIGS = {
     "c16": (lambda: scenes.demo_plus(16), 1920, 1080, 64),
     "c3": (lambda: scenes.random_spheres(1024), 1920, 1080, 16),
     "c5": (lambda: scenes.mirror_box(64), 1920, 1080, 64),
+    "c64": (lambda: scenes.random_spheres(64), 1920, 1080, 64),
+    "c256": (lambda: scenes.random_spheres(256), 1920, 1080, 32),
     "c4": (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
 }
 
@@ -32,8 +34,11 @@ def main():
     ap.add_argument("--modes", default="0,1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
     args = ap.parse_args()
     modes = [int(m) for m in args.modes.split(",")]
+    gates = [int(g) for g in args.gates.split(",")] if args.gates else [None]
+    variants = [(m, g) for m in modes for g in gates]
     for cname in args.configs.split(","):
         maker, w, h, spp = CONFIGS[cname]
         if args.spp:
@@ -43,27 +48,31 @@ def main():
         with api.RtContext(w, h) as ctx:
             ctx.set_scene(sph)
             ctx.set_camera(cam)
-            times = {m: [] for m in modes}
+            times = {v: [] for v in variants}
             pix, stats = {}, {}
+            lib = api.load_library()
             for r in range(args.rounds + 1):
-                for m in modes:
+                for v in variants:
+                    m, g = v
                     ctx.set_mode(m)
+                    lib.rt_debug_set_regen_gate(ctx._h, 0 if g is None else g)
                     ctx.reset()
                     px = ctx.render_pass(spp)
                     st = ctx.stats()
                     if r == 0:
-                        pix[m], stats[m] = px, st            # warm-up round: keep outputs only
+                        pix[v], stats[v] = px, st            # warm-up round: keep outputs only
                     else:
-                        times[m].append(st["last_kernel_ms"])
-            base = pix[modes[0]]
-            for m in modes:
-                st = stats[m]
+                        times[v].append(st["last_kernel_ms"])
+            base = pix[variants[0]]
+            for v in variants:
+                m, g = v
+                st = stats[v]
                 rays = st["samples"] + st["shadow_rays"]
-                med, mn = statistics.median(times[m]), min(times[m])
-                same = bool(np.array_equal(pix[m], base))
-                print(json.dumps({"config": cname, "mode": m, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                med, mn = statistics.median(times[v]), min(times[v])
+                same = bool(np.array_equal(pix[v], base))
+                print(json.dumps({"config": cname, "mode": m, "gate": g, "ms_median": round(med, 4), "ms_min": round(mn, 4),
                                   "Gray_s": round(rays / med / 1e6, 2), "same_as_first": same,
-                                  "psnr_vs_first": None if same else round(host.psnr(pix[m], base), 2),
+                                  "psnr_vs_first": None if same else round(host.psnr(pix[v], base), 2),
                                   "tests_per_sample": round(st["sphere_tests"] / st["samples"], 2),
                                   "alg_TFLOPs": round(20 * st["sphere_tests"] / med / 1e9, 3)}), flush=True)
 

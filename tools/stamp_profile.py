@@ -10,7 +10,7 @@ from raytracing_simple_amd import api, host, scenes  # noqa: E402
 from tools.ab_bench import CONFIGS  # noqa: E402
 
 NAMES = ["camera ray", "closest sweep", "hit point/normal", "light sample", "shadow sweep", "light contrib",
-         "diffuse bounce", "spec/refr", "loop trip", "accumulate"]
+         "diffuse bounce", "spec/refr", "loop trip", "accumulate", "closest roots", "shadow roots"]
 
 for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
     maker, w, h, spp = CONFIGS[cname]
@@ -24,7 +24,7 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
         st = ctx.stats()
         buf = (C.c_ulonglong * 24)()
         api.load_library().rt_debug_counters(ctx._h, buf)
-        v = list(buf)[:10]
+        v = list(buf)[:12]
         print(f"{cname}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
               f"active lanes per execution, executions per sample-wave")
         waves_samples = st["samples"] / 64.0
