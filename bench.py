@@ -68,10 +68,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # rehearsal knobs for a one-GPU box (never set by the driver): every rank on device 0,
+    # gloo instead of RCCL
+    if os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     spheres = host.demo_scene()
     cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, W, H)
@@ -118,6 +126,16 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
+    frame_ok = None
+    if world > 1 and rank == 0:
+        # the gathered frame of the last step against an unsharded render on this GPU
+        with api.RtContext(W, H, device=local_rank) as whole:
+            whole.set_scene(spheres)
+            whole.set_camera(cam)
+            whole.set_mode(mode)
+            want = whole.render_pass(SPP)
+        got = gather.full.cpu().numpy().astype("uint32").reshape(-1)
+        frame_ok = bool((got == want).all())
     st = ctx.stats()                      # counters of the last frame (reset clears them)
     counts = torch.tensor([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],
                           dtype=torch.int64, device=dev)
@@ -143,7 +161,7 @@ def main():
         alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 16 * len(spheres) * 3 + 60
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
+        if world == 1 and os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get(args.mode, {}).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
@@ -162,7 +180,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"C2: Demo scene (6 spheres), {W}x{H}, {SPP} spp, default seed stream",
-                       "mode": args.mode, "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
+                       "mode": args.mode, "collective": None if world == 1 else f"gather to rank 0 ({backend})",
+                       "gathered_frame_equals_unsharded": frame_ok, "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
                        "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
                        "Mray_s_all_rays": round((closest + shadow) * args.steps / elapsed / 1e6, 1),
                        "Msample_s": round(samples * args.steps / elapsed / 1e6, 1)},
