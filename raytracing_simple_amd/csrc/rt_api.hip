@@ -50,6 +50,8 @@ struct rt_ctx {
     bool have_scene = false, have_cam = false;
     int mode = RT_MODE_PARITY;
     int regen_gate = 0;           // 0 = choose from the scene size
+    int mat_lds_limit = 24 * 1024;
+    int coop_min = 64;            // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
     int current_sample = 0;
     uint64_t launches = 0;
     double last_ms = 0.0;
@@ -100,16 +102,19 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.local_rows = c->local_rows;
     p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
-    p.mat_in_lds = lds_all <= 64 * 1024;
+    // materials ride along in LDS only while that keeps at least 6 workgroups per CU resident
+    // (160 KiB / 24 KiB); larger scenes read them from L2 once per hit
+    p.mat_in_lds = lds_all <= (size_t)c->mat_lds_limit;
     const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
 
     dim3 grid((unsigned)((c->w + rt::kTileW - 1) / rt::kTileW),
               (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
     hipError_t e;
-    if (c->mode == RT_MODE_FAST) e = rt::launch_fast(0, p, grid, lds, stream);
+    const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+    if (c->mode == RT_MODE_FAST) e = rt::launch_fast(coop ? rt::kFastCoopVariant : 0, p, grid, lds, stream);
     else if (c->mode >= 200) e = rt::launch_fast(c->mode - 200, p, grid, lds, stream);
     else if (c->mode >= 100) e = rt::launch_parity(c->mode - 100, p, grid, lds, stream);
-    else e = rt::launch_parity(0, p, grid, lds, stream);
+    else e = rt::launch_parity(coop ? rt::kParityCoopVariant : 0, p, grid, lds, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
                     hipGetErrorString(e), grid.x, grid.y, lds);
@@ -254,8 +259,8 @@ int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
         HIP_TRY(hipMemcpy(d_lb, lb.data(), nl * sizeof(float4), hipMemcpyHostToDevice));
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, count, nl };
-    if (rt::lds_bytes(count, nl, false) > 159 * 1024)
-        return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 160 KiB)", rt::lds_bytes(count, nl, false));
+    if (rt::lds_bytes(count, nl, false) > 152 * 1024)
+        return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(count, nl, false));
     c->have_scene = true;
     return RT_OK;
 }
@@ -376,6 +381,18 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
 int rt_debug_set_regen_gate(rt_ctx *c, int gate) {
     if (!c || gate < 0 || gate > 64) return fail(RT_ERR_ARG, "gate %d", gate);
     c->regen_gate = gate;
+    return RT_OK;
+}
+
+int rt_debug_set_mat_lds_limit(rt_ctx *c, int bytes) {
+    if (!c || bytes < 0) return fail(RT_ERR_ARG, "bytes %d", bytes);
+    c->mat_lds_limit = bytes;
+    return RT_OK;
+}
+
+int rt_debug_set_coop_min(rt_ctx *c, int min_spheres) {
+    if (!c || min_spheres < 0) return fail(RT_ERR_ARG, "min_spheres %d", min_spheres);
+    c->coop_min = min_spheres;
     return RT_OK;
 }
 

@@ -58,6 +58,8 @@ inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, 
 // variant 0 = the shipped instance; higher indices are A/B shapes (mode 100+k / 200+k)
 hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
+constexpr int kParityCoopVariant = 4;   // index of the cooperative-shadow instance in each table
+constexpr int kFastCoopVariant = 3;
 int parity_variant_count();
 int fast_variant_count();
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);

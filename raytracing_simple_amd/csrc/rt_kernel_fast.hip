@@ -26,10 +26,19 @@
 #undef RT_OPT_UNROLL
 #undef RT_OPT_SKIPNEG
 
+#define RT_NS fast_coop
+#define RT_KERNEL_NAME rt_trace_fast_coop
+#define RT_OPT_COOP 1
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_COOP
+
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
-static KernelFn const kFastKernels[] = { fast::rt_trace_fast, fast_a1::rt_trace_fast_a1, fast::rt_sched_fast };
+static KernelFn const kFastKernels[] = { fast::rt_trace_fast, fast_a1::rt_trace_fast_a1, fast::rt_sched_fast,
+                                           fast_coop::rt_trace_fast_coop };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 
 int fast_variant_count() { return kFastCount; }
@@ -43,7 +52,7 @@ hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds
 hipError_t prepare_fast() {
     for (KernelFn k : kFastKernels) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -18,6 +18,22 @@
 #undef RT_OPT_UNROLL
 #undef RT_OPT_SKIPNEG
 
+#define RT_NS parity_coop
+#define RT_KERNEL_NAME rt_trace_parity_coop
+#define RT_OPT_COOP 1
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_COOP
+
+#define RT_NS parity_coopv
+#define RT_KERNEL_NAME rt_trace_parity_coopv
+#define RT_OPT_COOP 2
+#include "rt_trace.inc.h"
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_OPT_COOP
+
 #define RT_NS parity_a5
 #define RT_KERNEL_NAME rt_trace_parity_a5
 #define RT_SCHED_KERNEL_NAME rt_sched_parity_a5
@@ -34,7 +50,9 @@ namespace rt {
 using KernelFn = void (*)(const LaunchParams);
 static KernelFn const kParityKernels[] = {
     parity::rt_trace_parity, parity_a5::rt_trace_parity_a5,
-    parity::rt_sched_parity, parity_a5::rt_sched_parity_a5,
+    parity::rt_sched_parity, parity_a5::rt_sched_parity_a5, parity_coop::rt_trace_parity_coop,
+    parity_coopv::rt_trace_parity_coopv,
+
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
@@ -56,7 +74,7 @@ hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hip
 hipError_t prepare_parity() {
     for (KernelFn k : kParityKernels) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

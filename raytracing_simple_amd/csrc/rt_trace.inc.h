@@ -44,6 +44,13 @@
 #ifndef RT_OPT_STAMPS
 #define RT_OPT_STAMPS 0
 #endif
+#ifndef RT_OPT_WAVE_TILE_W
+#define RT_OPT_WAVE_TILE_W 8
+#endif
+// RT_OPT_COOP: shadow rays of a wavefront share the idle lanes (coop_any); for large scenes
+#ifndef RT_OPT_COOP
+#define RT_OPT_COOP 0
+#endif
 
 #undef RT_STAMP
 #undef RT_STAMP_ROOTS
@@ -168,6 +175,18 @@ RT_DEV bool wave_any_nonneg(float det) {
     return true;
 #endif
 }
+// Per-lane "the roots can matter".  Besides det < 0 a sphere is out when it lies behind the
+// ray: b < 0 and det <= fl(b*b) give sqrt_rn(det) <= sqrt_rn(fl(b*b)) = |b| (correctly rounded
+// sqrt is monotonic and returns |b| for a rounded square), so b - sq and b + sq are both <= 0
+// < EPSILON and the reference returns 0.
+RT_DEV float roots_matter(HitPre p) {
+#if RT_OPT_SKIPNEG >= 2
+    const float bb = p.b * p.b;
+    return (p.det >= 0.f && (p.b >= 0.f || p.det > bb)) ? 1.f : -1.f;
+#else
+    return p.det;
+#endif
+}
 
 // closest hit over spheres [0, n): .cl:215-232
 RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id,
@@ -178,7 +197,7 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1], g2 = s_geom[i + 2], g3 = s_geom[i + 3];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d), p2 = hit_pre(g2, o, d),
                      p3 = hit_pre(g3, o, d);
-        if (wave_any_nonneg(fmaxf(fmaxf(p0.det, p1.det), fmaxf(p2.det, p3.det)))) {
+        if (wave_any_nonneg(fmaxf(fmaxf(roots_matter(p0), roots_matter(p1)), fmaxf(roots_matter(p2), roots_matter(p3))))) {
             roots += 4;
             const float h0 = hit_post(p0), h1 = hit_post(p1), h2 = hit_post(p2), h3 = hit_post(p3);
             if (h0 != 0.f && h0 < t) { t = h0; id = i; }
@@ -192,12 +211,12 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
-        if (wave_any_nonneg(p0.det)) {
+        if (wave_any_nonneg(roots_matter(p0))) {
             roots += 1;
             const float h0 = hit_post(p0);
             if (h0 != 0.f && h0 < t) { t = h0; id = i; }
         }
-        if (wave_any_nonneg(p1.det)) {
+        if (wave_any_nonneg(roots_matter(p1))) {
             roots += 1;
             const float h1 = hit_post(p1);
             if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
@@ -206,7 +225,7 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
 #endif
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
-        if (wave_any_nonneg(p0.det)) {
+        if (wave_any_nonneg(roots_matter(p0))) {
             roots += 1;
             const float h0 = hit_post(p0);
             if (h0 != 0.f && h0 < t) { t = h0; id = i; }
@@ -224,7 +243,7 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
-        if (wave_any_nonneg(fmaxf(p0.det, p1.det))) {
+        if (wave_any_nonneg(fmaxf(roots_matter(p0), roots_matter(p1)))) {
             roots += 2;
             const float h0 = hit_post(p0), h1 = hit_post(p1);
             const bool b0 = (h0 != 0.f && h0 < max_t), b1 = (h1 != 0.f && h1 < max_t);
@@ -236,7 +255,7 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
 #endif
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
-        if (wave_any_nonneg(p0.det)) {
+        if (wave_any_nonneg(roots_matter(p0))) {
             roots += 1;
             const float h0 = hit_post(p0);
             const uint32_t cand = (h0 != 0.f && h0 < max_t) ? i : n;
@@ -246,6 +265,100 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
     }
     return first;
 }
+
+// One light of SampleLights (.cl:258-295) up to the visibility test.  Draws its two numbers
+// whatever happens next, as the reference does.  Returns true when a shadow ray is needed and
+// then gives its unit direction, its length and the numerator 4*pi*r^2*wi*wo of .cl:297.
+RT_DEV bool sample_light(float4 la, float4 lb, uint32_t &s0, uint32_t &s1, uint32_t &c_draws, V3 hp, V3 nl,
+                         V3 &sd, float &len, float &numer) {
+    float u1 = next_random(s0, s1);
+    float u2 = next_random(s0, s1);
+    c_draws += 2;
+    float zc = 1.f - 2.f * u1;                                             // .cl:203-213
+    float ring = rt_sqrt(fmaxf(0.f, 1.f - zc * zc));
+    float sphi, cphi;
+#if RT_FAST
+    fm_sincos_turns(u2, sphi, cphi);
+#else
+    dm_sincosf_pos((2.f * RT_PI) * u2, sphi, cphi);
+#endif
+    V3 us = mk(ring * cphi, ring * sphi, zc);
+    V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
+    sd = sub(on_light, hp);
+    len = rt_sqrt(dot(sd, sd));
+    sd = scale(sd, rt_rcp(len));
+    float wo = dot(sd, us);
+    if (wo > 0.f) return false;                                            // far side of the light
+    wo = -wo;
+    float wi = dot(sd, nl);
+    numer = lb.w * wi * wo;
+    return wi > 0.f;
+}
+
+#if RT_OPT_COOP
+constexpr int kCoopSlots = 32;                          // pending rays a wavefront can share out
+constexpr int kCoopWaveFloats = kCoopSlots * 9;         // per wavefront: 2 float4 + 1 word per slot
+
+// Cooperative any-hit (.cl:234-247) for the `want` lanes of a wavefront.  Called by every lane
+// that is in the loop.  K = pending rays (wave ballot); with G = 64 / K >= 2 each ray is tested
+// by G lanes, lane g of a ray taking spheres g, g+G, g+2G, ...; the smallest blocking index per
+// ray is combined with an LDS atomic min, so the result (and the test count derived from it)
+// equals the sequential sweep.  G counts only the lanes that are present in this call (a wave
+// ballot of the callers).  With G < 2 the lanes sweep for themselves.
+RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d, float max_t, float *scratch) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    const int K = __popcll(m);
+    if (K == 0) return n;
+    // lanes that are here to help: finished or gated lanes of the wavefront are not
+    const unsigned long long present = __builtin_amdgcn_ballot_w64(true);
+    const int G = __popcll(present) / K;
+    unsigned long long unused_roots = 0;
+    if (G < 2) {
+        uint32_t first = n;
+        if (want) first = sweep_any(s_geom, n, o, d, max_t, unused_roots);
+        return first;
+    }
+    float4 *ray_a = reinterpret_cast<float4 *>(scratch);                   // {origin, max_t}
+    float4 *ray_b = ray_a + kCoopSlots;                                    // {direction, -}
+    uint32_t *res = reinterpret_cast<uint32_t *>(ray_b + kCoopSlots);      // min blocking index
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (want) {
+        ray_a[rank] = make_float4(o.x, o.y, o.z, max_t);
+        ray_b[rank] = make_float4(d.x, d.y, d.z, 0.f);
+        res[rank] = n;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(present >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)present, 0u));
+    const int slot = idx % K;
+    const int grp = idx / K;
+    if (grp < G) {
+        const float4 ra = ray_a[slot];
+        const float4 rb = ray_b[slot];
+        const V3 ro = mk(ra.x, ra.y, ra.z), rd = mk(rb.x, rb.y, rb.z);
+        uint32_t found = n;
+        for (uint32_t i = (uint32_t)grp; i < n; i += (uint32_t)G) {
+            const HitPre p0 = hit_pre(s_geom[i], ro, rd);
+            if (wave_any_nonneg(p0.det)) {
+                const float h0 = hit_post(p0);
+                if (h0 != 0.f && h0 < ra.w) {
+                    found = i;
+                    break;
+                }
+            }
+        }
+        if (found < n) atomicMin(&res[slot], found);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t first = n;
+    if (want) first = res[rank];
+    __builtin_amdgcn_wave_barrier();
+    return first;
+}
+#endif
 
 // .cl:34
 RT_DEV int to_int(float v) {
@@ -302,8 +415,16 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 
     // ---- pixel of this lane ---------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
-    const int x = blockIdx.x * kTileW + wave * 8 + (lane & 7);
+#if RT_OPT_WAVE_TILE_W == 8
+    const int x = blockIdx.x * kTileW + wave * 8 + (lane & 7);              // 4 x 1 waves of 8x8
     const int lrow = blockIdx.y * kTileH + (lane >> 3);
+#elif RT_OPT_WAVE_TILE_W == 16
+    const int x = blockIdx.x * kTileW + (wave & 1) * 16 + (lane & 15);      // 2 x 2 waves of 16x4
+    const int lrow = blockIdx.y * kTileH + (wave >> 1) * 4 + (lane >> 4);
+#else
+    const int x = blockIdx.x * kTileW + (lane & 31);                        // 1 x 4 waves of 32x2
+    const int lrow = blockIdx.y * kTileH + wave * 2 + (lane >> 5);
+#endif
     const int tile = lrow / P.tile_rows;
     const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
@@ -339,6 +460,9 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     bool need_ray = true;
 
     unsigned long long st_roots_c = 0, st_roots_s = 0;   // wave-uniform; dead unless RT_OPT_STAMPS
+#if RT_OPT_COOP
+    __shared__ __attribute__((aligned(16))) float s_coop[4 * kCoopWaveFloats];
+#endif
 #if RT_OPT_STAMPS
     __shared__ unsigned long long s_census[12];
     if (tid < 12) s_census[tid] = 0;
@@ -390,10 +514,10 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         c_closest += 1;
         c_tests += n;
 
-#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 1
-        t = 1e20f;   // diagnostic: every ray misses
-#endif
         bool path_done = false;
+        bool is_diff = false, is_gloss = false;   // what the hit asks for next
+        V3 hp = o, nrm = d, nl = d, col = thr;
+        int refl = RT_DIFF;
         if (!(t < 1e20f)) {
             path_done = true;                                              // miss, .cl:327-330
         } else {
@@ -402,150 +526,167 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
             const float4 em4 = m_emis[id];
             const float4 co4 = m_colr[id];
             const V3 em = mk(em4.x, em4.y, em4.z);
-            const V3 col = mk(co4.x, co4.y, co4.z);
-            const int refl = __float_as_int(em4.w);
+            col = mk(co4.x, co4.y, co4.z);
+            refl = __float_as_int(em4.w);
 
-            V3 hp = add(o, scale(d, t));                                   // .cl:338-340
-            V3 nrm = unit(sub(hp, mk(ge.x, ge.y, ge.z)));                  // .cl:345-347
+            hp = add(o, scale(d, t));                                      // .cl:338-340
+            nrm = unit(sub(hp, mk(ge.x, ge.y, ge.z)));                     // .cl:345-347
             float dp = dot(nrm, d);
-            V3 nl = scale(nrm, -1.f * cl_sign(dp));                        // .cl:354-355
+            nl = scale(nrm, -1.f * cl_sign(dp));                           // .cl:354-355
 
-#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 2
-            if (true) {   // diagnostic: every hit ends the path like an emitter
-#else
             if (!((em.x == 0.f) && (em.z == 0.f))) {                       // .cl:358-368
-#endif
                 if (after_specular) rad = add(rad, mul(thr, scale(em, fabsf(dp))));
                 path_done = true;
-            } else if (refl == RT_DIFF) {                                  // .cl:370-412
+            } else if (refl == RT_DIFF) {                                  // .cl:370-373
                 after_specular = false;
                 thr = mul(thr, col);
+                is_diff = true;
+            } else {
+                is_gloss = true;
+            }
+        }
 
-                // ---- next-event estimation, .cl:249-303 ----
-                V3 ld = mk(0.f, 0.f, 0.f);
-                for (uint32_t j = 0; j < n_lights; ++j) {
+        // ---- next-event estimation, .cl:249-303 ----
+        V3 ld = mk(0.f, 0.f, 0.f);
+#if RT_OPT_COOP
+        // The light loop runs at wavefront level so that lanes without a shadow ray of their
+        // own (not diffuse, far side of the light, facing away) can take part of the any-hit
+        // sweep of the lanes that have one: coop_any splits the sphere list of each pending
+        // ray over 64/K lanes (K = rays pending in the wavefront, from a wave ballot).
+        if (__builtin_amdgcn_ballot_w64(is_diff) != 0ull) {
+            for (uint32_t j = 0; j < n_lights; ++j) {
+                bool want = false;
+                V3 sd = mk(0.f, 0.f, 1.f);
+                float len = 1.f, numer = 0.f;
+                const float4 lb = s_lightB[j];
+                if (is_diff) {
                     RT_STAMP(3);
-                    const float4 la = s_lightA[j];
-                    const float4 lb = s_lightB[j];
-                    float u1 = next_random(s0, s1);
-                    float u2 = next_random(s0, s1);
-                    c_draws += 2;
-#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 5
-                    asm volatile("" ::"v"(u1), "v"(u2));
-                    continue;   // diagnostic: draws kept (same paths), light sampling skipped
-#endif
-                    float zc = 1.f - 2.f * u1;                             // .cl:203-213
-                    float ring = rt_sqrt(fmaxf(0.f, 1.f - zc * zc));
-                    float sphi, cphi;
-#if RT_FAST
-                    fm_sincos_turns(u2, sphi, cphi);
-#else
-                    dm_sincosf_pos((2.f * RT_PI) * u2, sphi, cphi);
-#endif
-                    V3 us = mk(ring * cphi, ring * sphi, zc);
-                    V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
-                    V3 sd = sub(on_light, hp);
-                    float len = rt_sqrt(dot(sd, sd));
-                    sd = scale(sd, rt_rcp(len));
-                    float wo = dot(sd, us);
-                    if (wo > 0.f) continue;                                // far side of the light
-                    wo = -wo;
-                    float wi = dot(sd, nl);
-                    if (wi > 0.f) {
-                        // ---- shadow ray, any hit, .cl:234-247 ----
-                        const float max_t = len - RT_EPS;
-                        c_shadow += 1;
-                        RT_STAMP(4);
-#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 6
-                        const uint32_t first = n;   // diagnostic: shadow rays never blocked, no sweep
-                        asm volatile("" ::"v"(max_t));
-#else
-                        st_roots_s = 0;
-                        const uint32_t first = sweep_any(s_geom, n, hp, sd, max_t, st_roots_s);
-                        RT_STAMP_ROOTS(11, st_roots_s);
-#endif
-                        const bool blocked = first < n;
-                        c_tests += blocked ? first + 1 : n;
-                        if (!blocked) {
-                            RT_STAMP(5);
-                            float k = rt_div(lb.w * wi * wo, len * len);   // .cl:297
-                            ld = add(ld, scale(mk(lb.x, lb.y, lb.z), k));
+                    want = sample_light(s_lightA[j], lb, s0, s1, c_draws, hp, nl, sd, len, numer);
+                }
+                RT_STAMP(4);
+                const uint32_t first = coop_any(s_geom, n, want, hp, sd, len - RT_EPS, s_coop + wave * kCoopWaveFloats);
+#if RT_OPT_COOP == 2
+                {   // verification instance: the sequential sweep beside the cooperative one
+                    unsigned long long dummy = 0;
+                    const unsigned long long mm = __builtin_amdgcn_ballot_w64(want);
+                    if (want) {
+                        const uint32_t ref_first = sweep_any(s_geom, n, hp, sd, len - RT_EPS, dummy);
+                        atomicAdd(&P.counters[20], 1ull);
+                        if (ref_first != first) {
+                            atomicAdd(&P.counters[21], 1ull);
+                            P.counters[22] = ((unsigned long long)__popcll(mm) << 48) | ((unsigned long long)first << 24) | ref_first;
+                            {
+                                const int K_ = __popcll(mm), G_ = 64 / K_;
+                                const int rank_ = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+                                const float4 g_ = s_geom[ref_first];
+                                const HitPre pp = hit_pre(g_, hp, sd);
+                                P.counters[23] = ((unsigned long long)rank_ << 48) | ((unsigned long long)(ref_first % G_) << 32) |
+                                                 (unsigned long long)__float_as_uint(pp.det);
+                            }
                         }
                     }
                 }
-                rad = add(rad, mul(thr, ld));                              // .cl:377-378
-                RT_STAMP(6);
-#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 3
-                depth = kMaxDepth;   // diagnostic: stop after direct lighting
-#else
-
-                // ---- cosine-weighted bounce, .cl:383-411 ----
-                float u = next_random(s0, s1);
-                float r2 = next_random(s0, s1);
-                c_draws += 2;
-                float r2s = rt_sqrt(r2);
-                V3 w = nl;
-                V3 a = (fabsf(w.x) > .1f) ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
-                V3 uu = unit(cross(a, w));
-                V3 vv = cross(w, uu);
-                float s1v, c1v;
-#if RT_FAST
-                fm_sincos_turns(u, s1v, c1v);
-#else
-                dm_sincosf_pos((2.f * RT_PI) * u, s1v, c1v);
 #endif
-                V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
-                nd = add(nd, scale(w, rt_sqrt(1 - r2)));
-                o = hp;
-                d = nd;
-#if defined(RT_OPT_TRUNC) && RT_OPT_TRUNC == 4
-                asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z));
-                depth = kMaxDepth;   // diagnostic: stop after the first diffuse bounce is sampled
-#endif
-#endif
-            } else {
-                // reflection direction shared by SPEC and REFR, .cl:416-419 / 428-431
-                RT_STAMP(7);
-                V3 rfl = sub(d, scale(nrm, 2.f * dot(nrm, d)));
-                after_specular = true;
-                if (refl == RT_SPEC) {                                     // .cl:413-424
-                    thr = mul(thr, col);
-                    o = hp;
-                    d = rfl;
-                } else {                                                   // .cl:425-489
-                    bool into = dot(nrm, nl) > 0.f;
-                    const float nc = 1.f, nt = 1.52f;
-                    float nnt = into ? nc / nt : nt / nc;
-                    float ddn = dot(d, nl);
-                    float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
-                    if (cos2t < 0.f) {                                     // total internal reflection
-                        thr = mul(thr, col);
-                        o = hp;
-                        d = rfl;
-                    } else {
-                        float kk = (into ? 1.f : -1.f) * (ddn * nnt + rt_sqrt(cos2t));
-                        V3 td = unit(sub(scale(d, nnt), scale(nrm, kk)));
-                        const float fa = nt - nc, fb = nt + nc;
-                        const float R0 = fa * fa / (fb * fb);
-                        float c = 1 - (into ? -ddn : dot(td, nrm));
-                        float Re = R0 + (1 - R0) * c * c * c * c * c;
-                        float Tr = 1.f - Re;
-                        float Pr = .25f + .5f * Re;
-                        float RP = rt_div(Re, Pr);
-                        float TP = rt_div(Tr, 1.f - Pr);
-                        float pick = next_random(s0, s1);
-                        c_draws += 1;
-                        if (pick < Pr) {
-                            thr = mul(scale(thr, RP), col);
-                            d = rfl;
-                        } else {
-                            thr = mul(scale(thr, TP), col);
-                            d = td;
-                        }
-                        o = hp;
+                if (want) {
+                    c_shadow += 1;
+                    const bool blocked = first < n;
+                    c_tests += blocked ? first + 1 : n;
+                    if (!blocked) {
+                        float k = rt_div(numer, len * len);                // .cl:297
+                        ld = add(ld, scale(mk(lb.x, lb.y, lb.z), k));
                     }
                 }
             }
+        }
+#else
+        if (is_diff) {
+            for (uint32_t j = 0; j < n_lights; ++j) {
+                RT_STAMP(3);
+                const float4 lb = s_lightB[j];
+                V3 sd;
+                float len, numer;
+                if (!sample_light(s_lightA[j], lb, s0, s1, c_draws, hp, nl, sd, len, numer)) continue;
+                // ---- shadow ray, any hit, .cl:234-247 ----
+                c_shadow += 1;
+                RT_STAMP(4);
+                st_roots_s = 0;
+                const uint32_t first = sweep_any(s_geom, n, hp, sd, len - RT_EPS, st_roots_s);
+                RT_STAMP_ROOTS(11, st_roots_s);
+                const bool blocked = first < n;
+                c_tests += blocked ? first + 1 : n;
+                if (!blocked) {
+                    RT_STAMP(5);
+                    float k = rt_div(numer, len * len);                    // .cl:297
+                    ld = add(ld, scale(mk(lb.x, lb.y, lb.z), k));
+                }
+            }
+        }
+#endif
+
+        if (is_diff) {
+            rad = add(rad, mul(thr, ld));                                  // .cl:377-378
+            RT_STAMP(6);
+            // ---- cosine-weighted bounce, .cl:383-411 ----
+            float u = next_random(s0, s1);
+            float r2 = next_random(s0, s1);
+            c_draws += 2;
+            float r2s = rt_sqrt(r2);
+            V3 w = nl;
+            V3 a = (fabsf(w.x) > .1f) ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
+            V3 uu = unit(cross(a, w));
+            V3 vv = cross(w, uu);
+            float s1v, c1v;
+#if RT_FAST
+            fm_sincos_turns(u, s1v, c1v);
+#else
+            dm_sincosf_pos((2.f * RT_PI) * u, s1v, c1v);
+#endif
+            V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
+            nd = add(nd, scale(w, rt_sqrt(1 - r2)));
+            o = hp;
+            d = nd;
+        } else if (is_gloss) {
+            // reflection direction shared by SPEC and REFR, .cl:416-419 / 428-431
+            RT_STAMP(7);
+            V3 rfl = sub(d, scale(nrm, 2.f * dot(nrm, d)));
+            after_specular = true;
+            if (refl == RT_SPEC) {                                         // .cl:413-424
+                thr = mul(thr, col);
+                d = rfl;
+            } else {                                                       // .cl:425-489
+                bool into = dot(nrm, nl) > 0.f;
+                const float nc = 1.f, nt = 1.52f;
+                float nnt = into ? nc / nt : nt / nc;
+                float ddn = dot(d, nl);
+                float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
+                if (cos2t < 0.f) {                                         // total internal reflection
+                    thr = mul(thr, col);
+                    d = rfl;
+                } else {
+                    float kk = (into ? 1.f : -1.f) * (ddn * nnt + rt_sqrt(cos2t));
+                    V3 td = unit(sub(scale(d, nnt), scale(nrm, kk)));
+                    const float fa = nt - nc, fb = nt + nc;
+                    const float R0 = fa * fa / (fb * fb);
+                    float c = 1 - (into ? -ddn : dot(td, nrm));
+                    float Re = R0 + (1 - R0) * c * c * c * c * c;
+                    float Tr = 1.f - Re;
+                    float Pr = .25f + .5f * Re;
+                    float RP = rt_div(Re, Pr);
+                    float TP = rt_div(Tr, 1.f - Pr);
+                    float pick = next_random(s0, s1);
+                    c_draws += 1;
+                    if (pick < Pr) {
+                        thr = mul(scale(thr, RP), col);
+                        d = rfl;
+                    } else {
+                        thr = mul(scale(thr, TP), col);
+                        d = td;
+                    }
+                }
+            }
+            o = hp;
+        }
+        if (is_diff || is_gloss) {
             depth += 1;
             if (depth >= kMaxDepth) path_done = true;                      // .cl:320
         }

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--modes", default="0,1")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--coop-min", type=int, default=-1, help="override the cooperative any-hit threshold (0 = off)")
+    ap.add_argument("--mat-lds", type=int, default=-1, help="override the LDS byte limit for staging materials")
     ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
     args = ap.parse_args()
     modes = [int(m) for m in args.modes.split(",")]
@@ -51,6 +53,10 @@ def main():
             times = {v: [] for v in variants}
             pix, stats = {}, {}
             lib = api.load_library()
+            if args.mat_lds >= 0:
+                lib.rt_debug_set_mat_lds_limit(ctx._h, args.mat_lds)
+            if args.coop_min >= 0:
+                lib.rt_debug_set_coop_min(ctx._h, args.coop_min)
             for r in range(args.rounds + 1):
                 for v in variants:
                     m, g = v
