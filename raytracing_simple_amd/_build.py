@@ -24,7 +24,7 @@ UNITS = [
     ("rt_api.hip", ["-ffp-contract=off"]),
     ("rt_host.cpp", ["-ffp-contract=off"]),
 ]
-DEPS = ["rt_device.h", "rt_detmath.h", "rt_trace.inc.h", "rt_sched.inc.h", os.path.join("..", "..", "include", "rt_api.h")]
+DEPS = ["rt_device.h", "rt_detmath.h", "rt_trace.inc.h", "rt_sched.inc.h", "rt_opts_reset.h", os.path.join("..", "..", "include", "rt_api.h")]
 
 
 def hipcc():

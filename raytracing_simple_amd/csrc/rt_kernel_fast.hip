@@ -1,38 +1,31 @@
 // rt_kernel_fast.hip -- fused-arithmetic instances of the path-trace kernel
 // (-ffp-contract=fast, hardware rcp/rsq/sqrt/sin/cos/exp2/log2).  Gated by PSNR >= 50 dB
 // against the parity instance at equal spp (tests/test_gpu_parity.py).
+//   [0] rt_trace_fast, [3] rt_trace_fast_coop: shipped; the others are A/B shapes (mode 200+k).
 #define RT_FAST 1
 
 #define RT_NS fast
 #define RT_KERNEL_NAME rt_trace_fast
-#define RT_SCHED_KERNEL_NAME rt_sched_fast
 #include "rt_trace.inc.h"
+#define RT_SCHED_KERNEL_NAME rt_sched_fast
 #include "rt_sched.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_SCHED_KERNEL_NAME
+#include "rt_opts_reset.h"
 
 #define RT_VARIANT_KERNEL 1
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
 
-#define RT_NS fast_a1
+#define RT_NS fast_a1                /* the round-1 sweep shape: no unroll, no ballot skip */
 #define RT_KERNEL_NAME rt_trace_fast_a1
 #define RT_OPT_UNROLL 1
 #define RT_OPT_SKIPNEG 0
 #include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
+#include "rt_opts_reset.h"
 
 #define RT_NS fast_coop
 #define RT_KERNEL_NAME rt_trace_fast_coop
 #define RT_OPT_COOP 1
+#define RT_OPT_UNROLL 4
 #include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_COOP
+#include "rt_opts_reset.h"
 
 namespace rt {
 

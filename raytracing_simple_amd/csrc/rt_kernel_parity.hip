@@ -1,58 +1,55 @@
 // rt_kernel_parity.hip -- strict-arithmetic instances of the path-trace kernel.
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
-// Instance 0 is the shipped one (RT_MODE_PARITY); the others are A/B shapes of the same
-// arithmetic, selectable as mode 100+k for in-process comparisons (tools/ab_bench.py).
+//   [0] rt_trace_parity        shipped: small and medium scenes
+//   [4] rt_trace_parity_coop   shipped: scenes with >= 64 spheres (cooperative any-hit)
+// the rest are A/B and diagnostic shapes of the same arithmetic (mode 100+k, tools/ab_bench.py).
 #pragma clang fp contract(off)
 #define RT_FAST 0
 
 #define RT_NS parity
 #define RT_KERNEL_NAME rt_trace_parity
-#define RT_SCHED_KERNEL_NAME rt_sched_parity
+#define RT_OPT_MINWAVES 6            /* <= 80 VGPRs: 6 wavefronts per SIMD */
 #include "rt_trace.inc.h"
+#undef RT_OPT_MINWAVES
+#define RT_OPT_MINWAVES 1
+#define RT_SCHED_KERNEL_NAME rt_sched_parity
 #include "rt_sched.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_SCHED_KERNEL_NAME
+#include "rt_opts_reset.h"
 
-#define RT_VARIANT_KERNEL 1
-#undef RT_OPT_UNROLL
-#undef RT_OPT_SKIPNEG
+#define RT_VARIANT_KERNEL 1          /* the scalar-op eval kernel exists once, above */
 
 #define RT_NS parity_coop
 #define RT_KERNEL_NAME rt_trace_parity_coop
 #define RT_OPT_COOP 1
+#define RT_OPT_UNROLL 4
+#define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_COOP
+#include "rt_opts_reset.h"
 
-#define RT_NS parity_coopv
+#define RT_NS parity_coopv           /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coopv
 #define RT_OPT_COOP 2
 #include "rt_trace.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_OPT_COOP
+#include "rt_opts_reset.h"
 
-#define RT_NS parity_a5
+#define RT_NS parity_a5              /* section census (tools/stamp_profile.py) */
 #define RT_KERNEL_NAME rt_trace_parity_a5
 #define RT_SCHED_KERNEL_NAME rt_sched_parity_a5
 #define RT_OPT_STAMPS 1
 #include "rt_trace.inc.h"
 #include "rt_sched.inc.h"
-#undef RT_NS
-#undef RT_KERNEL_NAME
-#undef RT_SCHED_KERNEL_NAME
-#undef RT_OPT_STAMPS
+#include "rt_opts_reset.h"
 
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
 static KernelFn const kParityKernels[] = {
-    parity::rt_trace_parity, parity_a5::rt_trace_parity_a5,
-    parity::rt_sched_parity, parity_a5::rt_sched_parity_a5, parity_coop::rt_trace_parity_coop,
-    parity_coopv::rt_trace_parity_coopv,
-
+    parity::rt_trace_parity,            // 0
+    parity_a5::rt_trace_parity_a5,      // 1  census
+    parity::rt_sched_parity,            // 2  stage-scheduled (in-register queue) A/B
+    parity_a5::rt_sched_parity_a5,      // 3  its census
+    parity_coop::rt_trace_parity_coop,  // 4  = kParityCoopVariant
+    parity_coopv::rt_trace_parity_coopv,  // 5
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 

@@ -1,0 +1,11 @@
+// rt_opts_reset.h -- forget every per-instance option before the next instantiation of
+// rt_trace.inc.h / rt_sched.inc.h (no include guard: meant to be included repeatedly).
+#undef RT_NS
+#undef RT_KERNEL_NAME
+#undef RT_SCHED_KERNEL_NAME
+#undef RT_OPT_UNROLL
+#undef RT_OPT_SKIPNEG
+#undef RT_OPT_STAMPS
+#undef RT_OPT_WAVE_TILE_W
+#undef RT_OPT_COOP
+#undef RT_OPT_MINWAVES

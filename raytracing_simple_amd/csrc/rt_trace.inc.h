@@ -460,6 +460,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     bool need_ray = true;
 
     unsigned long long st_roots_c = 0, st_roots_s = 0;   // wave-uniform; dead unless RT_OPT_STAMPS
+    (void)st_roots_s;
 #if RT_OPT_COOP
     __shared__ __attribute__((aligned(16))) float s_coop[4 * kCoopWaveFloats];
 #endif

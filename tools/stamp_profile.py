@@ -19,7 +19,7 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
     with api.RtContext(w, h) as ctx:
         ctx.set_scene(sph)
         ctx.set_camera(cam)
-        ctx.set_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 105)
+        ctx.set_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 101)
         ctx.render_pass(spp, copy=False)
         st = ctx.stats()
         buf = (C.c_ulonglong * 24)()
