@@ -6,7 +6,8 @@ per pixel (= 64 passes of the reference's Config::updateRendering()), from the d
 stream, rendered by the HIP path through the C ABI.  Inputs (seeds, scene tables, camera) are
 resident in HBM before the timed region.  With N > 1 (one process per GPU, launched by
 torch.distributed.run) the image is sharded by interleaved 8-row tiles and each frame ends with
-one RCCL gather of the packed pixels to rank 0; total work is fixed, so scaling is "strong".
+one RCCL gather of the packed pixels to rank 0 (issued asynchronously: frame k's gather overlaps
+frame k+1's render, two send buffers); total work is fixed, so scaling is "strong".
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode parity|fast] [--no-cpu]
 
@@ -93,11 +94,18 @@ def main():
     stream = torch.cuda.current_stream()
     sh = stream.cuda_stream
     gather = None
+    SLOTS = 2          # frame k's gather overlaps frame k+1's render
     if world > 1:
-        gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev)
-        local_view = torch.as_tensor(ctx.device_pixels_array(), device=dev)
+        gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=SLOTS)
+    frame_no = [0]
 
     def step(ev=None):
+        k = frame_no[0]
+        frame_no[0] += 1
+        if gather is not None:
+            gather.wait(k)                                  # slot free again (its gather of frame k-2)
+            buf = gather.local_slot(k)
+            ctx.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
         ctx.reset_async(sh)
         if ev:
             ev[0].record(stream)
@@ -105,8 +113,12 @@ def main():
         if ev:
             ev[1].record(stream)
         if gather is not None:
-            gather.local[: gather.n_local].copy_(local_view[: gather.n_local])
-            gather.gather()
+            gather.gather(k, async_op=True)                 # queued behind the launch, not waited for
+
+    def drain():
+        if gather is not None:
+            for k in range(SLOTS):
+                gather.wait(k)
 
     def sync():
         torch.cuda.synchronize()
@@ -116,12 +128,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    drain()                                                 # every frame gathered and assembled
     sync()
     elapsed = time.perf_counter() - t0
 
@@ -134,7 +148,7 @@ def main():
             whole.set_camera(cam)
             whole.set_mode(mode)
             want = whole.render_pass(SPP)
-        got = gather.full.cpu().numpy().astype("uint32").reshape(-1)
+        got = gather.wait(frame_no[0] - 1).cpu().numpy().astype("uint32").reshape(-1)
         frame_ok = bool((got == want).all())
     st = ctx.stats()                      # counters of the last frame (reset clears them)
     counts = torch.tensor([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],

@@ -125,6 +125,12 @@ int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);
 /* Device address and element count (uint32) of the local pixel buffer.                       */
 int rt_device_pixels(rt_ctx *ctx, void **dptr, size_t *count);
 
+/* Redirect the packed pixels of later launches into a caller-owned DEVICE buffer of at least
+ * rt_local_rows()*w uint32 (e.g. the send buffer of the frame-end gather, so no copy is needed);
+ * NULL restores the context's own buffer.  The caller keeps the buffer alive and orders its
+ * reuse against the launches it issued.                                                      */
+int rt_set_pixel_buffer(rt_ctx *ctx, void *dptr, size_t count);
+
 int rt_local_rows(const rt_ctx *ctx);                      /* rows this context renders       */
 int rt_current_sample(const rt_ctx *ctx);                  /* mCurrentSample                  */
 

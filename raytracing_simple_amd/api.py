@@ -16,7 +16,7 @@ DIFF, SPEC, REFR = 0, 1, 2
 # every symbol include/rt_api.h declares (tests/test_abi.py checks the export table)
 SYMBOLS = ["rt_render", "rt_create", "rt_create_sharded", "rt_destroy", "rt_set_scene",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
-           "rt_device_pixels", "rt_local_rows", "rt_current_sample", "rt_read_colors",
+           "rt_device_pixels", "rt_set_pixel_buffer", "rt_local_rows", "rt_current_sample", "rt_read_colors",
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_compute_camera",
            "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_debug_eval"]
 
@@ -72,6 +72,7 @@ def load_library():
         "rt_render_pass": (i32, [vp, vp, i32]),
         "rt_render_async": (i32, [vp, i32, vp]),
         "rt_device_pixels": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
+        "rt_set_pixel_buffer": (i32, [vp, vp, sz]),
         "rt_local_rows": (i32, [vp]),
         "rt_current_sample": (i32, [vp]),
         "rt_read_colors": (i32, [vp, vp]),
@@ -184,6 +185,10 @@ class RtContext:
 
     def render_async(self, n_samples, stream=None):
         _check(self._lib.rt_render_async(self._h, n_samples, C.c_void_p(stream or 0)))
+
+    def set_pixel_buffer(self, dptr, count):
+        """Later launches write their packed pixels to this device address (None = own buffer)."""
+        _check(self._lib.rt_set_pixel_buffer(self._h, C.c_void_p(dptr or 0), count))
 
     def device_pixels(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -42,6 +42,7 @@ struct rt_ctx {
     uint32_t *d_seeds0 = nullptr;  // pristine default stream, for device-side resets
     float *d_colors = nullptr;
     uint32_t *d_pixels = nullptr;
+    uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
     unsigned long long *d_counters = nullptr;
     float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
     size_t tables_cap = 0;        // in float4
@@ -90,7 +91,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.cam = c->cam;
     p.seeds = c->d_seeds;
     p.colors = c->d_colors;
-    p.pixels = c->d_pixels;
+    p.pixels = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
     p.counters = c->d_counters;
     p.w = c->w;
     p.h = c->h;
@@ -322,7 +323,8 @@ int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (out_host && c->local_rows > 0)
-        HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels, (size_t)c->local_rows * c->w * sizeof(uint32_t),
+        HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels,
+                               (size_t)c->local_rows * c->w * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
@@ -331,9 +333,17 @@ int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     return RT_OK;
 }
 
+int rt_set_pixel_buffer(rt_ctx *c, void *dptr, size_t count) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (dptr && count < (size_t)c->local_rows * (size_t)c->w)
+        return fail(RT_ERR_ARG, "pixel buffer of %zu < %zu elements", count, (size_t)c->local_rows * (size_t)c->w);
+    c->d_pixels_ext = static_cast<uint32_t *>(dptr);
+    return RT_OK;
+}
+
 int rt_device_pixels(rt_ctx *c, void **dptr, size_t *count) {
     if (!c || !dptr || !count) return fail(RT_ERR_ARG, "null argument");
-    *dptr = c->d_pixels;
+    *dptr = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
     *count = (size_t)c->local_rows * (size_t)c->w;
     return RT_OK;
 }

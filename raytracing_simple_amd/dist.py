@@ -27,34 +27,70 @@ def scatter_index(h, w, nranks, tile_rows, device="cpu"):
 
 
 class FrameGatherer:
-    """Pre-allocated buffers for the per-frame gather.  `local` is this rank's padded buffer:
-    int32 [pad_rows, w]; rows beyond the rank's own count are padding."""
+    """Pre-allocated buffers for the per-frame gather.
 
-    def __init__(self, h, w, rank, nranks, tile_rows, device, group=None, dst=0):
+    `slots` send buffers (int32 [pad_rows, w], rows beyond the rank's own count are padding) let
+    the collective of frame k run while frame k+1 renders into the next slot: the renderer
+    writes straight into `local(k)` (rt_set_pixel_buffer), `gather(k, async_op=True)` queues the
+    collective behind that launch and returns at once, `wait(k)` is only needed before slot k
+    is rendered into again or its frame is read."""
+
+    def __init__(self, h, w, rank, nranks, tile_rows, device, group=None, dst=0, slots=1):
         self.h, self.w, self.rank, self.nranks, self.dst = h, w, rank, nranks, dst
         self.group = group
         self.src_idx, self.dst_idx, self.pad = scatter_index(h, w, nranks, tile_rows, device)
-        self.local = torch.zeros((self.pad, w), dtype=torch.int32, device=device)
         self.n_local = len(local_rows_of(h, rank, nranks, tile_rows))
-        self.parts = None
-        self.full = None
+        self.slots = slots
+        self._local = [torch.zeros((self.pad, w), dtype=torch.int32, device=device) for _ in range(slots)]
+        self._work = [None] * slots
+        self._parts = None
+        self._full = None
         if rank == dst:
-            self.parts = [torch.zeros((self.pad, w), dtype=torch.int32, device=device)
-                          for _ in range(nranks)]
-            self.full = torch.zeros((h, w), dtype=torch.int32, device=device)
+            self._parts = [[torch.zeros((self.pad, w), dtype=torch.int32, device=device)
+                            for _ in range(nranks)] for _ in range(slots)]
+            self._full = [torch.zeros((h, w), dtype=torch.int32, device=device) for _ in range(slots)]
 
-    def gather(self):
-        """The frame-end collective.  Returns the assembled [h, w] image on rank dst, else None."""
+    # single-slot conveniences (tests, simple callers)
+    @property
+    def local(self):
+        return self._local[0]
+
+    @property
+    def full(self):
+        return self._full[0] if self._full else None
+
+    def local_slot(self, k):
+        return self._local[k % self.slots]
+
+    def gather(self, k=0, async_op=False):
+        """The frame-end collective of slot k.  Returns the assembled [h, w] image on rank dst
+        (None elsewhere); with async_op=True returns None immediately -- call wait(k) later."""
+        k %= self.slots
         if self.nranks == 1:
-            self.full.copy_(self.local[: self.h])
-            return self.full
-        dist.gather(self.local, self.parts if self.rank == self.dst else None, dst=self.dst,
-                    group=self.group)
+            self._full[k].copy_(self._local[k][: self.h])
+            return self._full[k]
+        work = dist.gather(self._local[k], self._parts[k] if self.rank == self.dst else None, dst=self.dst,
+                           group=self.group, async_op=async_op)
+        if async_op:
+            self._work[k] = work
+            return None
+        return self._assemble(k)
+
+    def wait(self, k=0):
+        """Complete an async gather of slot k and assemble the frame (rank dst)."""
+        k %= self.slots
+        if self._work[k] is not None:
+            self._work[k].wait()
+            self._work[k] = None
+            return self._assemble(k)
+        return self._full[k] if self._full else None
+
+    def _assemble(self, k):
         if self.rank != self.dst:
             return None
-        stacked = torch.cat(self.parts, dim=0)
-        self.full.index_copy_(0, self.dst_idx, stacked.index_select(0, self.src_idx))
-        return self.full
+        stacked = torch.cat(self._parts[k], dim=0)
+        self._full[k].index_copy_(0, self.dst_idx, stacked.index_select(0, self.src_idx))
+        return self._full[k]
 
 
 def assemble_numpy(parts, h, w, nranks, tile_rows):

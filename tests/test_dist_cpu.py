@@ -35,10 +35,24 @@ def _worker(rank, world, port, h, w, tile_rows, q):
         g.local[: len(rows)] = torch.from_numpy(full[rows])
         out = g.gather()
         dist.barrier()
+        ok = True
         if rank == 0:
-            q.put(bool(np.array_equal(out.numpy(), full)))
+            ok = bool(np.array_equal(out.numpy(), full))
         else:
             assert out is None
+        # two slots, asynchronous: frame 1 is queued before frame 0 is waited for
+        g2 = rdist.FrameGatherer(h, w, rank, world, tile_rows, "cpu", slots=2)
+        for k in (0, 1):
+            g2.local_slot(k).zero_()
+            g2.local_slot(k)[: len(rows)] = torch.from_numpy(full[rows] + k)
+            assert g2.gather(k, async_op=True) is None
+        for k in (0, 1):
+            out = g2.wait(k)
+            if rank == 0:
+                ok = ok and bool(np.array_equal(out.numpy(), full + k))
+        dist.barrier()
+        if rank == 0:
+            q.put(ok)
     finally:
         dist.destroy_process_group()
 

@@ -148,6 +148,50 @@ def test_config_mirror_runs_reference_pass_loop():
         createConfig(8, 8, selectType(0))
 
 
+# ---- scheduling knobs never change a bit -------------------------------------------------------
+def test_regeneration_gate_and_cooperative_any_hit_are_bit_invisible():
+    lib = api.load_library()
+    sph, orig, target = scenes.random_spheres(96)
+    w, h, spp = 88, 56, 5
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    for gate in (1, 8, 33, 64):
+        for coop_min in (0, 16):
+            with api.RtContext(w, h) as ctx:
+                lib.rt_debug_set_regen_gate(ctx._h, gate)
+                lib.rt_debug_set_coop_min(ctx._h, coop_min)
+                ctx.set_scene(sph)
+                ctx.set_camera(cam)
+                px = ctx.render_pass(spp)
+                got = {"pixels": px, "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            _assert_same(got, want)
+    # the stage-scheduled (in-register queue) instance and the coop verification instance too
+    for mode in (102, 105):
+        got = _gpu(sph, cam, w, h, spp, mode=mode)
+        _assert_same(got, want)
+
+
+def test_render_into_caller_owned_device_buffer():
+    import torch
+    w, h, spp = 64, 40, 2
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    want = O.render(sph, cam, w, h, spp)["pixels"]
+    buf = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_pixel_buffer(buf.data_ptr(), buf.numel())
+        ctx.render_async(spp, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy().astype(np.uint32).reshape(-1), want)
+        with pytest.raises(api.RtError):
+            ctx.set_pixel_buffer(buf.data_ptr(), 10)          # too small
+        ctx.set_pixel_buffer(None, 0)
+        ctx.reset()
+        assert np.array_equal(ctx.render_pass(spp), want)
+
+
 # ---- sharding ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nranks,tile_rows", [(2, 8), (3, 8), (4, 16), (8, 8)])
 def test_row_tile_shards_reassemble_to_the_unsharded_image(nranks, tile_rows):
