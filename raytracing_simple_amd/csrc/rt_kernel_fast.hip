@@ -23,7 +23,6 @@
 #define RT_NS fast_coop
 #define RT_KERNEL_NAME rt_trace_fast_coop
 #define RT_OPT_COOP 1
-#define RT_OPT_UNROLL 4
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 

@@ -21,7 +21,6 @@
 #define RT_NS parity_coop
 #define RT_KERNEL_NAME rt_trace_parity_coop
 #define RT_OPT_COOP 1
-#define RT_OPT_UNROLL 4
 #define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
