@@ -52,6 +52,7 @@
 #define RT_OPT_COOP 0
 #endif
 
+
 #undef RT_STAMP
 #undef RT_STAMP_ROOTS
 #if RT_OPT_STAMPS
