@@ -425,9 +425,23 @@ int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w,
     return rc;
 }
 
+// exhaustive device-side check of the lean correctly-rounded sqrt: mismatches over all 2^32 inputs
+long long rt_debug_sqrt_mismatches(void) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
+    unsigned long long *d = nullptr, h = 0;
+    if (hipSetDevice(0) != hipSuccess || hipMalloc(&d, 8) != hipSuccess) return fail(RT_ERR_HIP, "alloc");
+    hipError_t e = hipMemset(d, 0, 8);
+    if (e == hipSuccess) e = rt::launch_sqrt_check(d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_sqrt_mismatches: %s", hipGetErrorString(e));
+    return (long long)h;
+}
+
 int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
     if ((!in_host || !out_host) && n) return fail(RT_ERR_ARG, "null argument");
-    if (op < 0 || op > 7) return fail(RT_ERR_ARG, "op %d", op);
+    if (op < 0 || op > 8) return fail(RT_ERR_ARG, "op %d", op);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
     if (n == 0) return RT_OK;

@@ -8,6 +8,7 @@
 
 #define RT_NS parity
 #define RT_KERNEL_NAME rt_trace_parity
+#define RT_OPT_LEAN_SQRT 1
 #define RT_OPT_MINWAVES 6            /* <= 80 VGPRs: 6 wavefronts per SIMD */
 #include "rt_trace.inc.h"
 #undef RT_OPT_MINWAVES
@@ -21,6 +22,7 @@
 #define RT_NS parity_coop
 #define RT_KERNEL_NAME rt_trace_parity_coop
 #define RT_OPT_COOP 1
+#define RT_OPT_LEAN_SQRT 1
 #define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
@@ -64,6 +66,11 @@ hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hip
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(parity::rt_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        stream, op, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(parity::rt_sqrt_check_kernel, dim3(256 * 16), dim3(256), 0, stream, d_mismatches);
     return hipGetLastError();
 }
 

@@ -9,3 +9,4 @@
 #undef RT_OPT_WAVE_TILE_W
 #undef RT_OPT_COOP
 #undef RT_OPT_MINWAVES
+#undef RT_OPT_LEAN_SQRT

@@ -51,6 +51,10 @@
 #ifndef RT_OPT_COOP
 #define RT_OPT_COOP 0
 #endif
+// RT_OPT_LEAN_SQRT: parity instances use ieee_sqrt_lean instead of the compiler's sqrtf expansion
+#ifndef RT_OPT_LEAN_SQRT
+#define RT_OPT_LEAN_SQRT 0
+#endif
 
 
 #undef RT_STAMP
@@ -97,9 +101,30 @@ RT_DEV V3 cross(V3 a, V3 b) {                                                   
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 
+// Correctly rounded square root without the compiler's generic wrapper.  The compiler expands
+// sqrtf into: scale tiny inputs by 2^32, v_sqrt_f32 (1 ulp), try the two neighbours with fused
+// residuals, unscale, patch zero/infinity -- 16 VALU.  The scaling and the patch are only needed
+// for nonzero inputs below 2^-96 in magnitude (the residuals stay normal otherwise; +-0, +inf, NaN and negative
+// inputs come out of the neighbour test unchanged, as worked through in DESIGN.md), so one wave
+// ballot routes the rare wavefront that holds such an input to the generic form and everybody
+// else runs 9 VALU + the check.  Equal to sqrtf for all 2^32 inputs (rt_debug_sqrt_mismatches).
+RT_DEV float ieee_sqrt_lean(float x) {
+    if (__builtin_amdgcn_ballot_w64(fabsf(x) < 0x1p-96f && x != 0.f) != 0ull) return sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_dn = __builtin_fmaf(-s_dn, s, x);
+    const float e_up = __builtin_fmaf(-s_up, s, x);
+    s = (e_dn <= 0.f) ? s_dn : s;
+    s = (e_up > 0.f) ? s_up : s;
+    return s;
+}
+
 RT_DEV float rt_sqrt(float x) {
 #if RT_FAST
     return __builtin_amdgcn_sqrtf(x);
+#elif RT_OPT_LEAN_SQRT
+    return ieee_sqrt_lean(x);
 #else
     return sqrtf(x);       // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
 #endif
@@ -122,7 +147,7 @@ RT_DEV V3 unit(V3 a) {                                                          
 #if RT_FAST
     return scale(a, __builtin_amdgcn_rsqf(dot(a, a)));
 #else
-    return scale(a, 1.f / sqrtf(dot(a, a)));
+    return scale(a, 1.f / rt_sqrt(dot(a, a)));
 #endif
 }
 
@@ -742,6 +767,19 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 }
 
 #if !RT_FAST && !defined(RT_VARIANT_KERNEL)
+// every binary32 bit pattern: ieee_sqrt_lean against the compiler's correctly rounded sqrtf
+extern "C" __global__ void rt_sqrt_check_kernel(unsigned long long *mismatches) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const uint32_t a = __float_as_uint(ieee_sqrt_lean(x)), r = __float_as_uint(sqrtf(x));
+        const bool both_nan = ((a & 0x7fffffffu) > 0x7f800000u) && ((r & 0x7fffffffu) > 0x7f800000u);
+        if (a != r && !both_nan) bad += 1;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // scalar building blocks, for rt_debug_eval
 extern "C" __global__ void rt_eval_kernel(int op, const float *in, float *out, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,6 +794,7 @@ extern "C" __global__ void rt_eval_kernel(int op, const float *in, float *out, s
         case 5: r = (float)to_int(v); break;
         case 6: dm_sincosf_pos(v, r, t); break;
         case 7: dm_sincosf_pos(v, t, r); break;
+        case 8: r = ieee_sqrt_lean(v); break;
         default: break;
     }
     out[i] = r;

@@ -255,6 +255,18 @@ def test_device_scalar_ops_bit_exact():
     assert np.array_equal(api.debug_eval(5, c), want_i)
 
 
+def test_lean_sqrt_equals_compiler_sqrt_for_every_float():
+    """ieee_sqrt_lean (used by the parity kernels) against the compiler's correctly rounded sqrtf
+    over all 2^32 bit patterns, on the device."""
+    import ctypes as C
+    lib = api.load_library()
+    lib.rt_debug_sqrt_mismatches.restype = C.c_longlong
+    assert lib.rt_debug_sqrt_mismatches() == 0
+    v = np.float32([0.0, -0.0, 1e-45, 1e-30, 2.0 ** -96, 0.25, 2.0, 3e38, np.inf])
+    with np.errstate(all="ignore"):
+        assert np.array_equal(api.debug_eval(8, v).view(np.uint32), np.sqrt(v).view(np.uint32))
+
+
 # ---- fast mode -----------------------------------------------------------------------------------
 def test_fast_mode_psnr_gate():
     w = h = 256
