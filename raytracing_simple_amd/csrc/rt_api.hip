@@ -44,6 +44,7 @@ struct rt_ctx {
     uint32_t *d_pixels = nullptr;
     uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
     unsigned long long *d_counters = nullptr;
+    unsigned long long *d_stats = nullptr;      // rt::kStatReplicas x 8 partial work counters
     float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
     size_t tables_cap = 0;        // in float4
     rt::SceneTables scene{};
@@ -52,7 +53,10 @@ struct rt_ctx {
     int mode = RT_MODE_PARITY;
     int regen_gate = 0;           // 0 = choose from the scene size
     int mat_lds_limit = 24 * 1024;
-    int coop_min = 64;            // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
+    int coop_min = 64;
+    int persist = 0;              // persistent-wavefront instances (tile queue + per-lane pixel hand-out)
+    int n_cus = 256;
+            // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
     int current_sample = 0;
     uint64_t launches = 0;
     double last_ms = 0.0;
@@ -77,6 +81,7 @@ int upload_default_seeds(rt_ctx *c) {
     HIP_TRY(hipMemset(c->d_colors, 0, 3 * (size_t)c->w * (size_t)c->h * sizeof(float)));
     HIP_TRY(hipMemset(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t)));
     HIP_TRY(hipMemset(c->d_counters, 0, 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long)));
     return RT_OK;
 }
 
@@ -93,6 +98,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.colors = c->d_colors;
     p.pixels = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
     p.counters = c->d_counters;
+    p.stats = c->d_stats;
     p.w = c->w;
     p.h = c->h;
     p.first_sample = c->current_sample;
@@ -112,7 +118,25 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
               (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
     hipError_t e;
     const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
-    if (c->mode == RT_MODE_FAST) e = rt::launch_fast(coop ? rt::kFastCoopVariant : 0, p, grid, lds, stream);
+    const bool persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
+    p.tiles_x = (c->w + 7) / 8;
+    p.n_tiles = p.tiles_x * ((c->local_rows + 7) / 8);
+    if (persist) {
+        // just enough workgroups to fill the machine; the tile queue (counters[30]) does the rest
+        size_t per_cu = lds > 0 ? (160 * 1024) / (lds + 6 * 1024) : 6;
+        if (per_cu > 6) per_cu = 6;
+        if (per_cu < 1) per_cu = 1;
+        size_t blocks = (size_t)c->n_cus * per_cu;
+        const size_t needed = ((size_t)p.n_tiles + 3) / 4;
+        if (blocks > needed) blocks = needed;
+        grid = dim3((unsigned)blocks, 1, 1);
+        HIP_TRY(hipMemsetAsync(c->d_counters + 30, 0, sizeof(unsigned long long), stream));
+    }
+    if (persist && c->mode == RT_MODE_FAST)
+        e = rt::launch_fast(coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant, p, grid, lds, stream);
+    else if (persist)
+        e = rt::launch_parity(coop ? rt::kParityPersistCoopVariant : rt::kParityPersistVariant, p, grid, lds, stream);
+    else if (c->mode == RT_MODE_FAST) e = rt::launch_fast(coop ? rt::kFastCoopVariant : 0, p, grid, lds, stream);
     else if (c->mode >= 200) e = rt::launch_fast(c->mode - 200, p, grid, lds, stream);
     else if (c->mode >= 100) e = rt::launch_parity(c->mode - 100, p, grid, lds, stream);
     else e = rt::launch_parity(coop ? rt::kParityCoopVariant : 0, p, grid, lds, stream);
@@ -149,6 +173,7 @@ int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nran
     if (device < 0 || device >= n_dev) return fail(RT_ERR_ARG, "device %d of %d", device, n_dev);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device,
                     prop.gcnArchName);
@@ -156,6 +181,7 @@ int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nran
     rt_ctx *c = new (std::nothrow) rt_ctx();
     if (!c) return fail(RT_ERR_ALLOC, "host allocation failed");
     c->device = device;
+    c->n_cus = n_cus;
     c->w = w;
     c->h = h;
     c->rank = rank;
@@ -180,6 +206,7 @@ int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nran
         HIP_TRY(hipMalloc(&c->d_colors, 3 * px * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 1) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&c->d_stats, rt::kStatReplicas * 8 * sizeof(unsigned long long)));
         HIP_TRY(rt::prepare_parity());
         HIP_TRY(rt::prepare_fast());
         return upload_default_seeds(c);
@@ -204,6 +231,7 @@ void rt_destroy(rt_ctx *c) {
         (void)hipFree(c->d_colors);
         (void)hipFree(c->d_pixels);
         (void)hipFree(c->d_counters);
+        (void)hipFree(c->d_stats);
         (void)hipFree(c->d_tables);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -303,6 +331,7 @@ int rt_reset_async(rt_ctx *c, void *hip_stream) {
     HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
                            hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), st));
     c->current_sample = 0;
     return RT_OK;
 }
@@ -376,11 +405,15 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     unsigned long long v[32];
     HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
     HIP_TRY(hipMemcpy(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost));
-    out->samples = v[0];
-    out->closest_rays = v[1];
-    out->shadow_rays = v[2];
-    out->sphere_tests = v[3];
-    out->rng_draws = v[4];
+    unsigned long long part[rt::kStatReplicas * 8], sum[5] = { 0, 0, 0, 0, 0 };
+    HIP_TRY(hipMemcpy(part, c->d_stats, sizeof part, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rt::kStatReplicas; ++r)
+        for (int k = 0; k < 5; ++k) sum[k] += part[r * 8 + k];
+    out->samples = sum[0];
+    out->closest_rays = sum[1];
+    out->shadow_rays = sum[2];
+    out->sphere_tests = sum[3];
+    out->rng_draws = sum[4];
     memcpy(c->debug_counters, v + 8, sizeof c->debug_counters);
     out->launches = c->launches;
     out->last_kernel_ms = c->last_ms;
@@ -397,6 +430,18 @@ int rt_debug_set_regen_gate(rt_ctx *c, int gate) {
 int rt_debug_set_mat_lds_limit(rt_ctx *c, int bytes) {
     if (!c || bytes < 0) return fail(RT_ERR_ARG, "bytes %d", bytes);
     c->mat_lds_limit = bytes;
+    return RT_OK;
+}
+
+int rt_debug_set_persist(rt_ctx *c, int on) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    c->persist = on ? 1 : 0;
+    return RT_OK;
+}
+
+int rt_debug_set_ncus(rt_ctx *c, int n) {      // shrink the persistent grid (tests of the tile queue)
+    if (!c || n < 1) return fail(RT_ERR_ARG, "n %d", n);
+    c->n_cus = n;
     return RT_OK;
 }
 

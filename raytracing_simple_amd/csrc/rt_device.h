@@ -13,6 +13,7 @@ constexpr int kBlockThreads = 256;  // 4 wavefronts
 constexpr int kTileW = 32;          // block tile: 32 x 8 pixels, one 8x8 sub-tile per wavefront
 constexpr int kTileH = 8;
 constexpr int kMaxDepth = 8;        // .cl:320 (depth > 7 ends the path)
+constexpr int kStatReplicas = 64;    // work counters are summed into 64 separate 64-byte lines
 constexpr int kMaxK2Table = 1024;   // running-average reciprocals kept in LDS up to this many passes per launch
 
 // Sphere tables in HBM, written once by rt_set_scene and staged into LDS by every workgroup.
@@ -39,11 +40,13 @@ struct LaunchParams {
     uint32_t *seeds;        // [2*w*h], pair per pixel at gid = y*w + x        (.cl:570-571)
     float *colors;          // [3*w*h], running average at (h-1-y)*w + x       (.cl:579)
     uint32_t *pixels;       // [local_rows*w], packed RGBX of this rank's rows (.cl:594)
-    unsigned long long *counters;  // 5 x u64: samples, closest, shadow, tests, draws
+    unsigned long long *stats;     // [kStatReplicas][8] u64: samples, closest, shadow, tests, draws (per-replica partial sums)
+    unsigned long long *counters;  // 32 u64: diagnostics [8..29], tile queue head [30]
     int w, h;
     int first_sample, n_samples;
     int rank, nranks, tile_rows, local_rows;
     int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
+    int n_tiles, tiles_x;   // persistent instances: 8x8 pixel tiles of this rank's rows, and tiles per row
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
 };
 
@@ -60,6 +63,8 @@ hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t l
 hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
 constexpr int kParityCoopVariant = 4;   // index of the cooperative-shadow instance in each table
 constexpr int kFastCoopVariant = 3;
+constexpr int kParityPersistVariant = 6, kParityPersistCoopVariant = 7;
+constexpr int kFastPersistVariant = 4, kFastPersistCoopVariant = 5;
 int parity_variant_count();
 int fast_variant_count();
 hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream);

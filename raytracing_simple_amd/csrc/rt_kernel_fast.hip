@@ -26,11 +26,25 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_persist
+#define RT_KERNEL_NAME rt_trace_fast_persist
+#define RT_OPT_PERSIST 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fast_persist_coop
+#define RT_KERNEL_NAME rt_trace_fast_persist_coop
+#define RT_OPT_PERSIST 1
+#define RT_OPT_COOP 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
 static KernelFn const kFastKernels[] = { fast::rt_trace_fast, fast_a1::rt_trace_fast_a1, fast::rt_sched_fast,
-                                           fast_coop::rt_trace_fast_coop };
+                                           fast_coop::rt_trace_fast_coop, fast_persist::rt_trace_fast_persist,
+                                           fast_persist_coop::rt_trace_fast_persist_coop };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 
 int fast_variant_count() { return kFastCount; }

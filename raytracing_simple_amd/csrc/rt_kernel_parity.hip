@@ -41,6 +41,23 @@
 #include "rt_sched.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_persist
+#define RT_KERNEL_NAME rt_trace_parity_persist
+#define RT_OPT_PERSIST 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_persist_coop
+#define RT_KERNEL_NAME rt_trace_parity_persist_coop
+#define RT_OPT_PERSIST 1
+#define RT_OPT_COOP 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
@@ -51,6 +68,8 @@ static KernelFn const kParityKernels[] = {
     parity_a5::rt_sched_parity_a5,      // 3  its census
     parity_coop::rt_trace_parity_coop,  // 4  = kParityCoopVariant
     parity_coopv::rt_trace_parity_coopv,  // 5
+    parity_persist::rt_trace_parity_persist,            // 6 = kParityPersistVariant
+    parity_persist_coop::rt_trace_parity_persist_coop,  // 7 = kParityPersistCoopVariant
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 

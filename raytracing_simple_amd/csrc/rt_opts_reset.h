@@ -10,3 +10,4 @@
 #undef RT_OPT_COOP
 #undef RT_OPT_MINWAVES
 #undef RT_OPT_LEAN_SQRT
+#undef RT_OPT_PERSIST

@@ -51,6 +51,13 @@
 #ifndef RT_OPT_COOP
 #define RT_OPT_COOP 0
 #endif
+// RT_OPT_PERSIST: persistent wavefronts.  The grid only fills the machine; each wavefront pulls
+// 8x8 pixel tiles from a global queue and hands their pixels to its lanes one by one as lanes
+// finish (wave ballot + prefix count), so no lane idles at the end of its pixel while the others
+// of the wavefront still work, and no CU idles while others still hold unstarted tiles.
+#ifndef RT_OPT_PERSIST
+#define RT_OPT_PERSIST 0
+#endif
 // RT_OPT_LEAN_SQRT: parity instances use ieee_sqrt_lean instead of the compiler's sqrtf expansion
 #ifndef RT_OPT_LEAN_SQRT
 #define RT_OPT_LEAN_SQRT 0
@@ -421,6 +428,8 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     const bool k2_in_lds = P.n_samples <= kMaxK2Table;
 
     const int tid = threadIdx.x;
+    __shared__ unsigned long long s_stat[5];
+    if (tid < 5) s_stat[tid] = 0;
     for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
         s_lightA[i] = P.scene.lightA[i];
@@ -441,6 +450,21 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 
     // ---- pixel of this lane ---------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
+    (void)wave;
+#if RT_OPT_PERSIST
+    // pixels are handed out inside the loop; nothing is owned yet
+    int x = 0, lrow = 0, y = 0;
+    bool has_pixel = false;
+    size_t gid = 0, ci = 0;
+    uint32_t s0 = 0, s1 = 0;
+    V3 acc = mk(0.f, 0.f, 0.f);
+    const int s_end = P.first_sample + P.n_samples;
+    int s = s_end;
+    uint32_t cur_tile = 0, cur_used = 64;      // wave-uniform: current 8x8 tile, pixels handed out of it
+    uint32_t c_samples = 0;
+    uint32_t dbg_trip = 0;
+    (void)dbg_trip;
+#else
 #if RT_OPT_WAVE_TILE_W == 8
     const int x = blockIdx.x * kTileW + wave * 8 + (lane & 7);              // 4 x 1 waves of 8x8
     const int lrow = blockIdx.y * kTileH + (lane >> 3);
@@ -467,6 +491,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         s1 = P.seeds[2 * gid + 1];
         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
     }
+#endif
 
     const float inv_w = rt_rcp((float)P.w);                                  // .cl:503-504
     const float inv_h = rt_rcp((float)P.h);
@@ -497,21 +522,105 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 #endif
     for (;;) {
         RT_STAMP(8);
+        // The wave-level decisions below (ballots) are only meaningful if ALL lanes that are
+        // still in the loop execute them together.  A `continue` for the waiting lanes gives the
+        // loop a second back edge, and the compiler is then free to spin the waiting lanes
+        // through the header on their own (observed: lanes at different trip counts, ballots
+        // that see a subset).  So waiting lanes skip the body through one `if` instead.
+        bool idle = false;
         // Gated regeneration: lanes whose path has ended wait until P.regen_gate of them can
         // start together (or nothing else is in flight).  Free-running lanes (gate 1) drift
         // apart in phase, so that every section of the loop runs in almost every trip for a
         // fraction of the lanes; a small gate keeps the lanes of a coherent tile in the same
         // phase of the bounce loop at the price of a few idle lane-trips.  Ordering within a
         // pixel is untouched.
+#if RT_OPT_PERSIST
+        {
+            // lanes between paths; those without samples left also want a new pixel
+            const unsigned long long bw = __builtin_amdgcn_ballot_w64(need_ray);
+            const unsigned long long ba = __builtin_amdgcn_ballot_w64(!need_ray);
+            const bool go = (__popcll(bw) >= P.regen_gate) || (ba == 0ull);
+            const bool take = need_ray && go && s >= s_end;
+            const unsigned long long F = __builtin_amdgcn_ballot_w64(take);
+#if RT_OPT_PERSIST == 2
+            dbg_trip += 1;
+            if (__builtin_amdgcn_ballot_w64(dbg_trip != (uint32_t)__builtin_amdgcn_readfirstlane((int)dbg_trip)) != 0ull)
+                atomicAdd(&P.counters[26], 1ull);        // lanes at different trip counts at the loop top
+            if (__builtin_amdgcn_ballot_w64(cur_used != (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_used)) != 0ull)
+                atomicAdd(&P.counters[27], 1ull);        // lanes disagree on the hand-out cursor
+#endif
+            if (F != 0ull) {
+                if (take && has_pixel) {                                   // .cl:580-599 of the finished pixel
+                    P.colors[3 * ci] = acc.x;
+                    P.colors[3 * ci + 1] = acc.y;
+                    P.colors[3 * ci + 2] = acc.z;
+                    P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =
+                        (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+                    P.seeds[2 * gid] = s0;
+                    P.seeds[2 * gid + 1] = s1;
+                    c_samples += (uint32_t)P.n_samples;
+                    has_pixel = false;
+#if RT_OPT_PERSIST == 2
+                    atomicAdd(&P.counters[29], 1ull);   // debug: pixels finalized
+#endif
+                }
+                // hand out the next popcount(F) pixels of the wavefront's tile stream
+                const uint32_t n_take = (uint32_t)__popcll(F);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(F >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)F, 0u));
+                uint32_t next_tile = cur_tile;
+                if (cur_used + n_take > 64u) {                             // wave-uniform: pull a tile
+                    const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+                    const int leader = __ffsll((long long)here) - 1;
+                    uint32_t got = 0;
+                    if (lane == leader) got = (uint32_t)atomicAdd(&P.counters[30], 1ull);
+                    next_tile = (uint32_t)__shfl((int)got, leader, 64);
+                }
+                const uint32_t slot = cur_used + rank;
+                const uint32_t my_tile = slot < 64u ? cur_tile : next_tile;
+                const uint32_t my_idx = slot & 63u;
+                if (cur_used + n_take > 64u) {
+                    cur_used = cur_used + n_take - 64u;
+                    cur_tile = next_tile;
+                } else {
+                    cur_used += n_take;
+                }
+                if (take) {
+                    if (my_tile >= (uint32_t)P.n_tiles) break;            // queue drained: this lane retires
+                    const int tx = (int)(my_tile % (uint32_t)P.tiles_x), ty = (int)(my_tile / (uint32_t)P.tiles_x);
+                    x = tx * 8 + (int)(my_idx & 7u);
+                    lrow = ty * 8 + (int)(my_idx >> 3);
+                    const int rtile = lrow / P.tile_rows;
+                    y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
+                    if ((x < P.w) && (lrow < P.local_rows) && (y < P.h)) {
+                        gid = (size_t)y * (size_t)P.w + (size_t)x;         // .cl:560-563
+                        ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;   // .cl:579
+                        s0 = P.seeds[2 * gid];
+                        s1 = P.seeds[2 * gid + 1];
+                        acc = mk(0.f, 0.f, 0.f);
+                        if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
+                        s = P.first_sample;
+                        has_pixel = true;
+#if RT_OPT_PERSIST == 2
+                        atomicAdd(&P.counters[28], 1ull);   // debug: pixels handed out
+#endif
+                    }
+                }
+            }
+            idle = need_ray && (!go || s >= s_end);                        // gated, or drew a pixel outside the image
+        }
+        if (!idle) {   // (no `continue`: every lane must meet again at the loop top, see below)
+        if (need_ray) {
+#else
         if (need_ray && s >= s_end) break;
         if (P.regen_gate > 1) {
             const unsigned long long bw = __builtin_amdgcn_ballot_w64(need_ray);
             const unsigned long long ba = __builtin_amdgcn_ballot_w64(!need_ray);
             const bool go = (__popcll(bw) >= P.regen_gate) || (ba == 0ull);
-            if (need_ray && !go) continue;
+            idle = need_ray && !go;
         }
+        if (!idle) {   // (no `continue`: every lane must meet again at the loop top, see below)
         if (need_ray) {
-            if (s >= s_end) break;
+#endif
             RT_STAMP(0);
             // ---- camera ray, .cl:494-549 ----
             float j1 = next_random(s0, s1) - 0.5f;
@@ -732,8 +841,10 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
             s += 1;
             need_ray = true;
         }
+        }   // if (!idle)
     }
 
+#if !RT_OPT_PERSIST
     if (valid && P.n_samples > 0) {
         P.colors[3 * ci] = acc.x;
         P.colors[3 * ci + 1] = acc.y;
@@ -744,8 +855,13 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         P.seeds[2 * gid + 1] = s1;
     }
 
+#endif
     // ---- exact work counters: one atomic per counter per wavefront ----
+#if RT_OPT_PERSIST
+    uint32_t n_done = c_samples;
+#else
     uint32_t n_done = valid ? (uint32_t)P.n_samples : 0u;
+#endif
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);
@@ -753,12 +869,20 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     unsigned long long tests64 = c_tests;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
+    // one LDS add per wavefront, then one global add per workgroup into one of kStatReplicas
+    // separate lines (162 000 same-address global atomics cost 1.8 ms per launch: one word takes
+    // about 88 atomics per microsecond)
     if (lane == 0) {
-        atomicAdd(&P.counters[0], (unsigned long long)t_samples);
-        atomicAdd(&P.counters[1], (unsigned long long)t_closest);
-        atomicAdd(&P.counters[2], (unsigned long long)t_shadow);
-        atomicAdd(&P.counters[3], tests64);
-        atomicAdd(&P.counters[4], (unsigned long long)t_draws);
+        atomicAdd(&s_stat[0], (unsigned long long)t_samples);
+        atomicAdd(&s_stat[1], (unsigned long long)t_closest);
+        atomicAdd(&s_stat[2], (unsigned long long)t_shadow);
+        atomicAdd(&s_stat[3], tests64);
+        atomicAdd(&s_stat[4], (unsigned long long)t_draws);
+    }
+    __syncthreads();
+    if (tid < 5) {
+        const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
+        atomicAdd(&P.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
     }
 #if RT_OPT_STAMPS
     __syncthreads();

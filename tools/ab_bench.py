@@ -35,12 +35,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--coop-min", type=int, default=-1, help="override the cooperative any-hit threshold (0 = off)")
+    ap.add_argument("--persist", default="", help="comma list of 0/1: sweep persistent-wavefront instances")
     ap.add_argument("--mat-lds", type=int, default=-1, help="override the LDS byte limit for staging materials")
     ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
     args = ap.parse_args()
     modes = [int(m) for m in args.modes.split(",")]
     gates = [int(g) for g in args.gates.split(",")] if args.gates else [None]
-    variants = [(m, g) for m in modes for g in gates]
+    persists = [int(g) for g in args.persist.split(",")] if args.persist else [None]
+    variants = [(m, g, q) for m in modes for g in gates for q in persists]
     for cname in args.configs.split(","):
         maker, w, h, spp = CONFIGS[cname]
         if args.spp:
@@ -59,9 +61,11 @@ def main():
                 lib.rt_debug_set_coop_min(ctx._h, args.coop_min)
             for r in range(args.rounds + 1):
                 for v in variants:
-                    m, g = v
+                    m, g, q = v
                     ctx.set_mode(m)
                     lib.rt_debug_set_regen_gate(ctx._h, 0 if g is None else g)
+                    if q is not None:
+                        lib.rt_debug_set_persist(ctx._h, q)
                     ctx.reset()
                     px = ctx.render_pass(spp)
                     st = ctx.stats()
@@ -71,12 +75,12 @@ def main():
                         times[v].append(st["last_kernel_ms"])
             base = pix[variants[0]]
             for v in variants:
-                m, g = v
+                m, g, q = v
                 st = stats[v]
                 rays = st["samples"] + st["shadow_rays"]
                 med, mn = statistics.median(times[v]), min(times[v])
                 same = bool(np.array_equal(pix[v], base))
-                print(json.dumps({"config": cname, "mode": m, "gate": g, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                print(json.dumps({"config": cname, "mode": m, "gate": g, "persist": q, "ms_median": round(med, 4), "ms_min": round(mn, 4),
                                   "Gray_s": round(rays / med / 1e6, 2), "same_as_first": same,
                                   "psnr_vs_first": None if same else round(host.psnr(pix[v], base), 2),
                                   "tests_per_sample": round(st["sphere_tests"] / st["samples"], 2),
