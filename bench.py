@@ -140,6 +140,32 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
+
+    # the other arithmetic mode on the same workload, outside the headline's timed region
+    # (N = 1 only; reported beside `value`, never instead of it)
+    other = None
+    if world == 1:
+        other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
+        last_pixels = ctx.render_pass(0, copy=True)           # frame of the last timed step
+        ctx.set_mode(other_mode)
+        n_other = 8
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n_other):
+            step()
+        sync()
+        dt = (time.perf_counter() - t1) / n_other
+        st_o = ctx.stats()
+        px_o = ctx.render_pass(0, copy=True)
+        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity",
+                 "ms_per_step": round(dt * 1e3, 4),
+                 "value": round((st_o["samples"] + st_o["shadow_rays"]) / dt / 1e6, 1), "unit": "Mray/s",
+                 "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2)}
+        ctx.set_mode(mode)
+        step()                                                # counters and frame of the headline mode again
+        sync()
     frame_ok = None
     if world > 1 and rank == 0:
         # the gathered frame of the last step against an unsharded render on this GPU
@@ -215,6 +241,8 @@ def main():
                         "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
             },
         }
+        if other is not None:
+            line["other_mode"] = other
         if world == 1 and not args.no_cpu:
             base, cpu_out = cpu_baseline(spheres, cam)
             line["cpu_baseline"] = base
