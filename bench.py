@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: room for the frames in flight
 
 W, H, SPP = 1920, 1080, 64
 TILE_ROWS = 8
@@ -54,6 +55,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="independent frames kept in flight per rank (0 = 2 for N<=2, 3 for N<=4, 4 beyond)")
     args = ap.parse_args()
 
     import torch                       # plumbing: streams, events, torch.distributed (RCCL)
@@ -86,38 +89,57 @@ def main():
     cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, W, H)
     mode = api.RT_MODE_FAST if args.mode == "fast" else api.RT_MODE_PARITY
 
-    ctx = api.RtContext(W, H, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
-    ctx.set_scene(spheres)
-    ctx.set_camera(cam)
-    ctx.set_mode(mode)
+    # Frames in flight.  A step is one frame; the K timed frames are independent (each restarts
+    # from the default seed stream), so several can be in flight on separate streams, each with
+    # its own seed/colour state -- what a renderer serving several views does.  One wavefront
+    # needs about a millisecond for its 64 pixels x 64 spp: a single frame leaves the machine
+    # partly idle while its last wavefronts finish (about 15 % at N = 1), and a 1/8 shard (4050
+    # wavefronts for 6144 wavefront slots) cannot fill a GPU at all.  F frames in flight fill
+    # those holes.  The single-stream figure is measured too (N = 1) and is the one the roofline
+    # and the rocprof summaries refer to.
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world <= 2 else (3 if world <= 4 else 4))
+    ctxs = []
+    for _ in range(F):
+        c = api.RtContext(W, H, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
+        c.set_scene(spheres)
+        c.set_camera(cam)
+        c.set_mode(mode)
+        ctxs.append(c)
+    ctx = ctxs[0]
 
-    stream = torch.cuda.current_stream()
-    sh = stream.cuda_stream
+    main_stream = torch.cuda.current_stream()
+    # each context's own HIP stream, wrapped for torch: they are created back to back and land on
+    # distinct hardware queues, which streams from torch's pool did not always do (two pool streams
+    # on one queue = no overlap at all; measured)
+    side_streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
     gather = None
-    SLOTS = 2          # frame k's gather overlaps frame k+1's render
     if world > 1:
-        gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=SLOTS)
+        gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=2 * F)
     frame_no = [0]
 
-    def step(ev=None):
+    def step(in_flight, ev=None):
         k = frame_no[0]
         frame_no[0] += 1
-        if gather is not None:
-            gather.wait(k)                                  # slot free again (its gather of frame k-2)
-            buf = gather.local_slot(k)
-            ctx.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
-        ctx.reset_async(sh)
-        if ev:
-            ev[0].record(stream)
-        ctx.render_async(SPP, sh)
-        if ev:
-            ev[1].record(stream)
-        if gather is not None:
-            gather.gather(k, async_op=True)                 # queued behind the launch, not waited for
+        c = ctxs[k % in_flight]
+        st = main_stream if in_flight == 1 else side_streams[k % in_flight]
+        with torch.cuda.stream(st):
+            if gather is not None:
+                gather.wait(k)                                  # slot free again (its last gather)
+                buf = gather.local_slot(k)
+                c.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
+            c.reset_async(st.cuda_stream)
+            if ev:
+                ev[0].record(st)
+            c.render_async(SPP, st.cuda_stream)
+            if ev:
+                ev[1].record(st)
+            if gather is not None:
+                gather.gather(k, async_op=True)                 # queued behind the launch, not waited for
+        return c
 
     def drain():
         if gather is not None:
-            for k in range(SLOTS):
+            for k in range(2 * F):
                 gather.wait(k)
 
     def sync():
@@ -126,46 +148,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(args.steps)]
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    drain()                                                 # every frame gathered and assembled
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed_region(in_flight, steps, warmup, with_events=True):
+        """W untimed + exactly `steps` timed frames; barrier + synchronize on both sides.
+        Per-launch HIP events only where asked: an event pair around every launch costs the
+        overlapped region its overlap (measured), and a per-launch duration means little there."""
+        for _ in range(warmup):
+            step(in_flight)
+        drain()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(steps)] if with_events else None
+        sync()
+        t0 = time.perf_counter()
+        last = None
+        for k in range(steps):
+            last = step(in_flight, events[k] if events else None)
+        drain()                                             # every frame gathered and assembled
+        sync()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = (sum(a.elapsed_time(b) for a, b in events) / max(steps, 1)) if events else elapsed / max(steps, 1) * 1e3
+        return elapsed, kernel_ms, last
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
-
-    # the other arithmetic mode on the same workload, outside the headline's timed region
-    # (N = 1 only; reported beside `value`, never instead of it)
-    other = None
+    single = None
     if world == 1:
-        other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
-        last_pixels = ctx.render_pass(0, copy=True)           # frame of the last timed step
-        ctx.set_mode(other_mode)
-        n_other = 8
-        for _ in range(2):
-            step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(n_other):
-            step()
-        sync()
-        dt = (time.perf_counter() - t1) / n_other
-        st_o = ctx.stats()
-        px_o = ctx.render_pass(0, copy=True)
-        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity",
-                 "ms_per_step": round(dt * 1e3, 4),
-                 "value": round((st_o["samples"] + st_o["shadow_rays"]) / dt / 1e6, 1), "unit": "Mray/s",
-                 "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2)}
-        ctx.set_mode(mode)
-        step()                                                # counters and frame of the headline mode again
-        sync()
+        el1, k1, last1 = timed_region(1, args.steps, args.warmup)
+        single = {"elapsed": el1, "kernel_ms": k1, "ctx": last1}
+    if F == 1 and single is not None:
+        elapsed, kernel_ms, last_ctx = single["elapsed"], single["kernel_ms"], single["ctx"]
+    else:
+        elapsed, kernel_ms, last_ctx = timed_region(F, args.steps, args.warmup, with_events=(world > 1 and F == 1))
+
     frame_ok = None
     if world > 1 and rank == 0:
         # the gathered frame of the last step against an unsharded render on this GPU
@@ -176,7 +187,25 @@ def main():
             want = whole.render_pass(SPP)
         got = gather.wait(frame_no[0] - 1).cpu().numpy().astype("uint32").reshape(-1)
         frame_ok = bool((got == want).all())
-    st = ctx.stats()                      # counters of the last frame (reset clears them)
+
+    st = last_ctx.stats()                 # counters of the last frame (reset clears them)
+    last_pixels = last_ctx.render_pass(0, copy=True) if world == 1 else None
+
+    # the other arithmetic mode on the same workload, single stream, outside the headline's
+    # timed region (N = 1 only; reported beside `value`, never instead of it)
+    other = None
+    if world == 1:
+        other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
+        ctx.set_mode(other_mode)
+        el_o, _, _ = timed_region(1, 8, 2)
+        st_o = ctx.stats()
+        px_o = ctx.render_pass(0, copy=True)
+        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "frames_in_flight": 1,
+                 "ms_per_step": round(el_o / 8 * 1e3, 4),
+                 "value": round((st_o["samples"] + st_o["shadow_rays"]) * 8 / el_o / 1e6, 1), "unit": "Mray/s",
+                 "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2)}
+        ctx.set_mode(mode)
+
     counts = torch.tensor([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],
                           dtype=torch.int64, device=dev)
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -193,10 +222,12 @@ def main():
         rays = samples + shadow                      # primary + shadow, the metric's ray count
         ms_per_step = elapsed / args.steps * 1e3
         value = rays * args.steps / elapsed / 1e6
-        # roofline of the dominant (only) kernel, per launch, from this rank's launches
+        # roofline of the dominant (only) kernel, per launch, from this rank's launches; at N = 1
+        # from the single-stream region, where launches do not overlap (what rocprof sees too)
+        roof_kernel_ms = single["kernel_ms"] if single is not None else kernel_ms
         my_tests = st["sphere_tests"]
         flops = FLOP_PER_SPHERE_TEST * my_tests
-        achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
+        achieved_tflops = flops / (roof_kernel_ms * 1e-3) / 1e12
         my_pixels = ctx.local_rows * W
         alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 16 * len(spheres) * 3 + 60
         traffic = None
@@ -221,6 +252,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2: Demo scene (6 spheres), {W}x{H}, {SPP} spp, default seed stream",
                        "mode": args.mode, "collective": None if world == 1 else f"gather to rank 0 ({backend})",
+                       "frames_in_flight": F,
                        "gathered_frame_equals_unsharded": frame_ok, "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
                        "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
                        "Mray_s_all_rays": round((closest + shadow) * args.steps / elapsed / 1e6, 1),
@@ -233,14 +265,18 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, 5),
                 "traffic": traffic,
-                "kernel_ms": round(kernel_ms, 4),
+                "launches_overlap": single is None,
+                "kernel_ms": round(roof_kernel_ms, 4),
                 "kernel_ms_max_rank": round(kernel_ms_max, 4),
                 "algorithmic_flops_per_launch": flops,
                 "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
-                        "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+                        "achieved": round(alg_bytes / (roof_kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(alg_bytes / (roof_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
             },
         }
+        if single is not None and F > 1:
+            line["single_stream"] = {"frames_in_flight": 1, "ms_per_step": round(single["elapsed"] / args.steps * 1e3, 4),
+                                     "value": round(rays * args.steps / single["elapsed"] / 1e6, 1), "unit": "Mray/s"}
         if other is not None:
             line["other_mode"] = other
         if world == 1 and not args.no_cpu:
@@ -248,14 +284,14 @@ def main():
             line["cpu_baseline"] = base
             if args.mode == "parity":
                 import numpy as np
-                px = ctx.render_pass(0, copy=True)           # frame of the last timed step
-                line["config"]["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(px, cpu_out["pixels"]))
+                line["config"]["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(last_pixels, cpu_out["pixels"]))
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -122,6 +122,10 @@ int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
  * and no synchronisation: the caller orders later work on that stream.                       */
 int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);
 
+/* The context's own non-blocking stream (a hipStream_t), the one rt_render_pass uses.  With
+ * several contexts in flight, rt_render_async(ctx, n, rt_stream(ctx)) runs each on its own.      */
+void *rt_stream(rt_ctx *ctx);
+
 /* Device address and element count (uint32) of the local pixel buffer.                       */
 int rt_device_pixels(rt_ctx *ctx, void **dptr, size_t *count);
 

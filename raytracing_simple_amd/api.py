@@ -16,7 +16,7 @@ DIFF, SPEC, REFR = 0, 1, 2
 # every symbol include/rt_api.h declares (tests/test_abi.py checks the export table)
 SYMBOLS = ["rt_render", "rt_create", "rt_create_sharded", "rt_destroy", "rt_set_scene",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
-           "rt_device_pixels", "rt_set_pixel_buffer", "rt_local_rows", "rt_current_sample", "rt_read_colors",
+           "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream", "rt_local_rows", "rt_current_sample", "rt_read_colors",
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_compute_camera",
            "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_debug_eval"]
 
@@ -73,6 +73,7 @@ def load_library():
         "rt_render_async": (i32, [vp, i32, vp]),
         "rt_device_pixels": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "rt_set_pixel_buffer": (i32, [vp, vp, sz]),
+        "rt_stream": (vp, [vp]),
         "rt_local_rows": (i32, [vp]),
         "rt_current_sample": (i32, [vp]),
         "rt_read_colors": (i32, [vp, vp]),
@@ -138,11 +139,15 @@ class RtContext:
         _check(self._lib.rt_create_sharded(C.byref(self._h), w, h, device, rank, nranks, tile_rows))
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             self._lib.rt_destroy(self._h)
-            self._h = C.c_void_p()
+            self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: modules may already be gone
+            pass
 
     def __enter__(self):
         return self
@@ -189,6 +194,11 @@ class RtContext:
     def set_pixel_buffer(self, dptr, count):
         """Later launches write their packed pixels to this device address (None = own buffer)."""
         _check(self._lib.rt_set_pixel_buffer(self._h, C.c_void_p(dptr or 0), count))
+
+    @property
+    def stream(self):
+        """Raw hipStream_t of the context's own stream (wrap with torch.cuda.ExternalStream)."""
+        return self._lib.rt_stream(self._h)
 
     def device_pixels(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -370,6 +370,11 @@ int rt_set_pixel_buffer(rt_ctx *c, void *dptr, size_t count) {
     return RT_OK;
 }
 
+// The context's own stream (hipStream_t, non-blocking): what rt_render_pass launches on.  Callers
+// that keep several contexts in flight can launch each on its own stream through
+// rt_render_async(ctx, n, rt_stream(ctx)).
+void *rt_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 int rt_device_pixels(rt_ctx *c, void **dptr, size_t *count) {
     if (!c || !dptr || !count) return fail(RT_ERR_ARG, "null argument");
     *dptr = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
