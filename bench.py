@@ -196,15 +196,17 @@ def main():
     other = None
     if world == 1:
         other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
-        ctx.set_mode(other_mode)
-        el_o, _, _ = timed_region(1, 8, 2)
-        st_o = ctx.stats()
-        px_o = ctx.render_pass(0, copy=True)
-        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "frames_in_flight": 1,
+        for c in ctxs:
+            c.set_mode(other_mode)
+        el_o, _, last_o = timed_region(F, 8, 2, with_events=False)
+        st_o = last_o.stats()
+        px_o = last_o.render_pass(0, copy=True)
+        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "frames_in_flight": F,
                  "ms_per_step": round(el_o / 8 * 1e3, 4),
                  "value": round((st_o["samples"] + st_o["shadow_rays"]) * 8 / el_o / 1e6, 1), "unit": "Mray/s",
                  "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2)}
-        ctx.set_mode(mode)
+        for c in ctxs:
+            c.set_mode(mode)
 
     counts = torch.tensor([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],
                           dtype=torch.int64, device=dev)
@@ -267,7 +269,7 @@ def main():
                 "traffic": traffic,
                 "launches_overlap": single is None,
                 "kernel_ms": round(roof_kernel_ms, 4),
-                "kernel_ms_max_rank": round(kernel_ms_max, 4),
+                "step_ms_max_rank": round(kernel_ms_max, 4),
                 "algorithmic_flops_per_launch": flops,
                 "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                         "achieved": round(alg_bytes / (roof_kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
