@@ -489,6 +489,21 @@ long long rt_debug_sqrt_mismatches(void) {
     return (long long)h;
 }
 
+// mismatches of the candidate lean reciprocals per input exponent: out[4][256]
+int rt_debug_rcp_probe(unsigned long long *out1024) {
+    if (!out1024) return fail(RT_ERR_ARG, "null argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
+    unsigned long long *d = nullptr;
+    if (hipSetDevice(0) != hipSuccess || hipMalloc(&d, 8192) != hipSuccess) return fail(RT_ERR_HIP, "alloc");
+    hipError_t e = hipMemset(d, 0, 8192);
+    if (e == hipSuccess) e = rt::launch_rcp_probe(d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out1024, d, 8192, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_rcp_probe: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
 int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
     if ((!in_host || !out_host) && n) return fail(RT_ERR_ARG, "null argument");
     if (op < 0 || op > 8) return fail(RT_ERR_ARG, "op %d", op);

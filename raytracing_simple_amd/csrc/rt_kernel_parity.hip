@@ -58,6 +58,14 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_r0              /* A/B: the shipped shape with the compiler's reciprocal */
+#define RT_KERNEL_NAME rt_trace_parity_r0
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_LEAN_RCP 0
+#define RT_OPT_MINWAVES 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
@@ -70,6 +78,7 @@ static KernelFn const kParityKernels[] = {
     parity_coopv::rt_trace_parity_coopv,  // 5
     parity_persist::rt_trace_parity_persist,            // 6 = kParityPersistVariant
     parity_persist_coop::rt_trace_parity_persist_coop,  // 7 = kParityPersistCoopVariant
+    parity_r0::rt_trace_parity_r0,                      // 8
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
@@ -90,6 +99,11 @@ hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hip
 
 hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream) {
     hipLaunchKernelGGL(parity::rt_sqrt_check_kernel, dim3(256 * 16), dim3(256), 0, stream, d_mismatches);
+    return hipGetLastError();
+}
+
+hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream) {
+    hipLaunchKernelGGL(parity::rt_rcp_probe_kernel, dim3(256 * 16), dim3(256), 0, stream, d_hist);
     return hipGetLastError();
 }
 

@@ -11,3 +11,4 @@
 #undef RT_OPT_MINWAVES
 #undef RT_OPT_LEAN_SQRT
 #undef RT_OPT_PERSIST
+#undef RT_OPT_LEAN_RCP

@@ -62,6 +62,10 @@
 #ifndef RT_OPT_LEAN_SQRT
 #define RT_OPT_LEAN_SQRT 0
 #endif
+// RT_OPT_LEAN_RCP: with LEAN_SQRT, normalisations use the lean reciprocal as well (sqrt_and_rcp)
+#ifndef RT_OPT_LEAN_RCP
+#define RT_OPT_LEAN_RCP 1
+#endif
 
 
 #undef RT_STAMP
@@ -150,12 +154,40 @@ RT_DEV float rt_div(float a, float b) {
     return a / b;
 #endif
 }
-RT_DEV V3 unit(V3 a) {                                                               // .cl:122-126
+// sqrt(dd) and 1/sqrt(dd), each correctly rounded (the reference's vnorm: f = 1.f/sqrt(v.v)).
+// Lean form: v_rcp_f32 plus ONE fused Newton step equals the correctly rounded quotient 1.f/x for
+// every x with biased exponent 1..252 (all 2^32 inputs tried on the device: tools/rcp_probe.py,
+// rt_debug_rcp_probe), and for dd in [2^-96, FLT_MAX] the root lies in [2^-48, 2^64].  One wave
+// ballot sends the rare wavefront holding anything else (zero, tiny, infinite, NaN) to the
+// generic expansions.
+RT_DEV float sqrt_and_rcp(float dd, float &root) {
 #if RT_FAST
-    return scale(a, __builtin_amdgcn_rsqf(dot(a, a)));
+    root = __builtin_amdgcn_sqrtf(dd);
+    return __builtin_amdgcn_rsqf(dd);
+#elif RT_OPT_LEAN_SQRT && RT_OPT_LEAN_RCP
+    if (__builtin_amdgcn_ballot_w64(!(dd >= 0x1p-96f && dd <= 0x1.fffffep+127f)) != 0ull) {
+        root = sqrtf(dd);
+        return 1.f / root;
+    }
+    float s = __builtin_amdgcn_sqrtf(dd);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float e_dn = __builtin_fmaf(-s_dn, s, dd);
+    const float e_up = __builtin_fmaf(-s_up, s, dd);
+    s = (e_dn <= 0.f) ? s_dn : s;
+    s = (e_up > 0.f) ? s_up : s;
+    root = s;
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e0 = __builtin_fmaf(-s, r0, 1.f);
+    return __builtin_fmaf(e0, r0, r0);
 #else
-    return scale(a, 1.f / rt_sqrt(dot(a, a)));
+    root = rt_sqrt(dd);
+    return 1.f / root;
 #endif
+}
+RT_DEV V3 unit(V3 a) {                                                               // .cl:122-126
+    float root;
+    return scale(a, sqrt_and_rcp(dot(a, a), root));
 }
 
 // .cl:354 sign(): +-1, zero keeps its sign, NaN -> 0
@@ -318,8 +350,7 @@ RT_DEV bool sample_light(float4 la, float4 lb, uint32_t &s0, uint32_t &s1, uint3
     V3 us = mk(ring * cphi, ring * sphi, zc);
     V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
     sd = sub(on_light, hp);
-    len = rt_sqrt(dot(sd, sd));
-    sd = scale(sd, rt_rcp(len));
+    sd = scale(sd, sqrt_and_rcp(dot(sd, sd), len));
     float wo = dot(sd, us);
     if (wo > 0.f) return false;                                            // far side of the light
     wo = -wo;
@@ -807,17 +838,13 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
                     float Re = R0 + (1 - R0) * c * c * c * c * c;
                     float Tr = 1.f - Re;
                     float Pr = .25f + .5f * Re;
-                    float RP = rt_div(Re, Pr);
-                    float TP = rt_div(Tr, 1.f - Pr);
                     float pick = next_random(s0, s1);
                     c_draws += 1;
-                    if (pick < Pr) {
-                        thr = mul(scale(thr, RP), col);
-                        d = rfl;
-                    } else {
-                        thr = mul(scale(thr, TP), col);
-                        d = td;
-                    }
+                    // RP = Re / P and TP = Tr / (1 - P): only the branch taken is divided
+                    const bool take_rfl = pick < Pr;
+                    const float wgt = rt_div(take_rfl ? Re : Tr, take_rfl ? Pr : 1.f - Pr);
+                    thr = mul(scale(thr, wgt), col);
+                    d = take_rfl ? rfl : td;
                 }
             }
             o = hp;
@@ -902,6 +929,31 @@ extern "C" __global__ void rt_sqrt_check_kernel(unsigned long long *mismatches) 
         if (a != r && !both_nan) bad += 1;
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+// candidate lean reciprocals against the compiler's correctly rounded 1.f/x, every bit pattern;
+// hist[v*256 + biased exponent of x] counts the mismatches of candidate v
+extern "C" __global__ void rt_rcp_probe_kernel(unsigned long long *hist) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const uint32_t ex = ((uint32_t)b >> 23) & 255u;
+        const uint32_t ref = __float_as_uint(1.f / x);
+        const bool ref_nan = (ref & 0x7fffffffu) > 0x7f800000u;
+        const float r0 = __builtin_amdgcn_rcpf(x);
+        const float e0 = __builtin_fmaf(-x, r0, 1.f);
+        const float r1 = __builtin_fmaf(e0, r0, r0);
+        const float e1 = __builtin_fmaf(-x, r1, 1.f);
+        const float r2 = __builtin_fmaf(e1, r1, r1);
+        const float r2b = __builtin_fmaf(e1, r0, r1);       // the compiler's shape: residual times the first estimate
+        const float cand[4] = { r0, r1, r2, r2b };
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const uint32_t a = __float_as_uint(cand[v]);
+            const bool a_nan = (a & 0x7fffffffu) > 0x7f800000u;
+            if (a != ref && !(a_nan && ref_nan)) atomicAdd(&hist[v * 256 + ex], 1ull);
+        }
+    }
 }
 
 // scalar building blocks, for rt_debug_eval

@@ -267,6 +267,19 @@ def test_lean_sqrt_equals_compiler_sqrt_for_every_float():
         assert np.array_equal(api.debug_eval(8, v).view(np.uint32), np.sqrt(v).view(np.uint32))
 
 
+def test_lean_reciprocal_equals_compiler_division_where_it_is_used():
+    """sqrt_and_rcp's reciprocal (v_rcp_f32 + one fused Newton step) against the compiler's
+    correctly rounded 1.f/x over all 2^32 bit patterns: it may only differ for inputs with biased
+    exponent 0, 253 or 254, which the wave ballot in sqrt_and_rcp routes to the generic form."""
+    import ctypes as C
+    lib = api.load_library()
+    hist = (C.c_ulonglong * 1024)()
+    assert lib.rt_debug_rcp_probe(hist) == 0
+    one_step = [hist[256 + e] for e in range(256)]
+    assert [e for e in range(256) if one_step[e]] == [0, 253, 254]
+    assert sum(hist[e] for e in range(1, 253)) > 0          # v_rcp_f32 alone is not enough
+
+
 # ---- fast mode -----------------------------------------------------------------------------------
 def test_fast_mode_psnr_gate():
     w = h = 256
