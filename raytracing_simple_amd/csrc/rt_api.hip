@@ -476,18 +476,21 @@ int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w,
 }
 
 // exhaustive device-side check of the lean correctly-rounded sqrt: mismatches over all 2^32 inputs
-long long rt_debug_sqrt_mismatches(void) {
+static long long sqrt_check(int which) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
     unsigned long long *d = nullptr, h = 0;
     if (hipSetDevice(0) != hipSuccess || hipMalloc(&d, 8) != hipSuccess) return fail(RT_ERR_HIP, "alloc");
     hipError_t e = hipMemset(d, 0, 8);
-    if (e == hipSuccess) e = rt::launch_sqrt_check(d, nullptr);
+    if (e == hipSuccess) e = rt::launch_sqrt_check(d, nullptr, which);
     if (e == hipSuccess) e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_sqrt_mismatches: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "sqrt check %d: %s", which, hipGetErrorString(e));
     return (long long)h;
 }
+long long rt_debug_sqrt_mismatches(void) { return sqrt_check(0); }
+// sphere test with the unchecked square root against the one with sqrtf, tiny discriminants
+long long rt_debug_hitpost_mismatches(void) { return sqrt_check(1); }
 
 // mismatches of the candidate lean reciprocals per input exponent: out[4][256]
 int rt_debug_rcp_probe(unsigned long long *out1024) {

@@ -67,7 +67,7 @@ constexpr int kParityPersistVariant = 6, kParityPersistCoopVariant = 7;
 constexpr int kFastPersistVariant = 4, kFastPersistCoopVariant = 5;
 int parity_variant_count();
 int fast_variant_count();
-hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream);
+hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream, int which = 0);
 hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream);
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);
 hipError_t prepare_parity();    // raise the dynamic-LDS limit (called once per context)

@@ -58,10 +58,10 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS parity_r0              /* A/B: the shipped shape with the compiler's reciprocal */
+#define RT_NS parity_r0              /* A/B: the shipped shape with range checks on every square root */
 #define RT_KERNEL_NAME rt_trace_parity_r0
 #define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_LEAN_RCP 0
+#define RT_OPT_SQRT_NOCHECK 0
 #define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
@@ -97,7 +97,11 @@ hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hip
     return hipGetLastError();
 }
 
-hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream) {
+hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream, int which) {
+    if (which == 1) {
+        hipLaunchKernelGGL(parity::rt_hitpost_check_kernel, dim3(256 * 16), dim3(256), 0, stream, d_mismatches);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(parity::rt_sqrt_check_kernel, dim3(256 * 16), dim3(256), 0, stream, d_mismatches);
     return hipGetLastError();
 }

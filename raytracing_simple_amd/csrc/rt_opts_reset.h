@@ -12,3 +12,4 @@
 #undef RT_OPT_LEAN_SQRT
 #undef RT_OPT_PERSIST
 #undef RT_OPT_LEAN_RCP
+#undef RT_OPT_SQRT_NOCHECK

@@ -66,6 +66,10 @@
 #ifndef RT_OPT_LEAN_RCP
 #define RT_OPT_LEAN_RCP 1
 #endif
+// RT_OPT_SQRT_NOCHECK: no range check where the argument cannot need it (rt_sqrt_unit, rt_sqrt_det)
+#ifndef RT_OPT_SQRT_NOCHECK
+#define RT_OPT_SQRT_NOCHECK 1
+#endif
 
 
 #undef RT_STAMP
@@ -119,8 +123,7 @@ RT_DEV V3 cross(V3 a, V3 b) {                                                   
 // inputs come out of the neighbour test unchanged, as worked through in DESIGN.md), so one wave
 // ballot routes the rare wavefront that holds such an input to the generic form and everybody
 // else runs 9 VALU + the check.  Equal to sqrtf for all 2^32 inputs (rt_debug_sqrt_mismatches).
-RT_DEV float ieee_sqrt_lean(float x) {
-    if (__builtin_amdgcn_ballot_w64(fabsf(x) < 0x1p-96f && x != 0.f) != 0ull) return sqrtf(x);
+RT_DEV float ieee_sqrt_core(float x) {
     float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
     const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
@@ -130,6 +133,10 @@ RT_DEV float ieee_sqrt_lean(float x) {
     s = (e_up > 0.f) ? s_up : s;
     return s;
 }
+RT_DEV float ieee_sqrt_lean(float x) {
+    if (__builtin_amdgcn_ballot_w64(fabsf(x) < 0x1p-96f && x != 0.f) != 0ull) return sqrtf(x);
+    return ieee_sqrt_core(x);
+}
 
 RT_DEV float rt_sqrt(float x) {
 #if RT_FAST
@@ -138,6 +145,35 @@ RT_DEV float rt_sqrt(float x) {
     return ieee_sqrt_lean(x);
 #else
     return sqrtf(x);       // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+#endif
+}
+// Square root of a value that is 0 or at least 2^-96 by construction (1 - z*z with z = 1 - 2k/2^23,
+// k/2^23, 1 - k/2^23): no range check.
+RT_DEV float rt_sqrt_unit(float x) {
+#if RT_FAST
+    return __builtin_amdgcn_sqrtf(x);
+#elif RT_OPT_LEAN_SQRT && RT_OPT_SQRT_NOCHECK
+    return ieee_sqrt_core(x);
+#elif RT_OPT_LEAN_SQRT
+    return ieee_sqrt_lean(x);
+#else
+    return sqrtf(x);
+#endif
+}
+// Square root of a discriminant (hit_post).  No range check either: for 0 < det < 2^-96 the
+// unscaled form returns some sq with 0 <= sq < 2^-47 (never NaN), and the roots b -+ sq then do
+// not depend on which: with |b| >= 2^-23 both round to b (sq is below half an ulp of b), and with
+// |b| < 2^-23 both are below EPSILON and the test returns 0 (rt_debug_hitpost_mismatches tries
+// every such det against a set of b on the device).
+RT_DEV float rt_sqrt_det(float x) {
+#if RT_FAST
+    return __builtin_amdgcn_sqrtf(x);
+#elif RT_OPT_LEAN_SQRT && RT_OPT_SQRT_NOCHECK
+    return ieee_sqrt_core(x);
+#elif RT_OPT_LEAN_SQRT
+    return ieee_sqrt_lean(x);
+#else
+    return sqrtf(x);
 #endif
 }
 RT_DEV float rt_rcp(float x) {
@@ -225,7 +261,7 @@ RT_DEV HitPre hit_pre(float4 g, V3 o, V3 d) {
     return HitPre{ b, b * b - dot(op, op) + g.w };
 }
 RT_DEV float hit_post(HitPre p) {
-    float sq = rt_sqrt(p.det);
+    float sq = rt_sqrt_det(p.det);
     float t1 = p.b - sq;
     float t2 = p.b + sq;
     float t = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
@@ -340,7 +376,7 @@ RT_DEV bool sample_light(float4 la, float4 lb, uint32_t &s0, uint32_t &s1, uint3
     float u2 = next_random(s0, s1);
     c_draws += 2;
     float zc = 1.f - 2.f * u1;                                             // .cl:203-213
-    float ring = rt_sqrt(fmaxf(0.f, 1.f - zc * zc));
+    float ring = rt_sqrt_unit(fmaxf(0.f, 1.f - zc * zc));
     float sphi, cphi;
 #if RT_FAST
     fm_sincos_turns(u2, sphi, cphi);
@@ -797,7 +833,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
             float u = next_random(s0, s1);
             float r2 = next_random(s0, s1);
             c_draws += 2;
-            float r2s = rt_sqrt(r2);
+            float r2s = rt_sqrt_unit(r2);
             V3 w = nl;
             V3 a = (fabsf(w.x) > .1f) ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
             V3 uu = unit(cross(a, w));
@@ -809,7 +845,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
             dm_sincosf_pos((2.f * RT_PI) * u, s1v, c1v);
 #endif
             V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
-            nd = add(nd, scale(w, rt_sqrt(1 - r2)));
+            nd = add(nd, scale(w, rt_sqrt_unit(1 - r2)));
             o = hp;
             d = nd;
         } else if (is_gloss) {
@@ -927,6 +963,30 @@ extern "C" __global__ void rt_sqrt_check_kernel(unsigned long long *mismatches) 
         const uint32_t a = __float_as_uint(ieee_sqrt_lean(x)), r = __float_as_uint(sqrtf(x));
         const bool both_nan = ((a & 0x7fffffffu) > 0x7f800000u) && ((r & 0x7fffffffu) > 0x7f800000u);
         if (a != r && !both_nan) bad += 1;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// hit_post with the unchecked square root against hit_post with sqrtf: every discriminant in
+// (0, 2^-96) and a few above, against b values around the decisions of the test
+extern "C" __global__ void rt_hitpost_check_kernel(unsigned long long *mismatches) {
+    const float bs[24] = { 0.f, -0.f, 0x1p-149f, 0x1p-126f, 0x1p-60f, 0x1p-48f, 0x1p-47f, 0x1p-46f, 0x1p-30f,
+                           0x1p-24f, 0x1.fffffep-24f, 0x1p-23f, 0x1.000002p-23f, 0x1p-22f, 0.005f, 0x1.47ae12p-7f,
+                           0.01f, 0x1.47ae16p-7f, 0.02f, 1.f, 3.f, 1000.f, 1e20f, 3e38f };
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < 0x10000000ull; k += stride) {
+        const float det = __uint_as_float((uint32_t)k + 1u);          // (0, 2^-95)
+        for (int j = 0; j < 24; ++j) {
+            for (int sg = 0; sg < 2; ++sg) {
+                const float b = sg ? -bs[j] : bs[j];
+                const float sq_ref = sqrtf(det);
+                const float t1r = b - sq_ref, t2r = b + sq_ref;
+                const float tr = t1r > RT_EPS ? t1r : (t2r > RT_EPS ? t2r : 0.f);
+                const float th = hit_post(HitPre{ b, det });
+                if (__float_as_uint(tr) != __float_as_uint(th)) bad += 1;
+            }
+        }
     }
     if (bad) atomicAdd(mismatches, bad);
 }

@@ -267,16 +267,28 @@ def test_lean_sqrt_equals_compiler_sqrt_for_every_float():
         assert np.array_equal(api.debug_eval(8, v).view(np.uint32), np.sqrt(v).view(np.uint32))
 
 
+def test_sphere_test_does_not_depend_on_the_rounding_of_tiny_discriminant_roots():
+    """hit_post takes the square root without the range check of ieee_sqrt_lean; for every
+    discriminant in (0, 2^-95) and b values around every decision of the test the result equals
+    the one computed with sqrtf."""
+    import ctypes as C
+    lib = api.load_library()
+    lib.rt_debug_hitpost_mismatches.restype = C.c_longlong
+    assert lib.rt_debug_hitpost_mismatches() == 0
+
+
 def test_lean_reciprocal_equals_compiler_division_where_it_is_used():
     """sqrt_and_rcp's reciprocal (v_rcp_f32 + one fused Newton step) against the compiler's
     correctly rounded 1.f/x over all 2^32 bit patterns: it may only differ for inputs with biased
-    exponent 0, 253 or 254, which the wave ballot in sqrt_and_rcp routes to the generic form."""
+    exponent 0, 253 or 254 and for the two infinities, which the wave ballot in sqrt_and_rcp routes
+    to the generic form."""
     import ctypes as C
     lib = api.load_library()
     hist = (C.c_ulonglong * 1024)()
     assert lib.rt_debug_rcp_probe(hist) == 0
     one_step = [hist[256 + e] for e in range(256)]
-    assert [e for e in range(256) if one_step[e]] == [0, 253, 254]
+    assert [e for e in range(256) if one_step[e]] == [0, 253, 254, 255]
+    assert one_step[255] == 2
     assert sum(hist[e] for e in range(1, 253)) > 0          # v_rcp_f32 alone is not enough
 
 
