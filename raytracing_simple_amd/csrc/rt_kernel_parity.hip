@@ -58,10 +58,10 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS parity_r0              /* A/B: the shipped shape with range checks on every square root */
+#define RT_NS parity_r0              /* A/B: the shipped shape without its newest change */
 #define RT_KERNEL_NAME rt_trace_parity_r0
 #define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_SQRT_NOCHECK 0
+#define RT_OPT_JOINT_SKIP 1
 #define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"

@@ -13,3 +13,5 @@
 #undef RT_OPT_PERSIST
 #undef RT_OPT_LEAN_RCP
 #undef RT_OPT_SQRT_NOCHECK
+#undef RT_OPT_SHORT_ROOTS
+#undef RT_OPT_JOINT_SKIP

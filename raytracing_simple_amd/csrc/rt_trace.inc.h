@@ -66,6 +66,13 @@
 #ifndef RT_OPT_LEAN_RCP
 #define RT_OPT_LEAN_RCP 1
 #endif
+// RT_OPT_SHORT_ROOTS: the sweeps use hit_roots' short form of the root decision
+#ifndef RT_OPT_SHORT_ROOTS
+#define RT_OPT_SHORT_ROOTS 1
+#endif
+#ifndef RT_OPT_JOINT_SKIP
+#define RT_OPT_JOINT_SKIP 0
+#endif
 // RT_OPT_SQRT_NOCHECK: no range check where the argument cannot need it (rt_sqrt_unit, rt_sqrt_det)
 #ifndef RT_OPT_SQRT_NOCHECK
 #define RT_OPT_SQRT_NOCHECK 1
@@ -267,6 +274,25 @@ RT_DEV float hit_post(HitPre p) {
     float t = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
     return p.det < 0.f ? 0.f : t;
 }
+// The same decision with fewer operations, for the sweeps: `hit` says that the reference's
+// SphereIntersect returns a non-zero distance and `t` is that distance.  sq >= 0 makes
+// t1 = fl(b - sq) <= b <= fl(b + sq) = t2, so "t1 > EPS or t2 > EPS" is "t2 > EPS".  The sign test
+// of the discriminant stays (it is the comparison the wave ballot of the sweep already made): the
+// unscaled v_sqrt_f32 does not return NaN for a negative subnormal.
+struct HitRoots {
+    float t;
+    bool hit;
+};
+RT_DEV HitRoots hit_roots(HitPre p) {
+#if !RT_OPT_SHORT_ROOTS
+    const float h = hit_post(p);
+    return HitRoots{ h, h != 0.f };
+#endif
+    const float sq = rt_sqrt_det(p.det);
+    const float t1 = p.b - sq;
+    const float t2 = p.b + sq;
+    return HitRoots{ t1 > RT_EPS ? t1 : t2, (p.det >= 0.f) && (t2 > RT_EPS) };
+}
 // true when some active lane needs the roots (NaN discriminants never hit: .cl:185-200)
 RT_DEV bool wave_any_nonneg(float det) {
 #if RT_OPT_SKIPNEG
@@ -300,11 +326,11 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
                      p3 = hit_pre(g3, o, d);
         if (wave_any_nonneg(fmaxf(fmaxf(roots_matter(p0), roots_matter(p1)), fmaxf(roots_matter(p2), roots_matter(p3))))) {
             roots += 4;
-            const float h0 = hit_post(p0), h1 = hit_post(p1), h2 = hit_post(p2), h3 = hit_post(p3);
-            if (h0 != 0.f && h0 < t) { t = h0; id = i; }
-            if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
-            if (h2 != 0.f && h2 < t) { t = h2; id = i + 2; }
-            if (h3 != 0.f && h3 < t) { t = h3; id = i + 3; }
+            const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1), h2 = hit_roots(p2), h3 = hit_roots(p3);
+            if (h0.hit && h0.t < t) { t = h0.t; id = i; }
+            if (h1.hit && h1.t < t) { t = h1.t; id = i + 1; }
+            if (h2.hit && h2.t < t) { t = h2.t; id = i + 2; }
+            if (h3.hit && h3.t < t) { t = h3.t; id = i + 3; }
         }
     }
 #endif
@@ -312,24 +338,33 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
+#if RT_OPT_JOINT_SKIP
+        if (wave_any_nonneg(fmaxf(roots_matter(p0), roots_matter(p1)))) {
+            roots += 2;
+            const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1);
+            if (h0.hit && h0.t < t) { t = h0.t; id = i; }
+            if (h1.hit && h1.t < t) { t = h1.t; id = i + 1; }
+        }
+#else
         if (wave_any_nonneg(roots_matter(p0))) {
             roots += 1;
-            const float h0 = hit_post(p0);
-            if (h0 != 0.f && h0 < t) { t = h0; id = i; }
+            const HitRoots h0 = hit_roots(p0);
+            if (h0.hit && h0.t < t) { t = h0.t; id = i; }
         }
         if (wave_any_nonneg(roots_matter(p1))) {
             roots += 1;
-            const float h1 = hit_post(p1);
-            if (h1 != 0.f && h1 < t) { t = h1; id = i + 1; }
+            const HitRoots h1 = hit_roots(p1);
+            if (h1.hit && h1.t < t) { t = h1.t; id = i + 1; }
         }
+#endif
     }
 #endif
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
         if (wave_any_nonneg(roots_matter(p0))) {
             roots += 1;
-            const float h0 = hit_post(p0);
-            if (h0 != 0.f && h0 < t) { t = h0; id = i; }
+            const HitRoots h0 = hit_roots(p0);
+            if (h0.hit && h0.t < t) { t = h0.t; id = i; }
         }
     }
 }
@@ -346,8 +381,8 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
         if (wave_any_nonneg(fmaxf(roots_matter(p0), roots_matter(p1)))) {
             roots += 2;
-            const float h0 = hit_post(p0), h1 = hit_post(p1);
-            const bool b0 = (h0 != 0.f && h0 < max_t), b1 = (h1 != 0.f && h1 < max_t);
+            const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1);
+            const bool b0 = (h0.hit && h0.t < max_t), b1 = (h1.hit && h1.t < max_t);
             const uint32_t cand = b0 ? i : (b1 ? i + 1 : n);
             first = first < cand ? first : cand;
             if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
@@ -358,8 +393,8 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
         const HitPre p0 = hit_pre(s_geom[i], o, d);
         if (wave_any_nonneg(roots_matter(p0))) {
             roots += 1;
-            const float h0 = hit_post(p0);
-            const uint32_t cand = (h0 != 0.f && h0 < max_t) ? i : n;
+            const HitRoots h0 = hit_roots(p0);
+            const uint32_t cand = (h0.hit && h0.t < max_t) ? i : n;
             first = first < cand ? first : cand;
             if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
         }
@@ -441,8 +476,8 @@ RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d
         for (uint32_t i = (uint32_t)grp; i < n; i += (uint32_t)G) {
             const HitPre p0 = hit_pre(s_geom[i], ro, rd);
             if (wave_any_nonneg(p0.det)) {
-                const float h0 = hit_post(p0);
-                if (h0 != 0.f && h0 < ra.w) {
+                const HitRoots h0 = hit_roots(p0);
+                if (h0.hit && h0.t < ra.w) {
                     found = i;
                     break;
                 }
@@ -984,9 +1019,22 @@ extern "C" __global__ void rt_hitpost_check_kernel(unsigned long long *mismatche
                 const float t1r = b - sq_ref, t2r = b + sq_ref;
                 const float tr = t1r > RT_EPS ? t1r : (t2r > RT_EPS ? t2r : 0.f);
                 const float th = hit_post(HitPre{ b, det });
+                const HitRoots hr = hit_roots(HitPre{ b, det });
                 if (__float_as_uint(tr) != __float_as_uint(th)) bad += 1;
+                if (__float_as_uint(tr) != __float_as_uint(hr.hit ? hr.t : 0.f)) bad += 1;
             }
         }
+        // and the short decision (hit_roots) against the reference's, arbitrary bit patterns
+        uint32_t h1 = (uint32_t)k * 2654435761u + 0x9e3779b9u, h2 = ((uint32_t)k ^ 0x85ebca6bu) * 2246822519u;
+        h1 ^= h1 >> 15; h1 *= 2246822519u; h1 ^= h1 >> 13;
+        h2 ^= h2 >> 16; h2 *= 3266489917u; h2 ^= h2 >> 14;
+        const float rb = __uint_as_float(h1), rdet = __uint_as_float(h2);
+        const float sq = sqrtf(rdet);
+        const float t1 = rb - sq, t2 = rb + sq;
+        float tr = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
+        tr = rdet < 0.f ? 0.f : tr;
+        const HitRoots hr = hit_roots(HitPre{ rb, rdet });
+        if (__float_as_uint(tr) != __float_as_uint(hr.hit ? hr.t : 0.f)) bad += 1;
     }
     if (bad) atomicAdd(mismatches, bad);
 }
