@@ -69,6 +69,41 @@ def test_synthetic_scenes_bit_exact_vs_oracle(maker, w, h, spp):
     _assert_same(_gpu(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp))
 
 
+def _fuzz_scene(seed):
+    """Adversarial random scene: overlapping spheres, a camera that may sit inside one, zero and
+    tiny radii, far-away and huge spheres, 0..3 lights, emission with only a green component (the
+    reference's zero test ignores y), all three materials."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 3, 5, 7, 12, 20, 33, 48, 63, 64, 65, 90, 130]))
+    sph = np.zeros(n, api.SPHERE_DT)
+    kind = rng.integers(0, 10, n)
+    sph["rad"] = np.where(kind == 0, 0.0, np.where(kind == 1, 1e-4, np.where(kind == 2, 5e3, rng.uniform(0.5, 25.0, n)))).astype(np.float32)
+    sph["p"] = rng.uniform(-60, 60, (n, 3)).astype(np.float32)
+    far = kind == 3
+    sph["p"][far] *= np.float32(1e4)
+    sph["c"] = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float32)
+    sph["refl"] = rng.choice([api.DIFF, api.DIFF, api.SPEC, api.REFR], n)
+    n_lights = int(rng.integers(0, 4))
+    for j in rng.choice(n, min(n_lights, n), replace=False):
+        sph["e"][j] = rng.uniform(2.0, 20.0, 3).astype(np.float32)
+    if n > 3 and seed % 3 == 0:
+        sph["e"][int(rng.integers(0, n))] = (0.0, 7.0, 0.0)        # .cl:135-138: not a light, not emissive
+    orig = rng.uniform(-80, 80, 3).astype(np.float32)
+    if seed % 4 == 1:
+        orig = (sph["p"][0] + np.float32(0.25) * sph["rad"][0]).astype(np.float32)   # inside sphere 0
+    target = rng.uniform(-10, 10, 3).astype(np.float32)
+    return sph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzzed_scenes_bit_exact_vs_oracle(seed):
+    sph, orig, target = _fuzz_scene(seed)
+    w, h, spp = [(40, 24, 3), (33, 17, 2), (64, 32, 5), (25, 40, 4)][seed % 4]
+    cam = host.compute_camera(orig, target, w, h)
+    with np.errstate(all="ignore"):
+        _assert_same(_gpu(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp))
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (33, 17), (64, 9), (31, 8)])
 def test_ragged_sizes(w, h):
     sph = host.demo_scene()
