@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fno-slp-vectorize",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
-          "-Wall", "-Wno-unused-function"]
+          "-Wall", "-Wno-unused-function", "-Wno-sometimes-uninitialized", "-Wno-uninitialized"]
 UNITS = [
     # source, extra flags
     ("rt_kernel_parity.hip", ["-ffp-contract=off"]),

@@ -233,8 +233,13 @@ RT_DEV V3 unit(V3 a) {                                                          
     return scale(a, sqrt_and_rcp(dot(a, a), root));
 }
 
-// .cl:354 sign(): +-1, zero keeps its sign, NaN -> 0
-RT_DEV float cl_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : (x != x ? 0.f : x)); }
+// .cl:354 sign(): +-1, zero keeps its sign, NaN -> 0.  Three selects, no branches.
+RT_DEV float cl_sign(float x) {
+    float r = __builtin_copysignf(1.f, x);
+    r = (x == 0.f) ? x : r;
+    r = (x != x) ? 0.f : r;
+    return r;
+}
 
 // .cl:143-169
 RT_DEV float next_random(uint32_t &s0, uint32_t &s1) {
@@ -547,8 +552,6 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         for (int i = tid; i < P.n_samples; i += kBlockThreads)
             s_k2[i] = rt_rcp((float)(P.first_sample + i) + 1.f);
     __syncthreads();
-    const float4 *m_emis = P.mat_in_lds ? s_emis : P.scene.emis;
-    const float4 *m_colr = P.mat_in_lds ? s_colr : P.scene.colr;
 
     // ---- pixel of this lane ---------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
@@ -603,7 +606,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     const V3 cam_y = mk(P.cam.y.x, P.cam.y.y, P.cam.y.z);
 
     uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
-    unsigned long long c_tests = 0;   // per-ray additions only (never inside a sphere loop)
+    unsigned long long c_tests = 0;   // shadow-ray tests (per-ray additions, never inside a sphere loop); closest-hit rays add n each, at the end
 
     // ---- path state -----------------------------------------------------------------
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);
@@ -750,19 +753,26 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         sweep_closest(s_geom, n, o, d, t, id, st_roots_c);
         RT_STAMP_ROOTS(10, st_roots_c);
         c_closest += 1;
-        c_tests += n;
 
         bool path_done = false;
         bool is_diff = false, is_gloss = false;   // what the hit asks for next
-        V3 hp = o, nrm = d, nl = d, col = thr;
-        int refl = RT_DIFF;
+        // the hit record: written by the hit branch, read only where is_diff / is_gloss say it was
+        V3 hp, nrm, nl, col;
+        int refl;
         if (!(t < 1e20f)) {
             path_done = true;                                              // miss, .cl:327-330
         } else {
             RT_STAMP(2);
             const float4 ge = s_geom[id];
-            const float4 em4 = m_emis[id];
-            const float4 co4 = m_colr[id];
+            float4 em4, co4;
+            if (P.mat_in_lds) {                 // wave-uniform: ds_read / global_load, not flat_load
+                em4 = s_emis[id];
+                co4 = s_colr[id];
+                asm volatile("; materials from LDS" : "+v"(em4.x));   // keeps the two loads from being merged into one generic-pointer load
+            } else {
+                em4 = P.scene.emis[id];
+                co4 = P.scene.colr[id];
+            }
             const V3 em = mk(em4.x, em4.y, em4.z);
             col = mk(co4.x, co4.y, co4.z);
             refl = __float_as_int(em4.w);
@@ -964,7 +974,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);
     uint32_t t_draws = wave_sum(c_draws);
-    unsigned long long tests64 = c_tests;
+    unsigned long long tests64 = c_tests + (unsigned long long)c_closest * n;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
     // one LDS add per wavefront, then one global add per workgroup into one of kStatReplicas
