@@ -15,3 +15,4 @@
 #undef RT_OPT_SQRT_NOCHECK
 #undef RT_OPT_SHORT_ROOTS
 #undef RT_OPT_JOINT_SKIP
+#undef RT_OPT_ANY_JOINT

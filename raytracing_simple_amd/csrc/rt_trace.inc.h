@@ -70,6 +70,10 @@
 #ifndef RT_OPT_SHORT_ROOTS
 #define RT_OPT_SHORT_ROOTS 1
 #endif
+// RT_OPT_ANY_JOINT: the any-hit sweep decides per sphere pair (the earlier shape) instead of per sphere
+#ifndef RT_OPT_ANY_JOINT
+#define RT_OPT_ANY_JOINT 0
+#endif
 #ifndef RT_OPT_JOINT_SKIP
 #define RT_OPT_JOINT_SKIP 0
 #endif
@@ -384,6 +388,7 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
+#if RT_OPT_ANY_JOINT
         if (wave_any_nonneg(fmaxf(roots_matter(p0), roots_matter(p1)))) {
             roots += 2;
             const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1);
@@ -392,15 +397,28 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
             first = first < cand ? first : cand;
             if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
         }
+#else
+        // a lane that already has its blocker asks for no more roots
+        if (__builtin_amdgcn_ballot_w64(first == n && p0.det >= 0.f) != 0ull) {
+            roots += 1;
+            const HitRoots h0 = hit_roots(p0);
+            if (first == n && h0.hit && h0.t < max_t) first = i;
+        }
+        if (__builtin_amdgcn_ballot_w64(first == n && p1.det >= 0.f) != 0ull) {
+            roots += 1;
+            const HitRoots h1 = hit_roots(p1);
+            if (first == n && h1.hit && h1.t < max_t) first = i + 1;
+        }
+        if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
+#endif
     }
 #endif
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
-        if (wave_any_nonneg(roots_matter(p0))) {
+        if (__builtin_amdgcn_ballot_w64(first == n && p0.det >= 0.f) != 0ull) {
             roots += 1;
             const HitRoots h0 = hit_roots(p0);
-            const uint32_t cand = (h0.hit && h0.t < max_t) ? i : n;
-            first = first < cand ? first : cand;
+            if (first == n && h0.hit && h0.t < max_t) first = i;
             if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
         }
     }
