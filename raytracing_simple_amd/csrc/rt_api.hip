@@ -53,7 +53,7 @@ struct rt_ctx {
     int mode = RT_MODE_PARITY;
     int regen_gate = 0;           // 0 = choose from the scene size
     int mat_lds_limit = 24 * 1024;
-    int coop_min = 64;
+    int coop_min = 12;
     int persist = 0;              // persistent-wavefront instances (tile queue + per-lane pixel hand-out)
     int n_cus = 256;
             // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)

@@ -1,7 +1,7 @@
 // rt_kernel_parity.hip -- strict-arithmetic instances of the path-trace kernel.
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
-//   [0] rt_trace_parity        shipped: small and medium scenes
-//   [4] rt_trace_parity_coop   shipped: scenes with >= 64 spheres (cooperative any-hit)
+//   [0] rt_trace_parity        shipped: small scenes
+//   [4] rt_trace_parity_coop   shipped: scenes with >= 12 spheres (cooperative any-hit)
 // the rest are A/B and diagnostic shapes of the same arithmetic (mode 100+k, tools/ab_bench.py).
 #pragma clang fp contract(off)
 #define RT_FAST 0

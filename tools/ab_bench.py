@@ -20,6 +20,9 @@ from raytracing_simple_amd import api, host, scenes  # noqa: E402
 CONFIGS = {
     "c2": (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 1920, 1080, 64),
     "c16": (lambda: scenes.demo_plus(16), 1920, 1080, 64),
+    "c9": (lambda: scenes.demo_plus(9), 1920, 1080, 64),
+    "c12": (lambda: scenes.demo_plus(12), 1920, 1080, 64),
+    "c32": (lambda: scenes.demo_plus(32), 1920, 1080, 64),
     "c3": (lambda: scenes.random_spheres(1024), 1920, 1080, 16),
     "c5": (lambda: scenes.mirror_box(64), 1920, 1080, 64),
     "c64": (lambda: scenes.random_spheres(64), 1920, 1080, 64),
