@@ -32,11 +32,28 @@ FLOP_PER_SPHERE_TEST = 20            # ray-sphere test
 BYTES_PER_PIXEL_PER_LAUNCH = 32      # seeds 8 R + 8 W, colour 12 W, pixel 4 W
 
 
+def host_cores():
+    """Cores this process may actually use: the smaller of the CPU count, the affinity mask and the
+    cgroup CPU quota (a one-GPU box of the pool shows 256 CPUs and grants 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(spheres, cam):
     """The oracle (CPU port of the reference kernel) on the host cores, same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     t0 = time.time()
     out = O.render(spheres, cam, W, H, SPP, threads=cores)
     dt = time.time() - t0
@@ -44,7 +61,8 @@ def cpu_baseline(spheres, cam):
     rays = st["samples"] + st["shadow_calls"]
     return {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "port",
             "sample": f"full workload: {W}x{H} x {SPP} spp, {rays} rays in {dt:.2f} s "
-                      f"({st['samples'] / dt / 1e6:.1f} Msample/s)",
+                      f"({st['samples'] / dt / 1e6:.1f} Msample/s) on {cores} threads "
+                      f"(host shows {os.cpu_count()} CPUs; cgroup quota / affinity grant {cores})",
             "ms_per_frame": round(dt * 1e3, 1)}, out
 
 
