@@ -245,13 +245,24 @@ RT_DEV float cl_sign(float x) {
     return r;
 }
 
-// .cl:143-169
-RT_DEV float next_random(uint32_t &s0, uint32_t &s1) {
+// .cl:143-169.  f lies in [2, 4) on a 2^-22 grid, so (f - 2) / 2 and f * 0.5 - 1 are both exact and
+// equal: one fused operation (written out: this translation unit never contracts by itself).
+RT_DEV uint32_t next_random_word(uint32_t &s0, uint32_t &s1) {
     s0 = 36969u * (s0 & 65535u) + (s0 >> 16);
     s1 = 18000u * (s1 & 65535u) + (s1 >> 16);
     uint32_t word = (s0 << 16) + s1;
-    float f = __uint_as_float((word & 0x007fffffu) | 0x40000000u);
-    return (f - 2.f) / 2.f;
+    return (word & 0x007fffffu) | 0x40000000u;
+}
+RT_DEV float next_random(uint32_t &s0, uint32_t &s1) {
+    return __builtin_fmaf(__uint_as_float(next_random_word(s0, s1)), 0.5f, -1.0f);
+}
+// GetRandom() - 0.5f (.cl:507-508): u lies on a 2^-23 grid in [0, 1), so u - 0.5 is exact too
+RT_DEV float next_random_centred(uint32_t &s0, uint32_t &s1) {
+    return __builtin_fmaf(__uint_as_float(next_random_word(s0, s1)), 0.5f, -1.5f);
+}
+// 1.f - 2.f * GetRandom() (.cl:204): 2u and 1 - 2u are exact (2^-22 grid in (-1, 1]) and equal 3 - f
+RT_DEV float next_random_z(uint32_t &s0, uint32_t &s1) {
+    return 3.0f - __uint_as_float(next_random_word(s0, s1));
 }
 
 // .cl:173-201.  g = {centre, radius^2}.  A negative discriminant makes sq NaN and every
@@ -430,10 +441,9 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
 // then gives its unit direction, its length and the numerator 4*pi*r^2*wi*wo of .cl:297.
 RT_DEV bool sample_light(float4 la, float4 lb, uint32_t &s0, uint32_t &s1, uint32_t &c_draws, V3 hp, V3 nl,
                          V3 &sd, float &len, float &numer) {
-    float u1 = next_random(s0, s1);
+    float zc = next_random_z(s0, s1);                                      // .cl:203-213: 1 - 2 u1
     float u2 = next_random(s0, s1);
     c_draws += 2;
-    float zc = 1.f - 2.f * u1;                                             // .cl:203-213
     float ring = rt_sqrt_unit(fmaxf(0.f, 1.f - zc * zc));
     float sphi, cphi;
 #if RT_FAST
@@ -746,8 +756,8 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 #endif
             RT_STAMP(0);
             // ---- camera ray, .cl:494-549 ----
-            float j1 = next_random(s0, s1) - 0.5f;
-            float j2 = next_random(s0, s1) - 0.5f;
+            float j1 = next_random_centred(s0, s1);
+            float j2 = next_random_centred(s0, s1);
             c_draws += 2;
             float kcx = ((float)x + j1) * inv_w - 0.5f;
             float kcy = ((float)y + j2) * inv_h - 0.5f;

@@ -41,3 +41,16 @@ def test_special_values():
     assert lib.orc_to_int(7.5) == 255
     assert lib.orc_to_int(-3.0) == 0
     assert lib.orc_to_int(float("nan")) == 0
+
+
+def test_rng_post_operations_fold_into_one_exact_operation():
+    """The kernel forms GetRandom() = (f - 2) / 2, GetRandom() - 0.5 and 1 - 2 * GetRandom()
+    (RayTracing_Kernel.cl:143-169, :507-508, :204) as fma(f, .5, -1), fma(f, .5, -1.5) and 3 - f.
+    All 2^23 values of f: the folded forms are the same binary32 numbers (every step is exact)."""
+    k = np.arange(1 << 23, dtype=np.uint32)
+    f = (k | np.uint32(0x40000000)).view(np.float32)
+    u = (f - np.float32(2)) / np.float32(2)
+    fma = lambda c: (f.astype(np.float64) * 0.5 + c).astype(np.float32)      # exact in binary64: one rounding
+    assert np.array_equal(fma(-1.0).view(np.uint32), u.view(np.uint32))
+    assert np.array_equal(fma(-1.5).view(np.uint32), (u - np.float32(0.5)).view(np.uint32))
+    assert np.array_equal((np.float32(3) - f).view(np.uint32), (np.float32(1) - np.float32(2) * u).view(np.uint32))

@@ -30,5 +30,8 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
         waves_samples = st["samples"] / 64.0
         for n, c in zip(NAMES, v):
             execs, lanes = c >> 32, c & 0xFFFFFFFF
-            if execs:
+            if n.endswith("roots"):
+                sweeps = (v[1] if n.startswith("closest") else v[4]) >> 32
+                print(f"  {n:18s} root halves {c:12d}  per sweep execution {c / max(sweeps, 1):6.2f} of {len(sph)} spheres")
+            elif execs:
                 print(f"  {n:18s} execs {execs:12d}  lanes/exec {lanes / execs:6.2f}  execs per 64 samples {execs / waves_samples:6.3f}")
