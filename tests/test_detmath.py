@@ -4,6 +4,7 @@ variants (this image); elsewhere the comparison is skipped, the HIP-vs-oracle te
 import platform
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
 import pytest
 
 import _oracle as O
