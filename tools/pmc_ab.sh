@@ -1,0 +1,21 @@
+#!/bin/bash
+# VALU instruction counts of kernel instances on one config: tools/pmc_ab.sh CONFIG MODES
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+CFG=${1:-c2}; MODES=${2:-0,108}
+OUT=$R/gpurun_out/pmc_ab
+rm -rf "$OUT"; mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/p" -- python3 $R/tools/pmc_modes.py $CFG $MODES > "$OUT/p.log" 2>&1 || { tail -5 "$OUT/p.log"; exit 1; }
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, os
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"].startswith("rt_trace"):
+            k = (r["Kernel_Name"], r["Counter_Name"])
+            acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
+    for k in sorted(acc):
+        print(f"{k[0]:28s} {k[1]:24s} {acc[k]:.6g}")
+PY
