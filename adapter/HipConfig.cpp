@@ -2,6 +2,7 @@
 // call for call; every rt_* failure becomes the reference's fprintf(stderr) + exit(-1).
 #include "HipConfig.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +24,9 @@ void HipConfig::die(const char* what) const {
 void HipConfig::allocateBuffer() {                       // OpenCLConfig.cpp:613-682
     pPixels = new unsigned[static_cast<size_t>(mWidth) * mHeight]();
     if (rt_create(&ctx, mWidth, mHeight) != RT_OK) die("Failed to create the HIP render context");
+    // the per-pass readback into pPixels then runs at the PCIe rate (optional; failure is not fatal)
+    (void)rt_pin_output(ctx, reinterpret_cast<uint32_t*>(pPixels), static_cast<size_t>(mWidth) * mHeight);
+    if (const char* v = getenv("RT_READBACK_MS")) readbackMs = atof(v);
 }
 
 void HipConfig::freeBuffer() {                           // OpenCLConfig.cpp:684-717
@@ -51,6 +55,19 @@ unsigned* HipConfig::getPixels() { return pPixels; }
 
 void HipConfig::setArguments() {}                        // OpenCLConfig.cpp:517-611
 
+// One pass.  The reference reads the frame back after EVERY pass (OpenCLConfig.cpp:498-512) although
+// the window only looks at it when it redraws (SetupGL.cpp:59-63, unsynchronised).  A pass takes
+// 0.05-0.12 ms on an MI355X and the 8.3 MB readback of a 1080p frame three times that, so the frame
+// is copied when it is due for display: on pass 0 and then every readbackMs (8 ms unless
+// RT_READBACK_MS says otherwise; 0 = after every pass, the reference's cadence).  The passes in
+// between are only queued (rt_render_async on the context's stream); the copy that is due waits for
+// them, which also bounds the queue to readbackMs of work.
 void HipConfig::execute() {                              // OpenCLConfig.cpp:407-515
-    if (rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), 1) != RT_OK) die("Failed to render a pass");
+    const auto now = std::chrono::steady_clock::now();
+    const bool due = mCurrentSample == 0 || readbackMs <= 0.0 ||
+                     std::chrono::duration<double, std::milli>(now - lastReadback).count() >= readbackMs;
+    const int rc = due ? rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), 1)
+                       : rt_render_async(ctx, 1, rt_stream(ctx));
+    if (rc != RT_OK) die("Failed to render a pass");
+    if (due) lastReadback = now;
 }

@@ -7,6 +7,7 @@
 #ifndef HIP_CONFIG_HPP
 #define HIP_CONFIG_HPP
 
+#include <chrono>
 #include <vector>
 
 #include "Camera.hpp"   // reference headers
@@ -27,7 +28,7 @@ public:
 
 private:
     void setArguments() override;   // nothing to bind: the context holds the arguments
-    void execute() override;        // one pass = rt_render_pass(ctx, pPixels, 1)
+    void execute() override;        // one pass = rt_render_pass(ctx, pPixels or NULL, 1)
     void allocateBuffer() override;
     void freeBuffer() override;
 
@@ -36,6 +37,8 @@ private:
     rt_ctx* ctx = nullptr;
     unsigned* pPixels = nullptr;    // stable for the life of the object (SetupGL.cpp:85 keeps it)
     Camera camera{};
+    double readbackMs = 8.0;        // copy the frame to pPixels when it is this old (0 = every pass)
+    std::chrono::steady_clock::time_point lastReadback{};
 };
 
 #endif

@@ -118,6 +118,13 @@ int rt_reset_async(rt_ctx *ctx, void *hip_stream);
  * a sharded one).  out_host may be NULL to skip the copy.  Blocking.                         */
 int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
 
+/* Page-lock the host buffer that rt_render_pass copies into (the host's `pPixels`,
+ * OpenCLConfig.cpp:618-621), so the per-pass readback of the reference's display loop
+ * (clEnqueueReadBuffer after every pass, OpenCLConfig.cpp:498-512) runs at the full PCIe rate
+ * instead of through a pageable staging copy.  `count` uint32 from `out_host` must stay valid
+ * and at the same address until rt_pin_output(ctx, NULL, 0) or rt_destroy.  Optional.        */
+int rt_pin_output(rt_ctx *ctx, uint32_t *out_host, size_t count);
+
 /* Same launch, asynchronous on `hip_stream` (a hipStream_t, NULL = default stream), no copy
  * and no synchronisation: the caller orders later work on that stream.                       */
 int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);

@@ -16,7 +16,7 @@ DIFF, SPEC, REFR = 0, 1, 2
 # every symbol include/rt_api.h declares (tests/test_abi.py checks the export table)
 SYMBOLS = ["rt_render", "rt_create", "rt_create_sharded", "rt_destroy", "rt_set_scene",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
-           "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream", "rt_local_rows", "rt_current_sample", "rt_read_colors",
+           "rt_pin_output", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream", "rt_local_rows", "rt_current_sample", "rt_read_colors",
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_compute_camera",
            "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_debug_eval"]
 
@@ -73,6 +73,7 @@ def load_library():
         "rt_render_async": (i32, [vp, i32, vp]),
         "rt_device_pixels": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "rt_set_pixel_buffer": (i32, [vp, vp, sz]),
+        "rt_pin_output": (i32, [vp, vp, sz]),
         "rt_stream": (vp, [vp]),
         "rt_local_rows": (i32, [vp]),
         "rt_current_sample": (i32, [vp]),
@@ -179,11 +180,23 @@ class RtContext:
         return self._lib.rt_current_sample(self._h)
 
     # --- rendering ----------------------------------------------------------------------
-    def render_pass(self, n_samples, copy=True):
-        """n_samples reference passes in one launch; returns the local pixel rows (uint32)."""
-        out = np.zeros(self.local_rows * self.w, np.uint32) if copy else None
-        _check(self._lib.rt_render_pass(self._h, _ptr(out) if copy else None, n_samples))
+    def render_pass(self, n_samples, copy=True, out=None):
+        """n_samples reference passes in one launch; returns the local pixel rows (uint32),
+        written into `out` when one is given (a C-contiguous uint32 array of that size)."""
+        if out is None:
+            out = np.zeros(self.local_rows * self.w, np.uint32) if copy else None
+        elif out.dtype != np.uint32 or out.size < self.local_rows * self.w or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint32 array of local_rows * w elements")
+        _check(self._lib.rt_render_pass(self._h, _ptr(out) if out is not None else None, n_samples))
         return out
+
+    def pin_output(self, out):
+        """Page-lock `out` (the array later passed to render_pass(out=...)) for full-rate readback;
+        None unpins.  The array must outlive the pin."""
+        if out is None:
+            _check(self._lib.rt_pin_output(self._h, None, 0))
+        else:
+            _check(self._lib.rt_pin_output(self._h, _ptr(out), out.size))
 
     def reset_async(self, stream=None):
         _check(self._lib.rt_reset_async(self._h, C.c_void_p(stream or 0)))

@@ -43,6 +43,7 @@ struct rt_ctx {
     float *d_colors = nullptr;
     uint32_t *d_pixels = nullptr;
     uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
+    void *pinned_out = nullptr;         // host buffer page-locked by rt_pin_output, or null
     unsigned long long *d_counters = nullptr;
     unsigned long long *d_stats = nullptr;      // rt::kStatReplicas x 8 partial work counters
     float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
@@ -226,6 +227,7 @@ void rt_destroy(rt_ctx *c) {
     if (!c) return;
     if (hipSetDevice(c->device) == hipSuccess) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->pinned_out) (void)hipHostUnregister(c->pinned_out);
         (void)hipFree(c->d_seeds);
         (void)hipFree(c->d_seeds0);
         (void)hipFree(c->d_colors);
@@ -359,6 +361,23 @@ int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
+    return RT_OK;
+}
+
+int rt_pin_output(rt_ctx *c, uint32_t *out_host, size_t count) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    if (c->pinned_out) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipHostUnregister(c->pinned_out);
+        c->pinned_out = nullptr;
+    }
+    if (!out_host) return RT_OK;
+    if (count < (size_t)c->local_rows * (size_t)c->w)
+        return fail(RT_ERR_ARG, "output buffer of %zu < %zu elements", count, (size_t)c->local_rows * (size_t)c->w);
+    HIP_TRY(hipHostRegister(out_host, count * sizeof(uint32_t), hipHostRegisterDefault));
+    c->pinned_out = out_host;
     return RT_OK;
 }
 

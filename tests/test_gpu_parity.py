@@ -206,6 +206,30 @@ def test_regeneration_gate_and_cooperative_any_hit_are_bit_invisible():
         _assert_same(got, want)
 
 
+def test_pinned_output_buffer_gives_the_same_frames():
+    """rt_pin_output page-locks the host buffer of the per-pass readback (the adapter's pPixels);
+    the progressive frames are the same as through a pageable buffer."""
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 200, 120)
+    sph = host.demo_scene()
+    want = []
+    with api.RtContext(200, 120) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        for _ in range(3):
+            want.append(ctx.render_pass(1))
+    buf = np.zeros(200 * 120, np.uint32)
+    with api.RtContext(200, 120) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.pin_output(buf)
+        for k in range(3):
+            got = ctx.render_pass(1, out=buf)
+            assert got is buf and np.array_equal(buf, want[k])
+        ctx.pin_output(None)
+        with pytest.raises(api.RtError):
+            ctx.pin_output(buf[:100])
+
+
 def test_render_into_caller_owned_device_buffer():
     import torch
     w, h, spp = 64, 40, 2

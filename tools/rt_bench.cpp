@@ -2,7 +2,7 @@
 // does (SimpleRT/src/Main.cpp:18-113) minus the GLUT window, with an image writer instead.
 //
 //   rt_bench <framework ID> <CPU/GPU (0/1)> <mem (0/1/2)> [scene.scn]
-//            [--w W] [--h H] [--spp N] [--passes-per-launch K] [--mode parity|fast]
+//            [--w W] [--h H] [--spp N] [--passes-per-launch K] [--pin] [--readback-ms T] [--mode parity|fast]
 //            [--no-doubling] [--out frame.ppm]
 //
 // The four positional arguments are the reference's; only framework ID 2 (the slot
@@ -41,7 +41,9 @@ static bool write_ppm(const std::string& path, const std::vector<uint32_t>& px, 
 }
 
 int main(int argc, char** argv) {
-    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY;   // SetupGL.cpp:32-33
+    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY;
+    bool pin = false;
+    double readback_ms = 0.0;   // > 0: copy the frame out only when the last copy is this old (the adapter's display cadence)   // SetupGL.cpp:32-33
     bool doubling = true;
     std::string out, scene_path;
     std::vector<const char*> pos;
@@ -52,6 +54,8 @@ int main(int argc, char** argv) {
         else if (a == "--h") h = atoi(next());
         else if (a == "--spp") spp = atoi(next());
         else if (a == "--passes-per-launch") per_launch = atoi(next());
+        else if (a == "--pin") pin = true;
+        else if (a == "--readback-ms") readback_ms = atof(next());
         else if (a == "--mode") mode = strcmp(next(), "fast") == 0 ? RT_MODE_FAST : RT_MODE_PARITY;
         else if (a == "--no-doubling") doubling = false;
         else if (a == "--out") out = next();
@@ -89,14 +93,24 @@ int main(int argc, char** argv) {
 
     std::vector<uint32_t> px(static_cast<size_t>(w) * h);
     if (per_launch <= 0) per_launch = spp;
+    if (pin && rt_pin_output(ctx, px.data(), px.size()) != RT_OK) return die("rt_pin_output");
     auto t0 = std::chrono::steady_clock::now();
+    auto last_copy = t0;
     double kernel_ms = 0.0;
     for (int done = 0; done < spp;) {
         int k = (spp - done < per_launch) ? spp - done : per_launch;
-        if (rt_render_pass(ctx, px.data(), k) != RT_OK) return die("rt_render_pass");
-        rt_stats st;
-        rt_get_stats(ctx, &st);
-        kernel_ms += st.last_kernel_ms;
+        const auto now = std::chrono::steady_clock::now();
+        const bool last = done + k >= spp;
+        const bool due = done == 0 || last || readback_ms <= 0.0 ||
+                         std::chrono::duration<double, std::milli>(now - last_copy).count() >= readback_ms;
+        if ((due ? rt_render_pass(ctx, px.data(), k) : rt_render_async(ctx, k, rt_stream(ctx))) != RT_OK)
+            return die("rt_render_pass");
+        if (due) {                       // (launches queued between two copies are not timed one by one)
+            last_copy = now;
+            rt_stats st;
+            rt_get_stats(ctx, &st);
+            kernel_ms += st.last_kernel_ms;
+        }
         done += k;
     }
     double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
