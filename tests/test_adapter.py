@@ -52,5 +52,10 @@ def test_cpp_host_writes_the_golden_frame(tmp_path, golden_dir):
     subprocess.run([exe, "2", "1", "0", "--w", "96", "--h", "64", "--spp", "5", "--out", str(out3)],
                    check=True, capture_output=True)
     assert out2.read_bytes() == out3.read_bytes()
+    # the adapter's display cadence: page-locked frame, copied when due, passes queued in between
+    out4 = tmp_path / "c1d.ppm"
+    subprocess.run([exe, "2", "1", "0", "--w", "96", "--h", "64", "--spp", "5", "--passes-per-launch", "1",
+                    "--pin", "--readback-ms", "1000", "--out", str(out4)], check=True, capture_output=True)
+    assert out4.read_bytes() == out3.read_bytes()
     bad = subprocess.run([exe, "0", "1", "0"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Unsupported Framework Type" in bad.stderr
