@@ -66,6 +66,7 @@ void HipConfig::execute() {                              // OpenCLConfig.cpp:407
     const auto now = std::chrono::steady_clock::now();
     const bool due = mCurrentSample == 0 || readbackMs <= 0.0 ||
                      std::chrono::duration<double, std::milli>(now - lastReadback).count() >= readbackMs;
+    rt_set_pixel_write(ctx, due ? 1 : 0);       // passes nobody looks at skip the gamma + pixel store
     const int rc = due ? rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), 1)
                        : rt_render_async(ctx, 1, rt_stream(ctx));
     if (rc != RT_OK) die("Failed to render a pass");

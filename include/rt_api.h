@@ -125,6 +125,12 @@ int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
  * and at the same address until rt_pin_output(ctx, NULL, 0) or rt_destroy.  Optional.        */
 int rt_pin_output(rt_ctx *ctx, uint32_t *out_host, size_t count);
 
+/* enable = 0: later launches advance seeds and the running average but leave the packed pixel
+ * buffer alone (no toInt, .cl:34,594-596, and no pixel store) -- for passes whose frame nobody
+ * will look at; the next launch with enable = 1 writes every pixel of its frame from the running
+ * average, so nothing is lost.  Default 1.                                                    */
+int rt_set_pixel_write(rt_ctx *ctx, int enable);
+
 /* Same launch, asynchronous on `hip_stream` (a hipStream_t, NULL = default stream), no copy
  * and no synchronisation: the caller orders later work on that stream.                       */
 int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);

@@ -16,7 +16,7 @@ DIFF, SPEC, REFR = 0, 1, 2
 # every symbol include/rt_api.h declares (tests/test_abi.py checks the export table)
 SYMBOLS = ["rt_render", "rt_create", "rt_create_sharded", "rt_destroy", "rt_set_scene",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
-           "rt_pin_output", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream", "rt_local_rows", "rt_current_sample", "rt_read_colors",
+           "rt_pin_output", "rt_set_pixel_write", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream", "rt_local_rows", "rt_current_sample", "rt_read_colors",
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_compute_camera",
            "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_debug_eval"]
 
@@ -74,6 +74,7 @@ def load_library():
         "rt_device_pixels": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "rt_set_pixel_buffer": (i32, [vp, vp, sz]),
         "rt_pin_output": (i32, [vp, vp, sz]),
+        "rt_set_pixel_write": (i32, [vp, i32]),
         "rt_stream": (vp, [vp]),
         "rt_local_rows": (i32, [vp]),
         "rt_current_sample": (i32, [vp]),
@@ -189,6 +190,9 @@ class RtContext:
             raise ValueError("out must be a C-contiguous uint32 array of local_rows * w elements")
         _check(self._lib.rt_render_pass(self._h, _ptr(out) if out is not None else None, n_samples))
         return out
+
+    def set_pixel_write(self, enable):
+        _check(self._lib.rt_set_pixel_write(self._h, 1 if enable else 0))
 
     def pin_output(self, out):
         """Page-lock `out` (the array later passed to render_pass(out=...)) for full-rate readback;

@@ -44,6 +44,7 @@ struct rt_ctx {
     uint32_t *d_pixels = nullptr;
     uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
     void *pinned_out = nullptr;         // host buffer page-locked by rt_pin_output, or null
+    int pixel_write = 1;                // rt_set_pixel_write
     unsigned long long *d_counters = nullptr;
     unsigned long long *d_stats = nullptr;      // rt::kStatReplicas x 8 partial work counters
     float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
@@ -108,6 +109,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.nranks = c->nranks;
     p.tile_rows = c->tile_rows;
     p.local_rows = c->local_rows;
+    p.skip_pixels = c->pixel_write ? 0 : 1;
     p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     // materials ride along in LDS only while that keeps at least 6 workgroups per CU resident
@@ -361,6 +363,12 @@ int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
+    return RT_OK;
+}
+
+int rt_set_pixel_write(rt_ctx *c, int enable) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    c->pixel_write = enable ? 1 : 0;
     return RT_OK;
 }
 

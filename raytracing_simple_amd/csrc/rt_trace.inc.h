@@ -687,8 +687,9 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
                     P.colors[3 * ci] = acc.x;
                     P.colors[3 * ci + 1] = acc.y;
                     P.colors[3 * ci + 2] = acc.z;
-                    P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =
-                        (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+                    if (!P.skip_pixels)
+                        P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =
+                            (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
                     P.seeds[2 * gid] = s0;
                     P.seeds[2 * gid + 1] = s1;
                     c_samples += (uint32_t)P.n_samples;
@@ -985,8 +986,9 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         P.colors[3 * ci] = acc.x;
         P.colors[3 * ci + 1] = acc.y;
         P.colors[3 * ci + 2] = acc.z;
-        P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =                  // .cl:594-596
-            (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+        if (!P.skip_pixels)                                                // (wave-uniform)
+            P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =              // .cl:594-596
+                (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         P.seeds[2 * gid] = s0;                                             // .cl:598-599
         P.seeds[2 * gid + 1] = s1;
     }

@@ -230,6 +230,25 @@ def test_pinned_output_buffer_gives_the_same_frames():
             ctx.pin_output(buf[:100])
 
 
+def test_passes_without_pixel_write_lose_nothing():
+    """rt_set_pixel_write(ctx, 0): the pass advances seeds and running average only; the next
+    pass with the switch on writes the frame that plain passes would have produced."""
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64)
+    sph = host.demo_scene()
+    want = _gpu(sph, cam, 96, 64, 3)
+    with api.RtContext(96, 64) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        first = ctx.render_pass(1)
+        ctx.set_pixel_write(False)
+        assert np.array_equal(ctx.render_pass(1), first)          # pixel buffer untouched
+        ctx.set_pixel_write(True)
+        px = ctx.render_pass(1)
+        assert np.array_equal(px, want["pixels"])
+        assert np.array_equal(ctx.read_colors().view(np.uint32), want["colors"].view(np.uint32))
+        assert np.array_equal(ctx.read_seeds(), want["seeds"])
+
+
 def test_render_into_caller_owned_device_buffer():
     import torch
     w, h, spp = 64, 40, 2

@@ -103,6 +103,7 @@ int main(int argc, char** argv) {
         const bool last = done + k >= spp;
         const bool due = done == 0 || last || readback_ms <= 0.0 ||
                          std::chrono::duration<double, std::milli>(now - last_copy).count() >= readback_ms;
+        if (readback_ms > 0.0) rt_set_pixel_write(ctx, due ? 1 : 0);
         if ((due ? rt_render_pass(ctx, px.data(), k) : rt_render_async(ctx, k, rt_stream(ctx))) != RT_OK)
             return die("rt_render_pass");
         if (due) {                       // (launches queued between two copies are not timed one by one)
