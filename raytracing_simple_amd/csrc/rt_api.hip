@@ -91,6 +91,8 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     if (!c->have_scene || !c->have_cam)
         return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
     if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
+    if (n_samples > 0x7fffffff - c->current_sample)
+        return fail(RT_ERR_ARG, "pass counter would overflow (%d + %d)", c->current_sample, n_samples);
     if (n_samples == 0 || c->local_rows == 0) return RT_OK;
 
     rt::LaunchParams p{};

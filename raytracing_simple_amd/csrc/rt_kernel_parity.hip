@@ -61,7 +61,7 @@
 #define RT_NS parity_r0              /* A/B: the shipped shape without its newest change */
 #define RT_KERNEL_NAME rt_trace_parity_r0
 #define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_ANY_JOINT 1
+#define RT_OPT_GLOSS_ID 0
 #define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"

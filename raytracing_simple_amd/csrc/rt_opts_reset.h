@@ -16,3 +16,4 @@
 #undef RT_OPT_SHORT_ROOTS
 #undef RT_OPT_JOINT_SKIP
 #undef RT_OPT_ANY_JOINT
+#undef RT_OPT_GLOSS_ID

@@ -71,6 +71,10 @@
 #define RT_OPT_SHORT_ROOTS 1
 #endif
 // RT_OPT_ANY_JOINT: the any-hit sweep decides per sphere pair (the earlier shape) instead of per sphere
+// RT_OPT_GLOSS_ID: the mirror/glass branch reuses n.d of the hit record instead of three more dot products
+#ifndef RT_OPT_GLOSS_ID
+#define RT_OPT_GLOSS_ID 1
+#endif
 #ifndef RT_OPT_ANY_JOINT
 #define RT_OPT_ANY_JOINT 0
 #endif
@@ -787,6 +791,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         bool is_diff = false, is_gloss = false;   // what the hit asks for next
         // the hit record: written by the hit branch, read only where is_diff / is_gloss say it was
         V3 hp, nrm, nl, col;
+        float dp;
         int refl;
         if (!(t < 1e20f)) {
             path_done = true;                                              // miss, .cl:327-330
@@ -808,7 +813,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 
             hp = add(o, scale(d, t));                                      // .cl:338-340
             nrm = unit(sub(hp, mk(ge.x, ge.y, ge.z)));                     // .cl:345-347
-            float dp = dot(nrm, d);
+            dp = dot(nrm, d);
             nl = scale(nrm, -1.f * cl_sign(dp));                           // .cl:354-355
 
             if (!((em.x == 0.f) && (em.z == 0.f))) {                       // .cl:358-368
@@ -925,16 +930,30 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         } else if (is_gloss) {
             // reflection direction shared by SPEC and REFR, .cl:416-419 / 428-431
             RT_STAMP(7);
-            V3 rfl = sub(d, scale(nrm, 2.f * dot(nrm, d)));
+#if RT_OPT_GLOSS_ID
+            // n.d is the dp of the hit record; nl = n * m with m = -sign(dp), and for m = +-1 every
+            // product and sum of (n.nl) and (d.nl) is the sign-flipped twin of the one in (n.n) and
+            // (n.d) (rounding is sign-symmetric), so n.nl > 0 <=> dp < 0 and d.nl = m * dp = -|dp|.
+            // dp = +-0 gives zeros of either sign, which the uses below do not tell apart; NaN stays NaN.
+            const float n_dot_d = dp;
+#else
+            const float n_dot_d = dot(nrm, d);
+#endif
+            V3 rfl = sub(d, scale(nrm, 2.f * n_dot_d));
             after_specular = true;
             if (refl == RT_SPEC) {                                         // .cl:413-424
                 thr = mul(thr, col);
                 d = rfl;
             } else {                                                       // .cl:425-489
-                bool into = dot(nrm, nl) > 0.f;
+#if RT_OPT_GLOSS_ID
+                const bool into = dp < 0.f;
+                const float ddn = -fabsf(dp);
+#else
+                const bool into = dot(nrm, nl) > 0.f;
+                const float ddn = dot(d, nl);
+#endif
                 const float nc = 1.f, nt = 1.52f;
                 float nnt = into ? nc / nt : nt / nc;
-                float ddn = dot(d, nl);
                 float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
                 if (cos2t < 0.f) {                                         // total internal reflection
                     thr = mul(thr, col);
