@@ -112,6 +112,8 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.tile_rows = c->tile_rows;
     p.local_rows = c->local_rows;
     p.skip_pixels = c->pixel_write ? 0 : 1;
+    p.inv_w = 1.f / (float)c->w;          // correctly rounded on the host as on the device (-ffp-contract=off, IEEE division)
+    p.inv_h = 1.f / (float)c->h;
     p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     // materials ride along in LDS only while that keeps at least 6 workgroups per CU resident

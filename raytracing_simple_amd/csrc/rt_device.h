@@ -48,6 +48,7 @@ struct LaunchParams {
     int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
     int n_tiles, tiles_x;   // persistent instances: 8x8 pixel tiles of this rank's rows, and tiles per row
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
+    float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
 };
 

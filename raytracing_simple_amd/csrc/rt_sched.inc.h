@@ -85,8 +85,8 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES)
         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
     }
 
-    const float inv_w = rt_rcp((float)P.w);
-    const float inv_h = rt_rcp((float)P.h);
+    const float inv_w = P.inv_w;
+    const float inv_h = P.inv_h;
     const V3 cam_o = mk(P.cam.orig.x, P.cam.orig.y, P.cam.orig.z);
     const V3 cam_d = mk(P.cam.dir.x, P.cam.dir.y, P.cam.dir.z);
     const V3 cam_x = mk(P.cam.x.x, P.cam.x.y, P.cam.x.z);
