@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="independent frames kept in flight per rank (0 = 2 for N<=2, 3 for N<=4, 4 beyond)")
+                    help="independent frames kept in flight per rank (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
     args = ap.parse_args()
 
     import torch                       # plumbing: streams, events, torch.distributed (RCCL)
@@ -115,7 +115,7 @@ def main():
     # wavefronts for 6144 wavefront slots) cannot fill a GPU at all.  F frames in flight fill
     # those holes.  The single-stream figure is measured too (N = 1) and is the one the roofline
     # and the rocprof summaries refer to.
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world <= 2 else (3 if world <= 4 else 4))
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world <= 2 else (3 if world <= 4 else 6))
     ctxs = []
     for _ in range(F):
         c = api.RtContext(W, H, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
