@@ -45,9 +45,11 @@ class FrameGatherer:
         self._work = [None] * slots
         self._parts = None
         self._full = None
+        self.tile_rows = tile_rows
         if rank == dst:
-            self._parts = [[torch.zeros((self.pad, w), dtype=torch.int32, device=device)
-                            for _ in range(nranks)] for _ in range(slots)]
+            # one contiguous [nranks, pad, w] block per slot; the collective writes into its rows
+            self._stacked = [torch.zeros((nranks, self.pad, w), dtype=torch.int32, device=device) for _ in range(slots)]
+            self._parts = [list(st.unbind(0)) for st in self._stacked]
             self._full = [torch.zeros((h, w), dtype=torch.int32, device=device) for _ in range(slots)]
 
     # single-slot conveniences (tests, simple callers)
@@ -86,11 +88,32 @@ class FrameGatherer:
         return self._full[k] if self._full else None
 
     def _assemble(self, k):
+        """De-interleave the gathered blocks into the image with at most three strided copies
+        (tile t of the image is local tile t // n of rank t % n): all complete groups of n
+        full-height tiles at once, the last incomplete group, the short tile at the bottom."""
         if self.rank != self.dst:
             return None
-        stacked = torch.cat(self._parts[k], dim=0)
-        self._full[k].index_copy_(0, self.dst_idx, stacked.index_select(0, self.src_idx))
-        return self._full[k]
+        n, tr, w, h = self.nranks, self.tile_rows, self.w, self.h
+        st, full = self._stacked[k], self._full[k]
+        t_full = h // tr                     # full-height tiles
+        g = t_full // n                      # complete groups of n tiles
+        if g:
+            full[: g * n * tr].view(g, n, tr * w).copy_(st[:, : g * tr].reshape(n, g, tr * w).transpose(0, 1))
+        r = t_full - g * n                   # full-height tiles of the last, incomplete group: ranks 0..r-1
+        if r:
+            full[g * n * tr:(g * n + r) * tr].view(r, tr * w).copy_(st[:r, g * tr:(g + 1) * tr].reshape(r, tr * w))
+        short = h - t_full * tr              # rows of the short tile, owned by rank t_full % n
+        if short:
+            owner, j = t_full % n, t_full // n
+            full[t_full * tr:].copy_(st[owner, j * tr: j * tr + short])
+        return full
+
+    def _assemble_by_index(self, k):
+        """The same permutation through the row index tables (kept as the check of _assemble)."""
+        stacked = self._stacked[k].view(self.nranks * self.pad, self.w)
+        out = torch.zeros_like(self._full[k])
+        out.index_copy_(0, self.dst_idx, stacked.index_select(0, self.src_idx))
+        return out
 
 
 def assemble_numpy(parts, h, w, nranks, tile_rows):

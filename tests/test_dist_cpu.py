@@ -84,3 +84,20 @@ def test_assemble_numpy():
     full = np.arange(h * w, dtype=np.uint32).reshape(h, w)
     parts = [full[api.local_rows_of(h, r, 3, 8)] for r in range(3)]
     assert np.array_equal(rdist.assemble_numpy(parts, h, w, 3, 8), full.reshape(-1))
+
+
+@pytest.mark.parametrize("h,w,n,tr", [(1080, 16, 8, 8), (1080, 16, 4, 16), (135, 7, 8, 8), (50, 33, 3, 8), (17, 5, 2, 16),
+                                       (8, 8, 2, 8), (7, 3, 4, 8), (2160, 4, 8, 8), (100, 9, 7, 8), (64, 5, 1, 8)])
+def test_strided_reassembly_equals_the_index_permutation(h, w, n, tr):
+    """FrameGatherer._assemble (at most three strided copies) against the row-index permutation and
+    against the image itself, with the blocks filled as the ranks would send them (no process group)."""
+    full = (np.arange(h * w, dtype=np.int64) * 2654435761 % (1 << 31)).astype(np.int32).reshape(h, w)
+    g = rdist.FrameGatherer(h, w, 0, n, tr, "cpu", slots=2)
+    for k in (0, 1):
+        g._stacked[k].fill_(-1)
+        for r in range(n):
+            rows = api.local_rows_of(h, r, n, tr)
+            g._stacked[k][r, : len(rows)] = torch.from_numpy(full[rows] + k)
+        out = g._assemble(k)
+        assert np.array_equal(out.numpy(), full + k)
+        assert torch.equal(out, g._assemble_by_index(k))
