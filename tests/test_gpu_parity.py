@@ -111,6 +111,14 @@ def test_ragged_sizes(w, h):
     _assert_same(_gpu(sph, cam, w, h, 3), O.render(sph, cam, w, h, 3))
 
 
+@pytest.mark.parametrize("w,h", [(8192, 9), (5, 4100), (16384, 1)])
+def test_extreme_aspect_ratios(w, h):
+    """Very wide and very tall images: pixel/tile arithmetic at the ends of its ranges."""
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    _assert_same(_gpu(sph, cam, w, h, 2), O.render(sph, cam, w, h, 2))
+
+
 def test_empty_scene_and_zero_samples():
     cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 40, 24)
     empty = np.zeros(0, api.SPHERE_DT)
