@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_api.h"
@@ -57,30 +58,66 @@ void rt_compute_camera(rt_camera *cam, int w, int h) {
 // generator x[i] = x[i-31] + x[i-3] (mod 2^32) over a 31-word table that is filled by the
 // Lehmer generator 16807 * s mod (2^31 - 1), run for 310 steps before the first output;
 // each output is x[i] >> 1.
-void rt_default_seeds(uint32_t *seeds, size_t count) {
-    if (!seeds) return;
+// The stream is a pure function of the index, so its head is generated once per process and kept
+// (up to kSeedCacheWords; a 1080p context needs 4.1 M words): creating a context, which
+// rt_render() does on every call, then costs a copy instead of 4 million generator steps.
+namespace {
+struct RandState {
     uint32_t tab[31];
-    int64_t word = 1;
-    tab[0] = 1;
-    for (int i = 1; i < 31; ++i) {
-        word = (16807 * word) % 2147483647;
-        if (word < 0) word += 2147483647;
-        tab[i] = static_cast<uint32_t>(word);
+    int f, r;
+    void init() {
+        int64_t word = 1;
+        tab[0] = 1;
+        for (int i = 1; i < 31; ++i) {
+            word = (16807 * word) % 2147483647;
+            if (word < 0) word += 2147483647;
+            tab[i] = static_cast<uint32_t>(word);
+        }
+        // front = index of x[i-31]'s slot, rear = x[i-3]'s; glibc starts them 3 apart
+        f = 3;
+        r = 0;
+        for (int i = 0; i < 310; ++i) (void)step();
     }
-    // front = index of x[i-31]'s slot, rear = x[i-3]'s; glibc starts them 3 apart
-    int f = 3, r = 0;
-    auto step = [&]() -> uint32_t {
+    uint32_t step() {
         tab[f] += tab[r];
         const uint32_t v = tab[f] >> 1;
         f = (f + 1 == 31) ? 0 : f + 1;
         r = (r + 1 == 31) ? 0 : r + 1;
         return v;
-    };
-    for (int i = 0; i < 310; ++i) (void)step();
-    for (size_t i = 0; i < count; ++i) {
-        uint32_t v = step();
-        seeds[i] = v < 2 ? 2u : v;                                    // OpenCLConfig.cpp:678-679
     }
+    uint32_t seed() {                                                 // OpenCLConfig.cpp:678-679
+        const uint32_t v = step();
+        return v < 2 ? 2u : v;
+    }
+};
+constexpr size_t kSeedCacheWords = size_t(1) << 23;                   // 32 MiB
+std::mutex g_seed_mutex;
+std::vector<uint32_t> g_seed_head;                                    // seeds [0, size)
+RandState g_seed_state;                                               // generator after g_seed_head.size() outputs
+bool g_seed_started = false;
+}  // namespace
+
+void rt_default_seeds(uint32_t *seeds, size_t count) {
+    if (!seeds) return;
+    RandState tail;
+    size_t have;
+    {
+        std::lock_guard<std::mutex> lock(g_seed_mutex);
+        if (!g_seed_started) {
+            g_seed_state.init();
+            g_seed_started = true;
+        }
+        const size_t want = count < kSeedCacheWords ? count : kSeedCacheWords;
+        if (g_seed_head.size() < want) {
+            const size_t old = g_seed_head.size();
+            g_seed_head.resize(want);
+            for (size_t i = old; i < want; ++i) g_seed_head[i] = g_seed_state.seed();
+        }
+        have = count < g_seed_head.size() ? count : g_seed_head.size();
+        memcpy(seeds, g_seed_head.data(), have * sizeof(uint32_t));
+        tail = g_seed_state;                                          // continues at g_seed_head.size()
+    }
+    for (size_t i = have; i < count; ++i) seeds[i] = tail.seed();
 }
 
 int rt_demo_scene(rt_sphere *out, uint32_t cap) {

@@ -62,6 +62,14 @@ def test_default_seeds_equal_oracle_and_pins(golden_dir):
     mine = host.default_seeds(2 * 64 * 64)
     assert np.array_equal(mine, pins["seeds_first_8192"])
     assert np.array_equal(host.default_seeds(2 * 800 * 600), O.seeds(800, 600))
+    # the library keeps the head of the stream per process (2^23 words): shorter requests, repeated
+    # requests and requests that run past the kept head all return the same stream
+    assert O.fnv(host.default_seeds(2 * 1920 * 1080)) == str(pins["fnv_seeds_1920x1080"])
+    long = host.default_seeds((1 << 23) + 4096)
+    want = O.seeds(2100, 2000)[: (1 << 23) + 4096]              # the oracle's own generator, 8.4 M words
+    assert np.array_equal(long, want)
+    assert np.array_equal(host.default_seeds(1000), want[:1000])
+    assert np.array_equal(host.default_seeds((1 << 23) + 4096), want)
 
 
 def test_compute_camera_equals_oracle_and_pins(golden_dir):
