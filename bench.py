@@ -50,7 +50,10 @@ def host_cores():
 
 
 def cpu_baseline(spheres, cam):
-    """The oracle (CPU port of the reference kernel) on the host cores, same workload."""
+    """The reference's CPU path on the host cores, same workload, same run: the reference's own
+    kernel compiled as host C++ (oracle/_ref, kind "reference") when that build travelled with the
+    snapshot, and the oracle (the CPU restatement, kind "port") -- the headline is the reference
+    build when it is there.  Both are checkers: neither is part of the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     cores = host_cores()
@@ -59,11 +62,24 @@ def cpu_baseline(spheres, cam):
     dt = time.time() - t0
     st = out["stats"]
     rays = st["samples"] + st["shadow_calls"]
-    return {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "port",
+    where = f"on {cores} threads (host shows {os.cpu_count()} CPUs; cgroup quota / affinity grant {cores})"
+    port = {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "port",
             "sample": f"full workload: {W}x{H} x {SPP} spp, {rays} rays in {dt:.2f} s "
-                      f"({st['samples'] / dt / 1e6:.1f} Msample/s) on {cores} threads "
-                      f"(host shows {os.cpu_count()} CPUs; cgroup quota / affinity grant {cores})",
-            "ms_per_frame": round(dt * 1e3, 1)}, out
+                      f"({st['samples'] / dt / 1e6:.1f} Msample/s) {where}",
+            "ms_per_frame": round(dt * 1e3, 1)}
+    if not O.ref_available():
+        return port, out
+    import numpy as np
+    t0 = time.time()
+    ref = O.ref_render_mt(spheres, cam, W, H, SPP, cores)
+    dt = time.time() - t0
+    base = {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "reference",
+            "sample": f"the reference's kernel source compiled as host C++ (oracle/_ref), full workload: {W}x{H} x {SPP} "
+                      f"passes, {rays} rays in {dt:.2f} s {where}",
+            "ms_per_frame": round(dt * 1e3, 1),
+            "equals_port_bit_exact": bool(np.array_equal(ref["pixels"], out["pixels"])),
+            "port": {k: port[k] for k in ("value", "ms_per_frame", "kind")}}
+    return base, out
 
 
 def main():

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "Camera.hpp"
@@ -88,6 +89,29 @@ void ref_render_pass(float* colors, unsigned* seeds, const void* spheres44, unsi
         k::RayTracing((k::Vec*)colors, seeds, (k::Sphere*)spheres44, (k::Camera*)cam15, n, w, h,
                       current_sample, pixels);
     }
+}
+
+// `n_passes` launches on `threads` host threads.  Work-items are independent (own seed pair, own
+// colour and pixel slot), so each thread runs all passes over its slice of the 1-D range; the
+// buffers end up exactly as after n_passes calls of ref_render_pass.  Used by bench.py's
+// cpu_baseline leg (kind "reference") on the GPU box's host cores.
+void ref_render_passes_mt(float* colors, unsigned* seeds, const void* spheres44, unsigned n,
+                          const float* cam15, int w, int h, int first_sample, int n_passes,
+                          int* pixels, int threads) {
+    if (threads < 1) threads = 1;
+    const long total = (long)w * h;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const long lo = total * t / threads, hi = total * (t + 1) / threads;
+        pool.emplace_back([=]() {
+            for (int s = first_sample; s < first_sample + n_passes; ++s)
+                for (long gid = lo; gid < hi; ++gid) {
+                    k::g_gid = (int)gid;
+                    k::RayTracing((k::Vec*)colors, seeds, (k::Sphere*)spheres44, (k::Camera*)cam15, n, w, h, s, pixels);
+                }
+        });
+    }
+    for (auto& th : pool) th.join();
 }
 
 float ref_get_random(unsigned* s0, unsigned* s1) { return k::GetRandom(s0, s1); }

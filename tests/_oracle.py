@@ -165,6 +165,19 @@ def ref_render(spheres, cam, w, h, spp):
     return {"pixels": pix, "colors": colors, "seeds": sd}
 
 
+def ref_render_mt(spheres, cam, w, h, spp, threads):
+    """The reference kernel on `threads` host threads (same buffers as ref_render)."""
+    lib = reference()
+    spheres = np.ascontiguousarray(spheres)
+    sd = np.zeros(2 * w * h, np.uint32)
+    lib.ref_seeds_init(_ptr(sd), w, h)
+    colors = np.zeros(3 * w * h, np.float32)
+    pix = np.zeros(w * h, np.uint32)
+    lib.ref_render_passes_mt(_ptr(colors), _ptr(sd), _ptr(spheres), C.c_uint(len(spheres)), _ptr(cam), w, h, 0, spp,
+                             _ptr(pix), threads)
+    return {"pixels": pix, "colors": colors, "seeds": sd}
+
+
 def ref_read_scene(path, cap=8192):
     lib = reference()
     buf = np.zeros(cap, SPHERE_DT)

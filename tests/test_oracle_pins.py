@@ -123,3 +123,16 @@ def test_oracle_equals_reference_build_both_backends():
         assert np.array_equal(got["pixels"], want["pixels"])
         assert np.array_equal(got["colors"].view(np.uint32), want["colors"].view(np.uint32))
         assert np.array_equal(got["seeds"], want["seeds"])
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="reference build exists only where oracle/_ref was built")
+def test_threaded_reference_leg_equals_the_sequential_launches():
+    """bench.py's cpu_baseline (kind "reference") runs the reference kernel on several host threads,
+    each doing all passes over its slice of work-items; the buffers equal launch-by-launch order."""
+    sph = O.demo_spheres()
+    w, h, spp = 96, 50, 5
+    cam = O.camera((20.0, 100.0, 120.0), (0.0, 25.0, 0.0), w, h)
+    want = O.ref_render(sph, cam, w, h, spp)
+    got = O.ref_render_mt(sph, cam, w, h, spp, 5)
+    for key in ("pixels", "colors", "seeds"):
+        assert np.array_equal(got[key].view(np.uint32), want[key].view(np.uint32))
