@@ -85,6 +85,11 @@ def ref_available():
     return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libref.so"))
 
 
+def ref_tree_available():
+    """The reference checkout itself (scene files, headers): only in the build container."""
+    return ref_available() and os.path.isdir(REF_ROOT)
+
+
 def reference():
     """The reference's kernel + host sources compiled in place (only in the build container)."""
     global _ref

@@ -119,7 +119,7 @@ def test_scene_reader_errors(tmp_path):
     assert len(got) == 0
 
 
-@pytest.mark.skipif(not O.ref_available(), reason="reference loader exists only in the build container")
+@pytest.mark.skipif(not O.ref_tree_available(), reason="reference loader exists only in the build container")
 def test_scene_reader_equals_reference_loader_on_shipped_scenes():
     d = os.path.join(O.REF_ROOT, "SimpleRT", "Scene")
     for name in sorted(os.listdir(d)):

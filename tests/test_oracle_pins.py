@@ -110,7 +110,7 @@ def test_demo_scene_literal_equals_reference_scene(golden_dir):
     assert sph.tobytes() == O.demo_spheres().tobytes()
 
 
-@pytest.mark.skipif(not O.ref_available(), reason="reference build exists only in the build container")
+@pytest.mark.skipif(not O.ref_tree_available(), reason="reference build exists only in the build container")
 def test_oracle_equals_reference_build_both_backends():
     """Restatement vs the reference kernel compiled in place, on a scene not in the fixtures'
     sizes; back-end 1 (host libm) and back-end 0 (restated libm) must both be bit-equal."""
