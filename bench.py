@@ -151,13 +151,13 @@ def main():
         gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=2 * F)
     frame_no = [0]
 
-    def step(in_flight, ev=None):
+    def step(in_flight, ev=None, do_gather=True):
         k = frame_no[0]
         frame_no[0] += 1
         c = ctxs[k % in_flight]
         st = main_stream if in_flight == 1 else side_streams[k % in_flight]
         with torch.cuda.stream(st):
-            if gather is not None:
+            if gather is not None and do_gather:
                 gather.wait(k)                                  # slot free again (its last gather)
                 buf = gather.local_slot(k)
                 c.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
@@ -167,7 +167,7 @@ def main():
             c.render_async(SPP, st.cuda_stream)
             if ev:
                 ev[1].record(st)
-            if gather is not None:
+            if gather is not None and do_gather:
                 gather.gather(k, async_op=True)                 # queued behind the launch, not waited for
         return c
 
@@ -182,12 +182,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(in_flight, steps, warmup, with_events=True):
+    def timed_region(in_flight, steps, warmup, with_events=True, do_gather=True):
         """W untimed + exactly `steps` timed frames; barrier + synchronize on both sides.
         Per-launch HIP events only where asked: an event pair around every launch costs the
         overlapped region its overlap (measured), and a per-launch duration means little there."""
         for _ in range(warmup):
-            step(in_flight)
+            step(in_flight, None, do_gather)
         drain()
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(steps)] if with_events else None
@@ -195,7 +195,7 @@ def main():
         t0 = time.perf_counter()
         last = None
         for k in range(steps):
-            last = step(in_flight, events[k] if events else None)
+            last = step(in_flight, events[k] if events else None, do_gather)
         drain()                                             # every frame gathered and assembled
         sync()
         elapsed = time.perf_counter() - t0
@@ -206,10 +206,17 @@ def main():
     if world == 1:
         el1, k1, last1 = timed_region(1, args.steps, args.warmup)
         single = {"elapsed": el1, "kernel_ms": k1, "ctx": last1}
+    else:
+        # per-launch duration of this rank's shard for the roofline object: a few launches one at a
+        # time, no gather, outside the headline's timed region
+        _, k1, _ = timed_region(1, min(args.steps, 8), 1, with_events=True, do_gather=False)
+        shard_kernel_ms = k1
     if F == 1 and single is not None:
         elapsed, kernel_ms, last_ctx = single["elapsed"], single["kernel_ms"], single["ctx"]
     else:
-        elapsed, kernel_ms, last_ctx = timed_region(F, args.steps, args.warmup, with_events=(world > 1 and F == 1))
+        elapsed, kernel_ms, last_ctx = timed_region(F, args.steps, args.warmup, with_events=False)
+        if world > 1:
+            kernel_ms = shard_kernel_ms
 
     frame_ok = None
     if world > 1 and rank == 0:
@@ -301,7 +308,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, 5),
                 "traffic": traffic,
-                "launches_overlap": single is None,
+                "launches_overlap": False,
                 "kernel_ms": round(roof_kernel_ms, 4),
                 "step_ms_max_rank": round(kernel_ms_max, 4),
                 "algorithmic_flops_per_launch": flops,
