@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--coop-min", type=int, default=-1, help="override the cooperative any-hit threshold (0 = off)")
     ap.add_argument("--persist", default="", help="comma list of 0/1: sweep persistent-wavefront instances")
     ap.add_argument("--mat-lds", type=int, default=-1, help="override the LDS byte limit for staging materials")
+    ap.add_argument("--skip-pixels", action="store_true", help="launches leave the packed pixels alone (rt_set_pixel_write 0)")
     ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
     args = ap.parse_args()
     modes = [int(m) for m in args.modes.split(",")]
@@ -62,6 +63,8 @@ def main():
                 lib.rt_debug_set_mat_lds_limit(ctx._h, args.mat_lds)
             if args.coop_min >= 0:
                 lib.rt_debug_set_coop_min(ctx._h, args.coop_min)
+            if args.skip_pixels:
+                ctx.set_pixel_write(False)
             for r in range(args.rounds + 1):
                 for v in variants:
                     m, g, q = v
