@@ -433,3 +433,19 @@ def test_full_size_single_pass_vs_oracle():
     sph = host.demo_scene()
     cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
     _assert_same(_gpu(sph, cam, w, h, 1), O.render(sph, cam, w, h, 1, threads=16))
+
+
+@pytest.mark.parametrize("name,maker,w,h,spp", [
+    ("C2", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 1920, 1080, 64),
+    ("16 spheres", lambda: scenes.demo_plus(16), 1920, 1080, 64),
+    ("C3", lambda: scenes.random_spheres(1024), 1920, 1080, 16),
+    ("C5", lambda: scenes.mirror_box(64), 1920, 1080, 64),
+    ("C4", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
+])
+def test_baseline_configurations_at_full_size_bit_exact(name, maker, w, h, spp):
+    """Every BASELINE.json configuration at its full size against the oracle on the box's host cores
+    (1 to 13 s each on 16 threads): pixels, colour plane, final seeds and all work counters."""
+    import bench
+    sph, orig, target = maker()
+    cam = host.compute_camera(orig, target, w, h)
+    _assert_same(_gpu(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp, threads=bench.host_cores()))
