@@ -138,11 +138,22 @@ def seeds(w, h):
     return s
 
 
+def _as_spheres(a):
+    """Sphere records as the 44-byte structured dtype (raw byte arrays, as the fixtures store them,
+    are reinterpreted; anything else would silently change the sphere count)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype != SPHERE_DT:
+        if a.dtype != np.uint8 or a.size % 44:
+            raise TypeError(f"spheres must be SPHERE_DT records or their raw bytes, not {a.dtype}[{a.size}]")
+        a = a.reshape(-1).view(SPHERE_DT)
+    return a
+
+
 def render(spheres, cam, w, h, spp, first_sample=0, seeds_in=None, colors_in=None, threads=8,
            backend=0):
     """Oracle render: returns dict(pixels, colors, seeds, stats)."""
     lib = oracle()
-    spheres = np.ascontiguousarray(spheres)
+    spheres = _as_spheres(spheres)
     sd = seeds(w, h) if seeds_in is None else seeds_in.copy()
     colors = np.zeros(3 * w * h, np.float32) if colors_in is None else colors_in.copy()
     pix = np.zeros(w * h, np.uint32)
@@ -159,7 +170,7 @@ def render(spheres, cam, w, h, spp, first_sample=0, seeds_in=None, colors_in=Non
 def ref_render(spheres, cam, w, h, spp):
     """The reference kernel itself, spp launches in gid order (container only)."""
     lib = reference()
-    spheres = np.ascontiguousarray(spheres)
+    spheres = _as_spheres(spheres)
     sd = np.zeros(2 * w * h, np.uint32)
     lib.ref_seeds_init(_ptr(sd), w, h)
     colors = np.zeros(3 * w * h, np.float32)
@@ -173,7 +184,7 @@ def ref_render(spheres, cam, w, h, spp):
 def ref_render_mt(spheres, cam, w, h, spp, threads):
     """The reference kernel on `threads` host threads (same buffers as ref_render)."""
     lib = reference()
-    spheres = np.ascontiguousarray(spheres)
+    spheres = _as_spheres(spheres)
     sd = np.zeros(2 * w * h, np.uint32)
     lib.ref_seeds_init(_ptr(sd), w, h)
     colors = np.zeros(3 * w * h, np.float32)

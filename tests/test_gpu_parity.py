@@ -449,3 +449,18 @@ def test_baseline_configurations_at_full_size_bit_exact(name, maker, w, h, spp):
     sph, orig, target = maker()
     cam = host.compute_camera(orig, target, w, h)
     _assert_same(_gpu(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp, threads=bench.host_cores()))
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if not c.startswith(("c1_", "demo_"))])
+def test_shipped_scenes_at_display_size_bit_exact(name):
+    """The reference's shipped .scn scenes (sphere arrays and cameras as stored in the fixtures) at
+    the reference's native 800x600 window size, 8 passes, against the oracle."""
+    import bench
+    z = np.load(os.path.join(GOLDEN, name))
+    w, h, spp = 800, 600, 8
+    cam = np.array(z["camera"], copy=True)
+    # the stored camera's basis belongs to the fixture's size: recompute it for this one
+    c = cam.view(np.float32).reshape(-1)
+    cam2 = host.compute_camera(tuple(float(v) for v in c[0:3]), tuple(float(v) for v in c[3:6]), w, h)
+    sph = np.ascontiguousarray(z["spheres"]).view(api.SPHERE_DT)       # stored as raw 44-byte records
+    _assert_same(_gpu(sph, cam2, w, h, spp), O.render(sph, cam2, w, h, spp, threads=bench.host_cores()))
