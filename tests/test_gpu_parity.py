@@ -111,6 +111,31 @@ def test_ragged_sizes(w, h):
     _assert_same(_gpu(sph, cam, w, h, 3), O.render(sph, cam, w, h, 3))
 
 
+def _degenerate_cases():
+    demo = host.demo_scene()
+    out = [("camera orig == target", demo, (1.0, 2.0, 3.0), (1.0, 2.0, 3.0)),
+           ("camera at 1e30", demo, (1e30, 1e30, 1e30), (0.0, 0.0, 0.0))]
+    for tag, field, idx, value in [("one radius NaN", "rad", 1, np.nan), ("one centre at 1e38", "p", 2, (1e38, 1e38, 1e38)),
+                                   ("ground radius inf", "rad", 0, np.inf), ("NaN colour", "c", 0, (np.nan, 0.5, 0.5)),
+                                   ("emission 1e38", "e", 5, (1e38, 1e38, 1e38)), ("negative radius", "rad", 3, -10.0),
+                                   ("tiny radii", "rad", slice(None), 1e-30)]:
+        s = demo.copy()
+        s[field][idx] = value
+        out.append((tag, s, host.DEMO_ORIG, host.DEMO_TARGET))
+    return out
+
+
+@pytest.mark.parametrize("case", _degenerate_cases(), ids=lambda c: c[0])
+def test_non_finite_and_degenerate_inputs(case):
+    """NaN / infinite / overflowing / negative / tiny scene values and a camera without a direction:
+    whatever the reference's arithmetic makes of them, the HIP path makes the same bits (NaNs included)."""
+    _, sph, orig, target = case
+    cam = host.compute_camera(orig, target, 48, 32)
+    with np.errstate(all="ignore"):
+        want = O.render(sph, cam, 48, 32, 3)
+    _assert_same(_gpu(sph, cam, 48, 32, 3), want)
+
+
 @pytest.mark.parametrize("w,h", [(8192, 9), (5, 4100), (16384, 1)])
 def test_extreme_aspect_ratios(w, h):
     """Very wide and very tall images: pixel/tile arithmetic at the ends of its ranges."""
