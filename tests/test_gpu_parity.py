@@ -111,6 +111,34 @@ def test_ragged_sizes(w, h):
     _assert_same(_gpu(sph, cam, w, h, 3), O.render(sph, cam, w, h, 3))
 
 
+def test_contexts_on_concurrent_host_threads():
+    """rt_* calls on ONE context are single-threaded by contract; different contexts may be driven
+    from different host threads at the same time (the reference runs its compute loop on a thread
+    of its own, Main.cpp:96-102)."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(scenes.demo_plus(16), 160, 96, 6), ((host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 200, 120, 5),
+            (scenes.random_spheres(96), 96, 64, 4), (scenes.mirror_box(64), 64, 64, 3)] * 2
+
+    def one(job):
+        (sph, orig, target), w, h, spp = job
+        cam = host.compute_camera(orig, target, w, h)
+        out = []
+        with api.RtContext(w, h) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            for _ in range(3):
+                ctx.reset()
+                out.append(ctx.render_pass(spp))
+        return out
+
+    serial = [one(j) for j in jobs[:4]]
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        threaded = list(pool.map(one, jobs))
+    for k, got in enumerate(threaded):
+        for frame in got:
+            assert np.array_equal(frame, serial[k % 4][0])
+
+
 def _degenerate_cases():
     demo = host.demo_scene()
     out = [("camera orig == target", demo, (1.0, 2.0, 3.0), (1.0, 2.0, 3.0)),
