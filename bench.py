@@ -273,13 +273,25 @@ def main():
         achieved_tflops = flops / (roof_kernel_ms * 1e-3) / 1e12
         my_pixels = ctx.local_rows * W
         alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 16 * len(spheres) * 3 + 60
-        traffic = None
+        traffic, executed = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if world == 1 and os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(args.mode, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                traffic = None
+                pm = json.load(open(prof)).get(args.mode, {})
+                traffic = pm.get("hbm_bytes_per_launch")
+                if pm.get("valu_insts_per_launch"):
+                    # what the VALU actually issues (PMC of the committed profile, same command): the
+                    # time its instructions need at full issue rate, and how much of a step that is
+                    floor_ms = pm["valu_busy_frac_single_stream"] * pm["profiled_kernel_ms"]
+                    executed = {"valu_insts_per_launch": pm["valu_insts_per_launch"],
+                                "active_lane_frac": pm["active_lane_frac"],
+                                "valu_issue_floor_ms": round(floor_ms, 4),
+                                "valu_busy_frac_one_frame_at_a_time": round(floor_ms / roof_kernel_ms, 4),
+                                "valu_busy_frac_headline": round(floor_ms / ms_per_step, 4),
+                                "l2_hit_rate": pm.get("l2_hit_rate"),
+                                "source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes, tools/profile_gpu.sh)"}
+            except (OSError, ValueError, KeyError):
+                traffic, executed = None, None
         line = {
             "metric": "Mray/s (primary+shadow) at 1080p 64spp",
             "value": round(value, 1),
@@ -317,6 +329,8 @@ def main():
                         "unit": "GB/s", "frac": round(alg_bytes / (roof_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
             },
         }
+        if executed is not None:
+            line["roofline"]["executed"] = executed
         if single is not None and F > 1:
             line["single_stream"] = {"frames_in_flight": 1, "ms_per_step": round(single["elapsed"] / args.steps * 1e3, 4),
                                      "value": round(rays * args.steps / single["elapsed"] / 1e6, 1), "unit": "Mray/s"}

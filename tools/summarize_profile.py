@@ -65,10 +65,18 @@ def main():
         summary["hbm_bytes_per_launch_fetch_x2"] = 2 * fetch_b + write_b
     if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
         summary["l2_hit_rate"] = avg["TCC_HIT_sum"] / max(avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"], 1.0)
-    if "SQ_ACTIVE_INST_VALU" in avg and "SQ_THREAD_CYCLES_VALU" in avg:
-        # lanes active per issued VALU cycle (64 = no divergence)
-        summary["valu_active_lanes_avg"] = avg["SQ_THREAD_CYCLES_VALU"] / max(avg["SQ_ACTIVE_INST_VALU"], 1.0) / 4.0 \
-            if False else None
+    if "SQ_INSTS_VALU" in avg and "SQ_THREAD_CYCLES_VALU" in avg:
+        # SQ_INSTS_VALU is an exact instruction count; SQ_THREAD_CYCLES_VALU counts active lanes per instruction
+        summary["active_lane_frac"] = avg["SQ_THREAD_CYCLES_VALU"] / (avg["SQ_INSTS_VALU"] * 64.0)
+        summary["valu_insts_per_launch"] = avg["SQ_INSTS_VALU"]
+    if "SQ_INSTS_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
+        # issue cycles per SIMD: a wave64 fp32 VALU instruction occupies its SIMD for 2 cycles, a
+        # transcendental for 8, an f64 operation for 4 (tools/ubench/valu_rate.hip); 1024 SIMDs;
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        trans = avg.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        f64 = sum(avg.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
+        busy = (2.0 * avg["SQ_INSTS_VALU"] + 6.0 * trans + 2.0 * f64) / 1024.0
+        summary["valu_busy_frac_single_stream"] = busy / (avg["GRBM_GUI_ACTIVE"] / 8.0)
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     with open(os.path.join(root, "profiles", out_name + ".json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
