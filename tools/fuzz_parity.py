@@ -10,10 +10,44 @@ from raytracing_simple_amd import api, host
 src = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
 ns = {"np": np, "api": api}
 exec(src[src.index("def _fuzz_scene"):src.index('@pytest.mark.parametrize("seed"')], ns)
+def family2(seed):
+    """Ties and containment: exact duplicates of spheres (equal distances: the lowest index must win),
+    concentric shells, spheres that touch, up to 8 lights, the camera inside nested glass."""
+    rng = np.random.default_rng(100000 + seed)
+    base = int(rng.integers(1, 12))
+    sph = np.zeros(base, api.SPHERE_DT)
+    sph["rad"] = rng.uniform(1.0, 30.0, base).astype(np.float32)
+    sph["p"] = rng.uniform(-50, 50, (base, 3)).astype(np.float32)
+    sph["c"] = rng.uniform(0.1, 0.95, (base, 3)).astype(np.float32)
+    sph["refl"] = rng.choice([api.DIFF, api.SPEC, api.REFR], base)
+    parts = [sph]
+    dup = sph[rng.integers(0, base, int(rng.integers(1, 6)))].copy()          # exact duplicates, other materials
+    dup["refl"] = rng.choice([api.DIFF, api.SPEC, api.REFR], len(dup))
+    dup["c"] = rng.uniform(0.1, 0.95, (len(dup), 3)).astype(np.float32)
+    parts.append(dup)
+    shell = sph[rng.integers(0, base, int(rng.integers(1, 5)))].copy()        # concentric shells
+    shell["rad"] = (shell["rad"] * rng.choice([0.5, 0.999, 1.0000001, 1.5, 2.0], len(shell))).astype(np.float32)
+    shell["refl"] = api.REFR
+    parts.append(shell)
+    touch = sph[:1].copy()                                                    # a sphere touching sphere 0
+    touch["p"][0] = sph["p"][0] + np.float32([sph["rad"][0] + 5.0, 0, 0])
+    touch["rad"] = 5.0
+    parts.append(touch)
+    allsph = np.concatenate(parts)
+    rng.shuffle(allsph)
+    for j in rng.choice(len(allsph), min(int(rng.integers(0, 9)), len(allsph)), replace=False):
+        allsph["e"][j] = rng.uniform(1.0, 30.0, 3).astype(np.float32)
+    inside = allsph["p"][0] + np.float32(0.1) * allsph["rad"][0]
+    orig = inside if seed % 2 else rng.uniform(-90, 90, 3).astype(np.float32)
+    target = rng.uniform(-20, 20, 3).astype(np.float32)
+    return allsph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
+
+
 first, count = int(sys.argv[1]), int(sys.argv[2])
+gen = family2 if len(sys.argv) > 3 and sys.argv[3] == "2" else ns["_fuzz_scene"]
 bad = []
 for seed in range(first, first + count):
-    sph, orig, target = ns["_fuzz_scene"](seed)
+    sph, orig, target = gen(seed)
     w, h, spp = [(40, 24, 3), (33, 17, 2), (64, 32, 5), (25, 40, 4), (96, 64, 2), (17, 9, 9)][seed % 6]
     cam = host.compute_camera(orig, target, w, h)
     with np.errstate(all="ignore"):
