@@ -11,8 +11,10 @@
  * stay off: every product and sum below is a separately rounded binary32 operation,
  * written in the association order of the reference expression it restates.
  *
- * Parity status: PINNED (tests/test_oracle_pins.py: SURVEY 8c hashes; oracle/_ref
- * cross-check in tests/test_oracle_vs_ref.py when /root/reference is present).
+ * Parity status: PINNED.  tests/test_oracle_pins.py checks it against tests/golden/*.npz, the
+ * outputs of the reference's own kernel source compiled as host C++ (oracle/_ref, built from
+ * /root/reference by oracle/Makefile; fixtures made by tests/golden/make_golden.py) for the Demo
+ * scene and all nine shipped .scn scenes, and directly against oracle/_ref where that build exists.
  */
 #include "rt_oracle.h"
 
