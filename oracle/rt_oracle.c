@@ -11,7 +11,7 @@
  * stay off: every product and sum below is a separately rounded binary32 operation,
  * written in the association order of the reference expression it restates.
  *
- * Parity status: PINNED.  tests/test_oracle_pins.py checks it against tests/golden/*.npz, the
+ * Parity status: PINNED.  tests/test_oracle_pins.py checks it against tests/golden (.npz files), the
  * outputs of the reference's own kernel source compiled as host C++ (oracle/_ref, built from
  * /root/reference by oracle/Makefile; fixtures made by tests/golden/make_golden.py) for the Demo
  * scene and all nine shipped .scn scenes, and directly against oracle/_ref where that build exists.

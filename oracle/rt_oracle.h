@@ -9,7 +9,7 @@
  *
  * Parity status: PINNED against the reference itself: the reference's own kernel
  * source compiled in place as host C++ (oracle/_ref/libref.so, see oracle/Makefile)
- * and the fixtures generated from it (tests/golden/*.npz: the Demo scene and all
+ * and the fixtures generated from it (tests/golden (.npz files): the Demo scene and all
  * nine shipped .scn scenes).  SURVEY.md section 8c's camera hex, rand() outputs and
  * ray statistics reproduce; its FNV hashes do not.
  *
