@@ -251,9 +251,17 @@ RT_DEV float cl_sign(float x) {
 
 // .cl:143-169.  f lies in [2, 4) on a 2^-22 grid, so (f - 2) / 2 and f * 0.5 - 1 are both exact and
 // equal: one fused operation (written out: this translation unit never contracts by itself).
+// One multiply-with-carry step, a * (s & 65535) + (s >> 16): v_mad_u32_u16 multiplies the low 16
+// bits of its operands itself, which saves the mask the compiler otherwise emits (it does not form
+// this instruction on its own).
+RT_DEV uint32_t mwc_step(uint32_t s, uint32_t a) {
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(s), "s"(a), "v"(s >> 16));
+    return r;
+}
 RT_DEV uint32_t next_random_word(uint32_t &s0, uint32_t &s1) {
-    s0 = 36969u * (s0 & 65535u) + (s0 >> 16);
-    s1 = 18000u * (s1 & 65535u) + (s1 >> 16);
+    s0 = mwc_step(s0, 36969u);
+    s1 = mwc_step(s1, 18000u);
     uint32_t word = (s0 << 16) + s1;
     return (word & 0x007fffffu) | 0x40000000u;
 }
