@@ -385,7 +385,7 @@ int rt_pin_output(rt_ctx *c, uint32_t *out_host, size_t count) {
         (void)hipHostUnregister(c->pinned_out);
         c->pinned_out = nullptr;
     }
-    if (!out_host) return RT_OK;
+    if (!out_host || (size_t)c->local_rows * (size_t)c->w == 0) return RT_OK;    // nothing to pin (a rank without rows)
     if (count < (size_t)c->local_rows * (size_t)c->w)
         return fail(RT_ERR_ARG, "output buffer of %zu < %zu elements", count, (size_t)c->local_rows * (size_t)c->w);
     HIP_TRY(hipHostRegister(out_host, count * sizeof(uint32_t), hipHostRegisterDefault));

@@ -517,3 +517,16 @@ def test_shipped_scenes_at_display_size_bit_exact(name):
     cam2 = host.compute_camera(tuple(float(v) for v in c[0:3]), tuple(float(v) for v in c[3:6]), w, h)
     sph = np.ascontiguousarray(z["spheres"]).view(api.SPHERE_DT)       # stored as raw 44-byte records
     _assert_same(_gpu(sph, cam2, w, h, spp), O.render(sph, cam2, w, h, spp, threads=bench.host_cores()))
+
+
+def test_random_operation_sequences_keep_the_running_average_exact():
+    """tools/fuzz_api.py: random sequences of passes, resets, pixel-write switches, pinned and
+    caller-owned buffers, mode round trips, asynchronous launches and 1-3 sharded contexts; the
+    state after each sequence equals the oracle's for the same number of passes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_api.py"), "1000", "60"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout.strip().splitlines()[-1].endswith("mismatches: []"), res.stdout[-2000:]
