@@ -530,3 +530,15 @@ def test_random_operation_sequences_keep_the_running_average_exact():
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     assert res.stdout.strip().splitlines()[-1].endswith("mismatches: []"), res.stdout[-2000:]
+
+
+def test_maximum_scene_size():
+    """RT_MAX_SPHERES (8192) spheres: 128 KiB of geometry in LDS, one workgroup per CU; one more is
+    refused with RT_ERR_ARG."""
+    sph, orig, target = scenes.random_spheres(8192)
+    cam = host.compute_camera(orig, target, 64, 40)
+    _assert_same(_gpu(sph, cam, 64, 40, 2), O.render(sph, cam, 64, 40, 2, threads=16))
+    too_many, _, _ = scenes.random_spheres(8193)
+    with api.RtContext(32, 32) as ctx:
+        with pytest.raises(api.RtError):
+            ctx.set_scene(too_many)
