@@ -542,3 +542,21 @@ def test_maximum_scene_size():
     with api.RtContext(32, 32) as ctx:
         with pytest.raises(api.RtError):
             ctx.set_scene(too_many)
+
+
+def test_long_accumulation_both_reciprocal_paths():
+    """20 000 passes: one launch (1/(s+1) divided in the loop: more passes than the LDS table holds)
+    and 20 launches of 1000 (table path) give the oracle's running average bit for bit."""
+    w, h, spp = 16, 12, 20000
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    want = O.render(sph, cam, w, h, spp, threads=8)
+    _assert_same(_gpu(sph, cam, w, h, spp), want)
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        for _ in range(20):
+            px = ctx.render_pass(1000)
+        assert np.array_equal(px, want["pixels"])
+        assert np.array_equal(ctx.read_colors().view(np.uint32), want["colors"].view(np.uint32))
+        assert np.array_equal(ctx.read_seeds(), want["seeds"])
