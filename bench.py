@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: room for the frames in flight
 
-W, H, SPP = 1920, 1080, 64
+W, H, SPP = 1920, 1080, 64            # the headline workload (BASELINE.json configs[1]); --workload changes them
 TILE_ROWS = 8
 FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0                # same table
@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5"], default="c2",
+                    help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames kept in flight per rank (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
     args = ap.parse_args()
@@ -119,8 +121,18 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    spheres = host.demo_scene()
-    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, W, H)
+    global W, H, SPP
+    from raytracing_simple_amd import scenes
+    workloads = {
+        "c2": ("C2: Demo scene (6 spheres)", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 1920, 1080, 64),
+        "c16": ("north-star target scene: Demo + 10 spheres (16)", lambda: scenes.demo_plus(16), 1920, 1080, 64),
+        "c3": ("C3: 1024 random spheres", lambda: scenes.random_spheres(1024), 1920, 1080, 16),
+        "c4": ("C4: Demo scene (6 spheres)", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
+        "c5": ("C5: 64-sphere mirror box, depth 8", lambda: scenes.mirror_box(64), 1920, 1080, 64),
+    }
+    wl_name, wl_maker, W, H, SPP = workloads[args.workload]
+    spheres, cam_orig, cam_target = wl_maker()
+    cam = host.compute_camera(cam_orig, cam_target, W, H)
     mode = api.RT_MODE_FAST if args.mode == "fast" else api.RT_MODE_PARITY
 
     # Frames in flight.  A step is one frame; the K timed frames are independent (each restarts
@@ -275,7 +287,7 @@ def main():
         alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 16 * len(spheres) * 3 + 60
         traffic, executed = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if world == 1 and os.path.exists(prof):
+        if world == 1 and args.workload == "c2" and os.path.exists(prof):
             try:
                 pm = json.load(open(prof)).get(args.mode, {})
                 traffic = pm.get("hbm_bytes_per_launch")
@@ -293,7 +305,8 @@ def main():
             except (OSError, ValueError, KeyError):
                 traffic, executed = None, None
         line = {
-            "metric": "Mray/s (primary+shadow) at 1080p 64spp",
+            "metric": "Mray/s (primary+shadow) at 1080p 64spp" if args.workload == "c2"
+                      else f"Mray/s (primary+shadow) at {W}x{H} {SPP}spp",
             "value": round(value, 1),
             "unit": "Mray/s",
             "n_gpus": world,
@@ -305,7 +318,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"C2: Demo scene (6 spheres), {W}x{H}, {SPP} spp, default seed stream",
+            "config": {"workload": f"{wl_name}, {W}x{H}, {SPP} spp, default seed stream",
                        "mode": args.mode, "collective": None if world == 1 else f"gather to rank 0 ({backend})",
                        "frames_in_flight": F,
                        "gathered_frame_equals_unsharded": frame_ok, "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
@@ -314,7 +327,7 @@ def main():
                        "Msample_s": round(samples * args.steps / elapsed / 1e6, 1)},
             "roofline": {
                 "bound": "valu-fp32",
-                "kernel": "rt_trace_" + args.mode,
+                "kernel": "rt_trace_" + args.mode + ("_coop" if len(spheres) >= 12 else ""),
                 "achieved": round(achieved_tflops, 3),
                 "peak": FP32_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
