@@ -8,6 +8,8 @@
 #define HIP_CONFIG_HPP
 
 #include <chrono>
+#include <memory>      // the factory (Config.cpp) uses std::make_unique / std::runtime_error and gets
+#include <stdexcept>   // them from the OpenCL / Cm headers today; with only this backend enabled, from here
 #include <vector>
 
 #include "Camera.hpp"   // reference headers

@@ -1,0 +1,65 @@
+// ref_host_main.cpp -- builds oracle/_ref/ref_host_hip: the REFERENCE's own host code around the HIP
+// backend.  TEST INFRASTRUCTURE (container build only; the binary is git-ignored and travels to the
+// GPU box like oracle/_ref/libref.so).
+//
+// Linked from the reference's sources where they lie (/root/reference/SimpleRT/src/{Config,Utility,
+// Vec,Scene}.cpp, unmodified) + adapter/HipConfig.cpp + librt_hip.so.  The flow below is the one
+// of SimpleRT/src/Main.cpp:68-102 without the freeglut window: scene from `readScene` or
+// `DemoSpheres`, `sceneSetup`, `updateCamera`, then N calls of `Config::updateRendering()` (the
+// reference's pass driver, Config.cpp:73-91, incl. its caption), and the frame `getPixels()`
+// returns, written as a PPM.  The reference's factory has no case for framework ID 2
+// (Config.cpp:63-65), so the object is constructed here the way INTEGRATION.md's factory edit
+// would construct it.
+//
+//   ref_host_hip <passes> <width> <height> <out.ppm> [scene.scn]
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "Config.hpp"
+#include "Scene.hpp"
+#include "Sphere.hpp"
+#include "Utility.hpp"
+#include "Vec.hpp"
+
+#include "HipConfig.hpp"
+
+int main(int argc, char** argv) {
+    if (argc < 5) {
+        fprintf(stderr, "usage: %s <passes> <width> <height> <out.ppm> [scene.scn]\n", argv[0]);
+        return 2;
+    }
+    const int passes = atoi(argv[1]), w = atoi(argv[2]), h = atoi(argv[3]);
+    std::unique_ptr<Config> config = std::make_unique<HipConfig>(w, h);   // = createConfig(w, h, selectType(2), true, MemType::Buffer) after INTEGRATION.md's edit
+
+    Vec orig, target;
+    std::vector<Sphere> spheres;
+    if (argc >= 6) {
+        spheres = readScene(argv[5], orig, target);                      // Main.cpp:74-76
+    } else {
+        orig = { 20.f, 100.f, 120.f };                                    // Main.cpp:80-84
+        target = { 0.f, 25.f, 0.f };
+        spheres = DemoSpheres;
+    }
+    config->sceneSetup(spheres, orig, target);                            // Main.cpp:89
+    config->updateCamera();                                               // Main.cpp:90
+
+    char caption[256] = "";
+    config->setCaptionBuffer(caption);                                    // SetupGL.cpp:83
+    for (int i = 0; i < passes; ++i) config->updateRendering();           // Main.cpp:96-102
+    fprintf(stderr, "%s", caption);
+
+    const unsigned* px = config->getPixels();                             // SetupGL.cpp:85
+    FILE* f = fopen(argv[4], "wb");
+    if (!f) return 1;
+    fprintf(f, "P6\n%d %d\n255\n", w, h);
+    for (int y = h - 1; y >= 0; --y)                                      // buffer row 0 is the bottom of the image
+        for (int x = 0; x < w; ++x) {
+            const unsigned p = px[(size_t)y * w + x];
+            const unsigned char rgb[3] = { (unsigned char)(p & 255), (unsigned char)((p >> 8) & 255), (unsigned char)((p >> 16) & 255) };
+            fwrite(rgb, 1, 3, f);
+        }
+    fclose(f);
+    return 0;
+}

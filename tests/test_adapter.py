@@ -59,3 +59,55 @@ def test_cpp_host_writes_the_golden_frame(tmp_path, golden_dir):
     assert out4.read_bytes() == out3.read_bytes()
     bad = subprocess.run([exe, "0", "1", "0"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Unsupported Framework Type" in bad.stderr
+
+
+REF_HOST = os.path.join(ROOT, "oracle", "_ref", "ref_host_hip")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_HOST), reason="oracle/_ref/ref_host_hip is built only where the reference checkout exists")
+def test_reference_host_code_drives_the_hip_backend(tmp_path, golden_dir):
+    """The reference's OWN host code -- Config::updateRendering (its pass driver), readScene with its
+    doubling, DemoSpheres, computeCameraVariables -- linked unmodified around adapter/HipConfig and
+    librt_hip.so (oracle/ref_host_main.cpp = Main.cpp's flow without the window).  Its frames must be
+    the golden frames of the reference's OpenCL kernel."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from raytracing_simple_amd import host, scenes
+    env = dict(os.environ, RT_READBACK_MS="0")                # copy after every pass: the last frame is the one compared
+
+    def frame(path, w, h):
+        raw = open(path, "rb").read()
+        head = b"P6\n%d %d\n255\n" % (w, h)
+        assert raw.startswith(head)
+        return np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)[::-1]
+
+    def rgb(pixels, w, h):
+        return np.ascontiguousarray(pixels, dtype=np.uint32).view(np.uint8).reshape(h, w, 4)[:, :, :3]
+
+    # C1 and a 3-pass Demo frame: the committed reference fixtures
+    for name, passes in (("c1_demo_256x256_1spp.npz", 1), ("demo_200x120_3spp.npz", 3)):
+        z = np.load(os.path.join(golden_dir, name))
+        w, h = int(z["w"]), int(z["h"])
+        out = tmp_path / (name + ".ppm")
+        res = subprocess.run([REF_HOST, str(passes), str(w), str(h), str(out)], env=env, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert "pass %d" % passes in res.stderr                  # the reference's own caption (Config.cpp:87-88)
+        assert np.array_equal(frame(out, w, h), rgb(z["pixels"], w, h))
+    # a scene FILE through the reference's loader (which doubles the sphere vector), 5 passes
+    sph, orig, target = scenes.demo_plus(16)
+    scn = tmp_path / "sixteen.scn"
+    host.write_scene(str(scn), sph, orig, target)
+    w, h, passes = 160, 96, 5
+    out = tmp_path / "sixteen.ppm"
+    res = subprocess.run([REF_HOST, str(passes), str(w), str(h), str(out), str(scn)], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    loaded, o2, t2 = host.read_scene(str(scn), reference_doubling=True)
+    want = O.render(loaded, host.compute_camera(o2, t2, w, h), w, h, passes)
+    assert np.array_equal(frame(out, w, h), rgb(want["pixels"], w, h))
+    # the display cadence (default RT_READBACK_MS): the frame after a long run is still a frame of the sequence
+    res = subprocess.run([REF_HOST, "1", "64", "48", str(tmp_path / "one.ppm")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    want1 = O.render(O.demo_spheres(), O.camera((20.0, 100.0, 120.0), (0.0, 25.0, 0.0), 64, 48), 64, 48, 1)
+    assert np.array_equal(frame(tmp_path / "one.ppm", 64, 48), rgb(want1["pixels"], 64, 48))   # pass 0 is always copied
