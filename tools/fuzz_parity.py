@@ -43,8 +43,27 @@ def family2(seed):
     return allsph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
 
 
+def family3(seed):
+    """Family 1 scaled by 10^-3 ... 10^4 (radii, centres, camera): the fixed EPSILON = 0.01 then
+    cuts into the geometry (tiny scenes) or drowns in rounding error (huge ones), and the camera
+    may sit a hair above a surface."""
+    sph, orig, target = ns["_fuzz_scene"](seed)
+    rng = np.random.default_rng(200000 + seed)
+    k = np.float32(10.0 ** rng.uniform(-3, 4))
+    sph = sph.copy()
+    sph["rad"] = sph["rad"] * k
+    sph["p"] = sph["p"] * k
+    orig = tuple(float(np.float32(v) * k) for v in orig)
+    target = tuple(float(np.float32(v) * k) for v in target)
+    if seed % 3 == 0 and len(sph):
+        j = int(rng.integers(0, len(sph)))
+        up = np.float32([0, 1, 0]) * (sph["rad"][j] * np.float32(1.0 + 10.0 ** rng.uniform(-7, -2)))
+        orig = tuple(float(v) for v in (sph["p"][j] + up))
+    return sph, orig, target
+
+
 first, count = int(sys.argv[1]), int(sys.argv[2])
-gen = family2 if len(sys.argv) > 3 and sys.argv[3] == "2" else ns["_fuzz_scene"]
+gen = {"2": family2, "3": family3}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
 bad = []
 for seed in range(first, first + count):
     sph, orig, target = gen(seed)
