@@ -336,8 +336,27 @@ int rt_reset_async(rt_ctx *c, void *hip_stream) {
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
-                           hipMemcpyDeviceToDevice, st));
+    if (c->nranks == 1) {
+        HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, st));
+    } else {
+        // only the row tiles this rank renders (the others are never written): tile t is the byte
+        // range [t, t+1) * tile_bytes of the seed array, the rank owns t = rank, rank + n, ...
+        const size_t tile_bytes = (size_t)c->tile_rows * c->w * 2 * sizeof(uint32_t);
+        const int full_tiles = c->h / c->tile_rows;                       // full-height tiles of the image
+        const int mine_full = full_tiles > c->rank ? (full_tiles - c->rank + c->nranks - 1) / c->nranks : 0;
+        char *dst = reinterpret_cast<char *>(c->d_seeds) + (size_t)c->rank * tile_bytes;
+        const char *src = reinterpret_cast<const char *>(c->d_seeds0) + (size_t)c->rank * tile_bytes;
+        if (mine_full > 0)
+            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->nranks * tile_bytes, src, (size_t)c->nranks * tile_bytes, tile_bytes,
+                                     (size_t)mine_full, hipMemcpyDeviceToDevice, st));
+        const int short_rows = c->h - full_tiles * c->tile_rows;          // the short tile at the top of the image, if any
+        if (short_rows > 0 && full_tiles % c->nranks == c->rank) {
+            const size_t off = (size_t)full_tiles * tile_bytes;
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(c->d_seeds) + off, reinterpret_cast<const char *>(c->d_seeds0) + off,
+                                   (size_t)short_rows * c->w * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        }
+    }
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), st));
     c->current_sample = 0;

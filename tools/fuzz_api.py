@@ -36,7 +36,10 @@ for seed in range(first, first + count):
         log.append((op, n))
         for k, c in enumerate(ctxs):
             if op == 0:
-                c.reset()
+                if n % 2:
+                    c.reset()
+                else:                                   # the device-side reset (only this rank's row tiles)
+                    c.reset_async(c.stream); torch.cuda.synchronize()
             elif op == 1:
                 c.set_pixel_write(False); c.render_pass(n, copy=False); c.set_pixel_write(True)
             elif op == 2:
