@@ -161,6 +161,7 @@ def main():
     gather = None
     if world > 1:
         gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=2 * F)
+        torch.cuda.synchronize()        # its zero-fills ran on torch's stream; the contexts' streams are non-blocking
     frame_no = [0]
 
     def step(in_flight, ev=None, do_gather=True):

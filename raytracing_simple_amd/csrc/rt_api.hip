@@ -74,16 +74,21 @@ int select_device(const rt_ctx *c) {
     return RT_OK;
 }
 
+// Everything the context does to its own buffers goes through its own stream: that stream is
+// non-blocking, so work put on the null stream (hipMemset, device-to-device hipMemcpy: both return
+// before they have run) would not be ordered against the launches that follow -- under load from
+// other host threads a frame could start on seeds and counters that were still being reset.
 int upload_default_seeds(rt_ctx *c) {
     const size_t count = 2 * (size_t)c->w * (size_t)c->h;
     std::vector<uint32_t> host(count);
     rt_default_seeds(host.data(), count);
-    HIP_TRY(hipMemcpy(c->d_seeds0, host.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_seeds, c->d_seeds0, count * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemset(c->d_colors, 0, 3 * (size_t)c->w * (size_t)c->h * sizeof(float)));
-    HIP_TRY(hipMemset(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->d_counters, 0, 32 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyAsync(c->d_seeds0, host.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_colors, 0, 3 * (size_t)c->w * (size_t)c->h * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));          // `host` goes out of scope; rt_create / rt_reset are blocking calls
     return RT_OK;
 }
 
@@ -440,7 +445,9 @@ int rt_read_colors(rt_ctx *c, float *out_host) {
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
-    HIP_TRY(hipMemcpy(out_host, c->d_colors, 3 * (size_t)c->w * c->h * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_colors, 3 * (size_t)c->w * c->h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -449,7 +456,9 @@ int rt_read_seeds(rt_ctx *c, uint32_t *out_host) {
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
-    HIP_TRY(hipMemcpy(out_host, c->d_seeds, 2 * (size_t)c->w * c->h * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_seeds, 2 * (size_t)c->w * c->h * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -459,9 +468,10 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     if (rc != RT_OK) return rc;
     unsigned long long v[32];
     HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
-    HIP_TRY(hipMemcpy(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost, c->stream));
     unsigned long long part[rt::kStatReplicas * 8], sum[5] = { 0, 0, 0, 0, 0 };
-    HIP_TRY(hipMemcpy(part, c->d_stats, sizeof part, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(part, c->d_stats, sizeof part, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     for (int r = 0; r < rt::kStatReplicas; ++r)
         for (int k = 0; k < 5; ++k) sum[k] += part[r * 8 + k];
     out->samples = sum[0];
