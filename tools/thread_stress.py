@@ -24,7 +24,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 bad = 0
 for r in range(rounds):
     try:
-        with ThreadPoolExecutor(max_workers=8) as pool:
+        with ThreadPoolExecutor(max_workers=int(os.environ.get("RT_STRESS_THREADS", "8"))) as pool:
             threaded = list(pool.map(one, jobs))
     except Exception:
         bad += 1
