@@ -106,9 +106,13 @@ def _ptr(a):
 
 
 def as_spheres(spheres):
+    """Sphere records as the 44-byte structured dtype; raw bytes (uint8, a multiple of 44) are
+    reinterpreted, anything else is refused rather than silently given another sphere count."""
     a = np.ascontiguousarray(spheres)
     if a.dtype != SPHERE_DT:
-        a = a.view(np.uint8).reshape(-1).view(SPHERE_DT)
+        if a.dtype != np.uint8 or a.size % SPHERE_DT.itemsize:
+            raise TypeError(f"spheres must be SPHERE_DT records or their raw bytes, not {a.dtype}[{a.size}]")
+        a = a.reshape(-1).view(SPHERE_DT)
     return a
 
 
