@@ -242,8 +242,18 @@ def main():
         got = gather.wait(frame_no[0] - 1).cpu().numpy().astype("uint32").reshape(-1)
         frame_ok = bool((got == want).all())
 
-    st = last_ctx.stats()                 # counters of the last frame (reset clears them)
-    last_pixels = last_ctx.render_pass(0, copy=True) if world == 1 else None
+    last_pixels = last_ctx.render_pass(0, copy=True) if world == 1 else None   # the last TIMED frame (checked against the oracle below)
+
+    def frame_counters(c):
+        """Exact ray / test counts of one frame of this rank (the same for every frame): from one more,
+        synchronous render after a synchronous reset, so that they do not depend on how the timed
+        region's asynchronous resets were ordered."""
+        c.set_pixel_buffer(0, 0)
+        c.reset()
+        c.render_pass(SPP, copy=False)
+        return c.stats()
+
+    st = frame_counters(last_ctx)
 
     # the other arithmetic mode on the same workload, single stream, outside the headline's
     # timed region (N = 1 only; reported beside `value`, never instead of it)
@@ -253,8 +263,8 @@ def main():
         for c in ctxs:
             c.set_mode(other_mode)
         el_o, _, last_o = timed_region(F, 8, 2, with_events=False)
-        st_o = last_o.stats()
         px_o = last_o.render_pass(0, copy=True)
+        st_o = frame_counters(last_o)
         other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "frames_in_flight": F,
                  "ms_per_step": round(el_o / 8 * 1e3, 4),
                  "value": round((st_o["samples"] + st_o["shadow_rays"]) * 8 / el_o / 1e6, 1), "unit": "Mray/s",

@@ -107,9 +107,10 @@ int rt_set_mode(rt_ctx *ctx, int mode);                    /* enum rt_mode; defa
 /* Back to pass 0: mCurrentSample = 0, seeds = default stream, counters cleared.              */
 int rt_reset(rt_ctx *ctx);
 
-/* rt_reset() without a host round trip: seeds restored from a device-resident copy of the
- * default stream and counters cleared, asynchronously on `hip_stream`.  (The colour plane
- * needs no clearing: pass 0 overwrites it, .cl:580-582.)                                    */
+/* rt_reset() without a host round trip: the next launch starts from a device-resident copy of
+ * the default stream (read in place, nothing is copied) and the counters are cleared by a small
+ * kernel on `hip_stream`.  (The colour plane needs no clearing: pass 0 overwrites it,
+ * .cl:580-582.)                                                                              */
 int rt_reset_async(rt_ctx *ctx, void *hip_stream);
 
 /* `n_samples` x { setArguments(); execute(); ++mCurrentSample; } (Config.cpp:73-81) as ONE

@@ -34,6 +34,18 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+// rt_reset_async zeroes the work counters with a kernel on the caller's stream and restores NO seeds:
+// the next launch reads the pristine default stream directly (LaunchParams::seeds_in).  Reason: with
+// several processes sharing one GPU and six streams each (tools/gather_stress.py), about one frame
+// in a thousand was rendered from seeds that the reset issued just before it ON THE SAME STREAM -- a
+// device-to-device copy at first, then a copy kernel -- had not yet made visible: every wrong pixel
+// equalled the frame computed from un-reset seeds, and a host-side wait between reset and launch
+// made it go away.  A frame that starts from data nobody writes cannot lose that race.
+__global__ void rt_zero_counters_kernel(unsigned long long *counters, unsigned long long *stats) {
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) counters[i] = 0ull;
+    for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) stats[i] = 0ull;
+}
+
 struct rt_ctx {
     int device = 0;
     int w = 0, h = 0;
@@ -45,6 +57,7 @@ struct rt_ctx {
     uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
     void *pinned_out = nullptr;         // host buffer page-locked by rt_pin_output, or null
     int pixel_write = 1;                // rt_set_pixel_write
+    bool seeds_default = false;         // after rt_reset_async: the next launch reads the pristine stream
     unsigned long long *d_counters = nullptr;
     unsigned long long *d_stats = nullptr;      // rt::kStatReplicas x 8 partial work counters
     float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
@@ -104,6 +117,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.scene = c->scene;
     p.cam = c->cam;
     p.seeds = c->d_seeds;
+    p.seeds_in = c->seeds_default ? c->d_seeds0 : c->d_seeds;
     p.colors = c->d_colors;
     p.pixels = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
     p.counters = c->d_counters;
@@ -157,6 +171,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
                     hipGetErrorString(e), grid.x, grid.y, lds);
     c->current_sample += n_samples;
     c->launches += 1;
+    c->seeds_default = false;           // this launch has written every seed pair the context renders
     return RT_OK;
 }
 
@@ -333,6 +348,7 @@ int rt_reset(rt_ctx *c) {
     c->current_sample = 0;
     c->launches = 0;
     c->last_ms = 0.0;
+    c->seeds_default = false;
     return upload_default_seeds(c);
 }
 
@@ -340,30 +356,9 @@ int rt_reset_async(rt_ctx *c, void *hip_stream) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    hipStream_t st = (hipStream_t)hip_stream;
-    if (c->nranks == 1) {
-        HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, st));
-    } else {
-        // only the row tiles this rank renders (the others are never written): tile t is the byte
-        // range [t, t+1) * tile_bytes of the seed array, the rank owns t = rank, rank + n, ...
-        const size_t tile_bytes = (size_t)c->tile_rows * c->w * 2 * sizeof(uint32_t);
-        const int full_tiles = c->h / c->tile_rows;                       // full-height tiles of the image
-        const int mine_full = full_tiles > c->rank ? (full_tiles - c->rank + c->nranks - 1) / c->nranks : 0;
-        char *dst = reinterpret_cast<char *>(c->d_seeds) + (size_t)c->rank * tile_bytes;
-        const char *src = reinterpret_cast<const char *>(c->d_seeds0) + (size_t)c->rank * tile_bytes;
-        if (mine_full > 0)
-            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)c->nranks * tile_bytes, src, (size_t)c->nranks * tile_bytes, tile_bytes,
-                                     (size_t)mine_full, hipMemcpyDeviceToDevice, st));
-        const int short_rows = c->h - full_tiles * c->tile_rows;          // the short tile at the top of the image, if any
-        if (short_rows > 0 && full_tiles % c->nranks == c->rank) {
-            const size_t off = (size_t)full_tiles * tile_bytes;
-            HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(c->d_seeds) + off, reinterpret_cast<const char *>(c->d_seeds0) + off,
-                                   (size_t)short_rows * c->w * 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-        }
-    }
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(rt_zero_counters_kernel, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, c->d_counters, c->d_stats);
+    HIP_TRY(hipGetLastError());
+    c->seeds_default = true;            // the next launch reads d_seeds0
     c->current_sample = 0;
     return RT_OK;
 }
@@ -383,11 +378,15 @@ int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     rc = launch(c, n_samples, c->stream);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    if (out_host && c->local_rows > 0)
+    // the launch is complete before the readback is issued (not merely queued behind it: see
+    // rt_reset_kernel for why this library does not lean on copy-after-kernel ordering)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (out_host && c->local_rows > 0) {
         HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels,
                                (size_t)c->local_rows * c->w * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
@@ -456,8 +455,8 @@ int rt_read_seeds(rt_ctx *c, uint32_t *out_host) {
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_seeds, 2 * (size_t)c->w * c->h * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, c->seeds_default ? c->d_seeds0 : c->d_seeds, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }

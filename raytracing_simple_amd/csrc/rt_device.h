@@ -37,7 +37,9 @@ struct SceneTables {
 struct LaunchParams {
     SceneTables scene;
     rt_camera cam;
-    uint32_t *seeds;        // [2*w*h], pair per pixel at gid = y*w + x        (.cl:570-571)
+    uint32_t *seeds;        // [2*w*h], pair per pixel at gid = y*w + x        (.cl:570-571); written at the end of a launch
+    const uint32_t *seeds_in;   // read at the start of a launch: `seeds`, or the pristine default stream for the
+                                // first launch after rt_reset_async (no copy, and no dependence on one having landed)
     float *colors;          // [3*w*h], running average at (h-1-y)*w + x       (.cl:579)
     uint32_t *pixels;       // [local_rows*w], packed RGBX of this rank's rows (.cl:594)
     unsigned long long *stats;     // [kStatReplicas][8] u64: samples, closest, shadow, tests, draws (per-replica partial sums)

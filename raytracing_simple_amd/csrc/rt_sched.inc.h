@@ -80,8 +80,8 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES)
     int s = P.first_sample;
     const int s_end = P.first_sample + P.n_samples;
     if (valid) {
-        s0 = P.seeds[2 * gid];
-        s1 = P.seeds[2 * gid + 1];
+        s0 = P.seeds_in[2 * gid];
+        s1 = P.seeds_in[2 * gid + 1];
         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
     }
 

@@ -632,8 +632,8 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     int s = P.first_sample;
     const int s_end = valid ? P.first_sample + P.n_samples : P.first_sample;
     if (valid) {
-        s0 = P.seeds[2 * gid];
-        s1 = P.seeds[2 * gid + 1];
+        s0 = P.seeds_in[2 * gid];
+        s1 = P.seeds_in[2 * gid + 1];
         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
     }
 #endif
@@ -740,8 +740,8 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
                     if ((x < P.w) && (lrow < P.local_rows) && (y < P.h)) {
                         gid = (size_t)y * (size_t)P.w + (size_t)x;         // .cl:560-563
                         ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;   // .cl:579
-                        s0 = P.seeds[2 * gid];
-                        s1 = P.seeds[2 * gid + 1];
+                        s0 = P.seeds_in[2 * gid];
+                        s1 = P.seeds_in[2 * gid + 1];
                         acc = mk(0.f, 0.f, 0.f);
                         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
                         s = P.first_sample;
