@@ -561,3 +561,20 @@ def test_long_accumulation_both_reciprocal_paths():
         assert np.array_equal(px, want["pixels"])
         assert np.array_equal(ctx.read_colors().view(np.uint32), want["colors"].view(np.uint32))
         assert np.array_equal(ctx.read_seeds(), want["seeds"])
+
+
+def test_multi_rank_frame_loop_every_frame_checked():
+    """tools/gather_stress.py: bench.py's N > 1 frame loop -- frames in flight, render into the
+    gather's send slot, asynchronous gather, slot reuse -- as 3 processes sharing this GPU (gloo
+    carries the collective; RCCL refuses several ranks on one device), every gathered frame compared."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RT_BENCH_SINGLE_DEVICE="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731",
+                          os.path.join(root, "tools", "gather_stress.py"), "90", "3", "gloo"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("gather stress:")]
+    assert lines and lines[-1].endswith("-> 0 wrong frames"), res.stdout[-3000:]
