@@ -35,15 +35,32 @@ int fail(int code, const char *fmt, ...) {
 }  // namespace
 
 // rt_reset_async zeroes the work counters with a kernel on the caller's stream and restores NO seeds:
-// the next launch reads the pristine default stream directly (LaunchParams::seeds_in).  Reason: with
-// several processes sharing one GPU and six streams each (tools/gather_stress.py), about one frame
-// in a thousand was rendered from seeds that the reset issued just before it ON THE SAME STREAM -- a
-// device-to-device copy at first, then a copy kernel -- had not yet made visible: every wrong pixel
-// equalled the frame computed from un-reset seeds, and a host-side wait between reset and launch
-// made it go away.  A frame that starts from data nobody writes cannot lose that race.
+// the next launch reads the pristine default stream directly (LaunchParams::seeds_in).  Reason: in
+// the multi-rank frame loop (tools/gather_stress.py: 4 processes sharing one GPU, 6 streams each, a
+// torch.distributed collective per frame) about one frame in a thousand was rendered from seeds that
+// the reset issued just before it ON THE SAME STREAM -- a device-to-device copy at first, then a copy
+// kernel -- had not restored yet: every wrong pixel equalled the frame computed from un-reset seeds,
+// and a probe kernel placed between reset and launch (RT_PROBE=1) saw whole workgroups' worth of
+// un-restored seed words.  It needs the collective's worker in the process: the same loop without
+// the gather, with several host threads, or as pure HIP (tools/ubench/stream_order.hip: dependent
+// kernels, events, waits, a copying worker thread, 4-6 processes) never showed it, so the cause is
+// not pinned down.  A frame that starts from data nobody writes cannot lose that race.
 __global__ void rt_zero_counters_kernel(unsigned long long *counters, unsigned long long *stats) {
     for (int i = threadIdx.x; i < 32; i += blockDim.x) counters[i] = 0ull;
     for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) stats[i] = 0ull;
+}
+
+// diagnostic only (rt_debug_reset_by_copy): the reset this library used before -- a copy kernel that
+// restores the seed words, which the next launch then reads back
+__global__ void rt_debug_copy_seeds_kernel(uint32_t *seeds, const uint32_t *seeds0, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) seeds[i] = seeds0[i];
+}
+
+__global__ void rt_debug_probe_seeds_kernel(const uint32_t *seeds, const uint32_t *seeds0, size_t n, unsigned long long *out) {
+    unsigned long long b = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b += (seeds[i] != seeds0[i]);
+    if (b) atomicAdd(out, b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 1, 1ull);     // probes run
 }
 
 struct rt_ctx {
@@ -360,6 +377,43 @@ int rt_reset_async(rt_ctx *c, void *hip_stream) {
     HIP_TRY(hipGetLastError());
     c->seeds_default = true;            // the next launch reads d_seeds0
     c->current_sample = 0;
+    return RT_OK;
+}
+
+int rt_debug_reset_by_copy(rt_ctx *c, void *hip_stream, int use_memcpy) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    const size_t n = 2 * (size_t)c->w * (size_t)c->h;
+    if (use_memcpy) {
+        HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    } else {
+        hipLaunchKernelGGL(rt_debug_copy_seeds_kernel, dim3(1024), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0, n);
+        HIP_TRY(hipGetLastError());
+    }
+    c->seeds_default = false;
+    c->current_sample = 0;
+    return RT_OK;
+}
+
+// diagnostic: a kernel on `hip_stream` that counts the seed words differing from the default stream
+// into counters[28] (and the number of probes into counters[29]); read them with rt_debug_counters_raw
+int rt_debug_probe_seeds(rt_ctx *c, void *hip_stream) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(rt_debug_probe_seeds_kernel, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0,
+                       2 * (size_t)c->w * (size_t)c->h, c->d_counters + 28);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_debug_counters_raw(rt_ctx *c, unsigned long long *out32) {
+    if (!c || !out32) return fail(RT_ERR_ARG, "null argument");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out32, c->d_counters, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -19,9 +19,28 @@ for k in range(F):
     with api.RtContext(w, h) as ref:
         ref.set_scene(sph); ref.set_camera(cam); want.append(ref.render_pass(spp))
 bad = 0
+progressive = len(sys.argv) > 3 and sys.argv[3] == "progressive"
 for r in range(rounds):
+    if progressive:          # launches that depend on each other through seeds and colours, queued without waiting
+        for c in ctxs:
+            c.reset_async(c.stream)
+        for _ in range(spp // 2):
+            for c in ctxs:
+                c.render_async(2, c.stream)
+        torch.cuda.synchronize()
+        for k, c in enumerate(ctxs):
+            if not np.array_equal(c.render_pass(0), want[k]):
+                bad += 1; print("round", r, "context", k, "differs (progressive)", flush=True)
+        continue
     for c in ctxs:
-        c.reset_async(c.stream); c.render_async(spp, c.stream)
+        if len(sys.argv) > 3 and sys.argv[3] in ("copykernel", "memcpy"):    # the earlier reset: seeds restored by a copy, read back by the launch
+            import ctypes as C
+            lib = api.load_library()
+            lib.rt_debug_reset_by_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            lib.rt_debug_reset_by_copy(c._h, C.c_void_p(c.stream), 1 if sys.argv[3] == "memcpy" else 0)
+        else:
+            c.reset_async(c.stream)
+        c.render_async(spp, c.stream)
     torch.cuda.synchronize()
     for k, c in enumerate(ctxs):
         if not np.array_equal(c.render_pass(0), want[k]):
