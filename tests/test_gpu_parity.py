@@ -578,3 +578,27 @@ def test_multi_rank_frame_loop_every_frame_checked():
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("gather stress:")]
     assert lines and lines[-1].endswith("-> 0 wrong frames"), res.stdout[-3000:]
+
+
+@pytest.mark.parametrize("w,h,nranks", [(33, 17, 1), (31, 8, 1), (64, 9, 3), (200, 120, 4), (7, 3, 2), (1920, 7, 1)])
+def test_no_write_outside_the_pixel_buffer(w, h, nranks):
+    """Guard bands around a caller-owned pixel buffer: ragged image sizes and sharded contexts leave
+    every word before and after the rank's rows alone (tiles overhang the image, lanes beyond it must
+    not store)."""
+    import torch
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    guard = 4096
+    for rank in range(nranks):
+        with api.RtContext(w, h, rank=rank, nranks=nranks, tile_rows=8) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            n = ctx.local_rows * w
+            buf = torch.full((guard + n + guard,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.set_pixel_buffer(buf.data_ptr() + 4 * guard, n)
+            ctx.render_pass(2, copy=False)
+            got = buf.cpu().numpy().view(np.uint32)
+            assert (got[:guard] == 0x5A5A5A5A).all() and (got[guard + n:] == 0x5A5A5A5A).all()
+            plain = _gpu(sph, cam, w, h, 2, rank=rank, nranks=nranks, tile_rows=8)["pixels"]
+            assert np.array_equal(got[guard:guard + n], plain)
