@@ -22,7 +22,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: room for the frames in flight
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# Before HIP starts: a hardware queue of its own for every stream in the process (frames in flight, the
+# collective's streams, torch's).  With the default of 4 two frames shared a queue and did not overlap
+# at all; and whenever streams SHARED queues (4, 8 or 16 queues for the ten-odd streams of a rank) the
+# multi-rank frame loop with a torch.distributed collective in the process showed its ordering failure
+# (tools/gather_stress.py); with 24 it never did, and nothing runs slower.
 
 W, H, SPP = 1920, 1080, 64            # the headline workload (BASELINE.json configs[1]); --workload changes them
 TILE_ROWS = 8

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """F contexts in flight on their own streams (bench.py's pattern), every frame checked."""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

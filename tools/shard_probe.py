@@ -3,7 +3,7 @@
 Renders rank 0's interleaved share of the C2 frame with F contexts / streams in flight and prints
 microseconds per frame (what one rank of an N-GPU job sustains before the gather)."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from raytracing_simple_amd import api, host
