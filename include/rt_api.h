@@ -137,7 +137,10 @@ int rt_set_pixel_write(rt_ctx *ctx, int enable);
 int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);
 
 /* The context's own non-blocking stream (a hipStream_t), the one rt_render_pass uses.  With
- * several contexts in flight, rt_render_async(ctx, n, rt_stream(ctx)) runs each on its own.      */
+ * several contexts in flight, rt_render_async(ctx, n, rt_stream(ctx)) runs each on its own.
+ * HIP gives a process GPU_MAX_HW_QUEUES hardware queues (default 4) and lets further streams
+ * share them: two contexts on one queue do not overlap at all, so a host that keeps F contexts
+ * in flight should start with GPU_MAX_HW_QUEUES >= the number of streams it uses (bench.py: 24). */
 void *rt_stream(rt_ctx *ctx);
 
 /* Device address and element count (uint32) of the local pixel buffer.                       */
