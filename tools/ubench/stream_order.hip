@@ -66,6 +66,11 @@ int main(int argc, char **argv) {
         hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming);
         for (int i = 0; !stop.load(); ++i) {
             hipStream_t w = ws[i & 3];
+            if (with_wait >= 5) {            // 5: the worker also launches kernels and chains its streams with events
+                hipLaunchKernelGGL(spin, dim3(8), dim3(256), 0, w, sink, 500);
+                hipEventRecord(e, w);
+                hipStreamWaitEvent(ws[(i + 1) & 3], e, 0);
+            }
             hipMemcpyAsync(h, d, 1 << 20, hipMemcpyDeviceToHost, w);
             hipEventRecord(e, w);
             hipStreamSynchronize(w);
