@@ -76,6 +76,15 @@ def build_harness(cc, force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    # tools/rt_inflight: bench.py's frames-in-flight loop as a native host program (HIP only for the final wait)
+    src2 = os.path.join(root, "tools", "rt_inflight.cpp")
+    exe2 = os.path.join(HERE, "rt_inflight")
+    if force or _stale(exe2, [src2, OUT, os.path.join(root, "include", "rt_api.h")]):
+        cmd = [cc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src2, "-o", exe2,
+               "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return exe
 
 
