@@ -65,6 +65,14 @@ def write_ppm(path, pixels, w, h):
         f.write(np.ascontiguousarray(rgb).tobytes())
 
 
+def write_png(path, pixels, w, h):
+    """PNG of a packed pixel buffer (rows flipped like write_ppm).  Needs Pillow."""
+    from PIL import Image
+    px = np.ascontiguousarray(pixels, dtype=np.uint32).reshape(h, w)
+    rgb = np.ascontiguousarray(px.view(np.uint8).reshape(h, w, 4)[::-1, :, :3])
+    Image.fromarray(rgb, "RGB").save(path)
+
+
 def psnr(a_pix, b_pix):
     a = np.ascontiguousarray(a_pix, dtype=np.uint32).view(np.uint8).reshape(-1, 4)[:, :3].astype(np.float64)
     b = np.ascontiguousarray(b_pix, dtype=np.uint32).view(np.uint8).reshape(-1, 4)[:, :3].astype(np.float64)

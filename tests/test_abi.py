@@ -129,6 +129,16 @@ def test_scene_reader_equals_reference_loader_on_shipped_scenes():
         assert go == wo and gt == wt
 
 
+def test_png_writer_equals_ppm_writer(tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    px = (np.arange(7 * 5, dtype=np.uint32) * 2654435761 % (1 << 24)).astype(np.uint32)
+    host.write_png(str(tmp_path / "a.png"), px, 7, 5)
+    host.write_ppm(str(tmp_path / "a.ppm"), px, 7, 5)
+    png = np.asarray(PIL.open(str(tmp_path / "a.png")).convert("RGB"))
+    ppm = np.frombuffer(open(tmp_path / "a.ppm", "rb").read()[len(b"P6\n7 5\n255\n"):], np.uint8).reshape(5, 7, 3)
+    assert np.array_equal(png, ppm)
+
+
 def test_ppm_writer_flips_rows(tmp_path):
     px = np.arange(6, dtype=np.uint32).reshape(3, 2)      # row 0 = bottom
     host.write_ppm(tmp_path / "a.ppm", px, 2, 3)
