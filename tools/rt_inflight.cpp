@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     const int F = argc > 1 ? atoi(argv[1]) : 2, frames = argc > 2 ? atoi(argv[2]) : 40;
     const int w = argc > 5 ? atoi(argv[3]) : 1920, h = argc > 5 ? atoi(argv[4]) : 1080, spp = argc > 5 ? atoi(argv[5]) : 64;
     const bool fast = argc > 6 && !strcmp(argv[6], "fast");
+    const int raw_mode = (argc > 6 && argv[6][0] >= '0' && argv[6][0] <= '9') ? atoi(argv[6]) : -1;   // 100+k / 200+k: A/B instances
     rt_sphere sph[6];
     if (rt_demo_scene(sph, 6) != 6) return 1;
     rt_camera cam{};
@@ -27,7 +28,7 @@ int main(int argc, char** argv) {
     std::vector<rt_ctx*> ctx(F, nullptr);
     for (auto& c : ctx) {
         if (rt_create(&c, w, h) != RT_OK || rt_set_scene(c, sph, 6) != RT_OK || rt_set_camera(c, &cam) != RT_OK ||
-            rt_set_mode(c, fast ? RT_MODE_FAST : RT_MODE_PARITY) != RT_OK) {
+            rt_set_mode(c, raw_mode >= 0 ? raw_mode : (fast ? RT_MODE_FAST : RT_MODE_PARITY)) != RT_OK) {
             fprintf(stderr, "setup failed: %s\n", rt_last_error());
             return 1;
         }
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
     const double rays = (double)(st.samples + st.shadow_rays);
     printf("{\"frames_in_flight\": %d, \"frames\": %d, \"w\": %d, \"h\": %d, \"spp\": %d, \"mode\": \"%s\", \"ms_per_frame\": %.4f, "
            "\"Mray_s_primary_shadow\": %.1f, \"frame_checksum\": \"%016llx\"}\n",
-           F, frames, w, h, spp, fast ? "fast" : "parity", ms / frames, rays * frames / (ms * 1e3), sum);
+           F, frames, w, h, spp, raw_mode >= 0 ? argv[6] : (fast ? "fast" : "parity"), ms / frames, rays * frames / (ms * 1e3), sum);
     for (auto c : ctx) rt_destroy(c);
     return 0;
 }
