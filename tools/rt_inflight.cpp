@@ -14,6 +14,8 @@
 
 #include "rt_api.h"
 
+extern "C" int rt_debug_set_regen_gate(rt_ctx*, int);     // diagnostic knob of the library (not in the public header)
+
 int main(int argc, char** argv) {
     const int F = argc > 1 ? atoi(argv[1]) : 2, frames = argc > 2 ? atoi(argv[2]) : 40;
     const int w = argc > 5 ? atoi(argv[3]) : 1920, h = argc > 5 ? atoi(argv[4]) : 1080, spp = argc > 5 ? atoi(argv[5]) : 64;
@@ -32,6 +34,7 @@ int main(int argc, char** argv) {
             fprintf(stderr, "setup failed: %s\n", rt_last_error());
             return 1;
         }
+        if (const char* g = getenv("RT_GATE")) rt_debug_set_regen_gate(c, atoi(g));
     }
     auto frame = [&](int k) {
         rt_ctx* c = ctx[k % F];
