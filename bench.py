@@ -167,6 +167,9 @@ def main():
     if world > 1:
         gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=2 * F)
         torch.cuda.synchronize()        # its zero-fills ran on torch's stream; the contexts' streams are non-blocking
+        gather.gather(0)                # plumbing, not a step: RCCL builds its communicator and point-to-point
+        torch.cuda.synchronize()        # channels on first use (seconds); keep that out of the timed region even with --warmup 0
+        dist.barrier()
     frame_no = [0]
 
     def step(in_flight, ev=None, do_gather=True):
