@@ -51,7 +51,20 @@ void HipConfig::updateCamera() {                         // OpenCLConfig.cpp:386
     if (rt_set_camera(ctx, &c) != RT_OK) die("Failed to set the camera");
 }
 
-unsigned* HipConfig::getPixels() { return pPixels; }
+// The reference copies the frame out after every pass, so its getPixels() always names the latest frame
+// (OpenCLConfig.cpp:498-512).  Here passes between two display copies are only queued: a caller that asks
+// for the pixels gets them brought up to date first -- rt_read_pixels waits for the queued passes, packs the
+// frame from the running average if their pixel stores were skipped, and copies it.  (The GLUT flow asks
+// once, before the first frame, SetupGL.cpp:85; hosts that render N passes and then read, like
+// oracle/ref_host_main.cpp, get the N-pass frame.)  The address stays the same for the life of the object.
+unsigned* HipConfig::getPixels() {
+    std::lock_guard<std::mutex> lock(guard);
+    if (stale) {
+        if (rt_read_pixels(ctx, reinterpret_cast<uint32_t*>(pPixels)) != RT_OK) die("Failed to read the frame back");
+        stale = false;
+    }
+    return pPixels;
+}
 
 void HipConfig::setArguments() {}                        // OpenCLConfig.cpp:517-611
 
@@ -63,6 +76,7 @@ void HipConfig::setArguments() {}                        // OpenCLConfig.cpp:517
 // between are only queued (rt_render_async on the context's stream); the copy that is due waits for
 // them, which also bounds the queue to readbackMs of work.
 void HipConfig::execute() {                              // OpenCLConfig.cpp:407-515
+    std::lock_guard<std::mutex> lock(guard);
     const auto now = std::chrono::steady_clock::now();
     const bool due = mCurrentSample == 0 || readbackMs <= 0.0 ||
                      std::chrono::duration<double, std::milli>(now - lastReadback).count() >= readbackMs;
@@ -70,5 +84,6 @@ void HipConfig::execute() {                              // OpenCLConfig.cpp:407
     const int rc = due ? rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), 1)
                        : rt_render_async(ctx, 1, rt_stream(ctx));
     if (rc != RT_OK) die("Failed to render a pass");
+    stale = !due;
     if (due) lastReadback = now;
 }

@@ -8,6 +8,7 @@
 #define HIP_CONFIG_HPP
 
 #include <chrono>
+#include <mutex>
 #include <memory>      // the factory (Config.cpp) uses std::make_unique / std::runtime_error and gets
 #include <stdexcept>   // them from the OpenCL / Cm headers today; with only this backend enabled, from here
 #include <vector>
@@ -41,6 +42,8 @@ private:
     Camera camera{};
     double readbackMs = 8.0;        // copy the frame to pPixels when it is this old (0 = every pass)
     std::chrono::steady_clock::time_point lastReadback{};
+    bool stale = false;             // passes have run since pPixels was last brought up to date
+    std::mutex guard;               // execute() runs on the compute thread, getPixels() on the caller's (Main.cpp:96-106)
 };
 
 #endif

@@ -22,6 +22,14 @@
 extern "C" {
 #endif
 
+/* The library is built with hidden visibility: exactly the functions declared in this header
+ * (and, in the diagnostics build librt_hip_diag.so, in rt_debug.h) are exported.               */
+#if defined(RT_BUILDING_LIBRARY)
+#define RT_API __attribute__((visibility("default")))
+#else
+#define RT_API
+#endif
+
 /* ---- data layouts: identical, byte for byte, to the reference's host structs ---------- */
 typedef struct { float x, y, z; } rt_vec3;                /* include/Vec.hpp:10-34   (12 B) */
 
@@ -78,117 +86,164 @@ typedef struct rt_ctx rt_ctx;
  * Config::updateRendering() [Config.cpp:73-81], after which `out` holds what getPixels()
  * returns: out[y*w+x] = R | G<<8 | B<<16, row 0 = bottom of the image (.cl:594-596).
  * `cam` carries dir/x/y already computed by the host (Utility.cpp:71-85).
- * `out` is a host buffer of w*h uint32.  Parity mode, device 0, blocking.                    */
-int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w, int h, int spp);
+ * `out` is a host buffer of w*h uint32.  Parity mode, device 0, blocking.
+ * The library keeps the device state of the last few (w, h) it was called with -- buffers, the
+ * device-resident default seed stream, page-locked staging for the read-back -- so that a host
+ * which calls rt_render per frame pays for them once; rt_release_cache() frees it.
+ * Thread-safe (calls are serialised inside).                                                  */
+RT_API int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w, int h, int spp);
+RT_API void rt_release_cache(void);
 
 /* ---- progressive interface: one context = one OpenCLConfigBuffer ------------------------ */
 
 /* ctor + allocateBuffer (OpenCLConfig.cpp:398-400, 613-682): device buffers for colours
  * (12 B/px), seeds (8 B/px, initialised to the default stream) and pixels (4 B/px).         */
-int rt_create(rt_ctx **out, int w, int h);
+RT_API int rt_create(rt_ctx **out, int w, int h);
+
+/* one context that renders on `ngpus` devices of this process (HIP devices
+ * 0..ngpus-1; rt_create_multi_on names them).  The image is sharded by interleaved row tiles of
+ * `tile_rows` rows (tile t -> device t % ngpus; 0 = the default of 8), every device renders its rows
+ * on its own stream, and each frame ends with ONE gather to the first device over RCCL
+ * (ncclGroupStart; root: ncclRecv x (n-1); others: ncclSend; ncclGroupEnd; ncclUint32), a
+ * de-interleave kernel there and one copy to the host.  Every other call of this header works on
+ * such a context as on a plain one and means the whole image: rt_render_pass returns all h rows,
+ * rt_get_stats sums the devices, rt_read_colors / rt_read_seeds merge them.  Results are bit-identical
+ * to a one-device context.  ngpus = 1 runs the same code (a communicator of one).
+ * rt_create_multi_on with a device listed more than once is the one-GPU rehearsal of the same
+ * path: RCCL refuses two ranks on one device, so the transfers into the root's receive slots are
+ * device-to-device copies there; everything else (shards, slots, de-interleave) is unchanged.  */
+RT_API int rt_create_multi(rt_ctx **out, int w, int h, int ngpus);
+RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, int ngpus, int tile_rows);
+RT_API int rt_shard_count(const rt_ctx *ctx);                     /* 1 for a plain context        */
 
 /* Same, on HIP device `device`, rendering only the row tiles this rank owns: tile t (rows
  * [t*tile_rows, (t+1)*tile_rows)) belongs to rank t % nranks.  tile_rows must be a positive
  * multiple of 8.  The rank's rows are packed in order into a local pixel buffer of
  * rt_local_rows() rows (interleaved row tiles).  nranks = 1 is rt_create().       */
-int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nranks,
-                      int tile_rows);
+RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nranks,
+                             int tile_rows);
 
-void rt_destroy(rt_ctx *ctx);                              /* freeBuffer, :684-717            */
+RT_API void rt_destroy(rt_ctx *ctx);                              /* freeBuffer, :684-717            */
 
-/* sceneSetup (:720-747) + the per-pass sphere upload (:450).  Copies; caller keeps `spheres`. */
-int rt_set_scene(rt_ctx *ctx, const rt_sphere *spheres, uint32_t count);
+/* sceneSetup (:720-747) + the per-pass sphere upload (:450).  Copies; caller keeps `spheres`.
+ * The 44-byte records go to the device as they are and a small kernel there builds the tables the
+ * render kernel reads (centre | radius^2, emission | material, colour | radius, and the light list
+ * SampleLights walks, with 4*pi*radius^2 -- all in binary32, the reference's own operations).
+ * Ordered after every launch issued on this context; no device-wide synchronisation.  A refused
+ * scene (bad arguments, too large) leaves the previous one in place.                                                         */
+RT_API int rt_set_scene(rt_ctx *ctx, const rt_sphere *spheres, uint32_t count);
+
+/* Device-resident scene update: replace spheres [first, first+count) of the scene set
+ * by rt_set_scene -- moving spheres, changed materials, lights switched on or off -- without a
+ * host wait: the records are staged through page-locked memory, copied and the tables rebuilt by the
+ * device-side kernel, all asynchronously on `hip_stream` (a hipStream_t; NULL = the default stream, as
+ * for rt_render_async); launches issued later on this context see the new scene.  The sphere count does not
+ * change.  `spheres` may be reused as soon as the call returns.                                 */
+RT_API int rt_update_spheres_async(rt_ctx *ctx, uint32_t first, uint32_t count, const rt_sphere *spheres,
+                                   void *hip_stream);
 
 /* updateCamera's result + the per-pass camera upload (:418).  dir/x/y must be filled in.     */
-int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
+RT_API int rt_set_camera(rt_ctx *ctx, const rt_camera *cam);
 
-int rt_set_mode(rt_ctx *ctx, int mode);                    /* enum rt_mode; default parity    */
+RT_API int rt_set_mode(rt_ctx *ctx, int mode);                    /* enum rt_mode; default parity    */
 
 /* Back to pass 0: mCurrentSample = 0, seeds = default stream, counters cleared.              */
-int rt_reset(rt_ctx *ctx);
+RT_API int rt_reset(rt_ctx *ctx);
 
 /* rt_reset() without a host round trip: the next launch starts from a device-resident copy of
  * the default stream (read in place, nothing is copied) and the counters are cleared by a small
- * kernel on `hip_stream`.  (The colour plane needs no clearing: pass 0 overwrites it,
- * .cl:580-582.)                                                                              */
-int rt_reset_async(rt_ctx *ctx, void *hip_stream);
+ * kernel on `hip_stream`.  The colour plane and the packed pixels are NOT cleared (pass 0 overwrites
+ * every pixel, .cl:580-582): until the next launch rt_read_colors / rt_read_pixels still return the
+ * previous frame, rt_read_seeds the default stream.  The launch counter and last_kernel_ms restart.
+ * Like every call on a context it must not race with other calls on the same context.        */
+RT_API int rt_reset_async(rt_ctx *ctx, void *hip_stream);
 
 /* `n_samples` x { setArguments(); execute(); ++mCurrentSample; } (Config.cpp:73-81) as ONE
  * launch that keeps seeds and the running average in registers, then one D2H copy of the
  * pixel buffer into `out_host` (the full image for an unsharded context, the local rows for
  * a sharded one).  out_host may be NULL to skip the copy.  Blocking.                         */
-int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
+RT_API int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
 
 /* Page-lock the host buffer that rt_render_pass copies into (the host's `pPixels`,
  * OpenCLConfig.cpp:618-621), so the per-pass readback of the reference's display loop
  * (clEnqueueReadBuffer after every pass, OpenCLConfig.cpp:498-512) runs at the full PCIe rate
  * instead of through a pageable staging copy.  `count` uint32 from `out_host` must stay valid
  * and at the same address until rt_pin_output(ctx, NULL, 0) or rt_destroy.  Optional.        */
-int rt_pin_output(rt_ctx *ctx, uint32_t *out_host, size_t count);
+RT_API int rt_pin_output(rt_ctx *ctx, uint32_t *out_host, size_t count);
 
 /* enable = 0: later launches advance seeds and the running average but leave the packed pixel
  * buffer alone (no toInt, .cl:34,594-596, and no pixel store) -- for passes whose frame nobody
  * will look at; the next launch with enable = 1 writes every pixel of its frame from the running
  * average, so nothing is lost.  Default 1.                                                    */
-int rt_set_pixel_write(rt_ctx *ctx, int enable);
+RT_API int rt_set_pixel_write(rt_ctx *ctx, int enable);
+
+/* getPixels() for hosts that skip pixel stores: brings the packed frame up to date -- if the last
+ * launches ran with the pixel store off, a small kernel packs the frame from the running average
+ * (same toInt, .cl:34,594-596) -- and copies it to `out_host` (local rows x w uint32).  Waits for
+ * the launches issued on this context.                                                        */
+RT_API int rt_read_pixels(rt_ctx *ctx, uint32_t *out_host);
 
 /* Same launch, asynchronous on `hip_stream` (a hipStream_t, NULL = default stream), no copy
  * and no synchronisation: the caller orders later work on that stream.                       */
-int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);
+RT_API int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);
 
 /* The context's own non-blocking stream (a hipStream_t), the one rt_render_pass uses.  With
  * several contexts in flight, rt_render_async(ctx, n, rt_stream(ctx)) runs each on its own.
  * HIP gives a process GPU_MAX_HW_QUEUES hardware queues (default 4) and lets further streams
  * share them: two contexts on one queue do not overlap at all, so a host that keeps F contexts
  * in flight should start with GPU_MAX_HW_QUEUES >= the number of streams it uses (bench.py: 24). */
-void *rt_stream(rt_ctx *ctx);
+RT_API void *rt_stream(rt_ctx *ctx);
 
 /* Device address and element count (uint32) of the local pixel buffer.                       */
-int rt_device_pixels(rt_ctx *ctx, void **dptr, size_t *count);
+RT_API int rt_device_pixels(rt_ctx *ctx, void **dptr, size_t *count);
 
 /* Redirect the packed pixels of later launches into a caller-owned DEVICE buffer of at least
  * rt_local_rows()*w uint32 (e.g. the send buffer of the frame-end gather, so no copy is needed);
  * NULL restores the context's own buffer.  The caller keeps the buffer alive and orders its
  * reuse against the launches it issued.                                                      */
-int rt_set_pixel_buffer(rt_ctx *ctx, void *dptr, size_t count);
+RT_API int rt_set_pixel_buffer(rt_ctx *ctx, void *dptr, size_t count);
 
-int rt_local_rows(const rt_ctx *ctx);                      /* rows this context renders       */
-int rt_current_sample(const rt_ctx *ctx);                  /* mCurrentSample                  */
+RT_API int rt_local_rows(const rt_ctx *ctx);                      /* rows this context renders       */
+RT_API int rt_current_sample(const rt_ctx *ctx);                  /* mCurrentSample                  */
 
 /* Copies of the reference's other two buffers, for parity checks: the colour plane
  * (3 floats/px, y-flipped as .cl:579 stores it) and the seed pairs, full image size; rows
  * this rank does not own keep their initial content.                                         */
-int rt_read_colors(rt_ctx *ctx, float *out_host);
-int rt_read_seeds(rt_ctx *ctx, uint32_t *out_host);
+RT_API int rt_read_colors(rt_ctx *ctx, float *out_host);
+RT_API int rt_read_seeds(rt_ctx *ctx, uint32_t *out_host);
 
-int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 
 /* Text of the calling thread's last failure ("" if none).                                    */
-const char *rt_last_error(void);
+RT_API const char *rt_last_error(void);
 
 /* ---- host-side helpers either side of the path ---------------------------- */
 
 /* computeCameraVariables, Utility.cpp:71-85 (Vec::norm's double sqrt, Vec.cpp:28-30).        */
-void rt_compute_camera(rt_camera *cam, int w, int h);
+RT_API void rt_compute_camera(rt_camera *cam, int w, int h);
 
 /* The seed initialisation of OpenCLConfig.cpp:676-680 without depending on the host libc:
  * glibc's never-seeded rand() stream restated, each value clamped to >= 2.                   */
-void rt_default_seeds(uint32_t *seeds, size_t count);
+RT_API void rt_default_seeds(uint32_t *seeds, size_t count);
 
 /* DemoSpheres, Scene.cpp:5-12.  Returns the sphere count (6), or -count if cap is smaller.   */
-int rt_demo_scene(rt_sphere *out, uint32_t cap);
+RT_API int rt_demo_scene(rt_sphere *out, uint32_t cap);
 
 /* readScene, Utility.cpp:90-160: "camera ox oy oz tx ty tz" / "size N" / N x "sphere rad
  * px py pz ex ey ez cx cy cz mat".  With reference_doubling != 0 the result is what the
  * reference's loader actually hands to the kernel: N value-initialised spheres followed by
  * the N parsed ones (:120,154).  Returns RT_OK and *count, or RT_ERR_ARG (rt_last_error).    */
-int rt_read_scene(const char *path, rt_sphere *out, uint32_t cap, uint32_t *count,
+RT_API int rt_read_scene(const char *path, rt_sphere *out, uint32_t cap, uint32_t *count,
                   rt_vec3 *orig, rt_vec3 *target, int reference_doubling);
 
-/* Device-side evaluation of the scalar building blocks, for unit parity tests:
- * op 0: sinf, 1: cosf, 2: pow(x, 1/2.2f), 3: 1/x, 4: sqrt(x), 5: toInt(x) (result as float),
- * 6/7: the kernel's branch-free sinf/cosf (x >= 0).                                           */
-int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n);
+/* ---- frame assembly on the gather root --------------------------------------
+ * De-interleave kernel: `gathered` holds the ranks' local pixel blocks one after another, rank r
+ * at gathered + r * pad_rows * w (its rows packed in order, as rt_create_sharded lays them out);
+ * full[y * w + x] = the pixel of image row y.  Both are DEVICE pointers on `device`; asynchronous
+ * on `hip_stream`.  Used by the in-library multi-GPU context and by process-per-GPU hosts after
+ * their own gather (bench.py: torch.distributed over RCCL).                                    */
+RT_API int rt_deinterleave_rows(uint32_t *full, const uint32_t *gathered, int w, int h, int nranks,
+                                int tile_rows, int pad_rows, int device, void *hip_stream);
 
 #ifdef __cplusplus
 }

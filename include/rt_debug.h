@@ -1,0 +1,62 @@
+/*
+ * rt_debug.h -- diagnostics interface of librt_hip_diag.so (the library built with
+ * -DRT_DIAGNOSTICS=1: every A/B and verification instance of the kernel, the exhaustive device-side
+ * checks of the lean square root / reciprocal, scheduling knobs, device wall-clock logs).
+ * NOT part of the drop-in boundary: librt_hip.so exports none of this.  Used by tests/ (parity of
+ * every instance, scalar building blocks) and tools/ (A/B timing, stress, timelines).
+ */
+#ifndef RT_DEBUG_H
+#define RT_DEBUG_H
+
+#include "rt_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* rt_set_mode() of the diagnostics library also accepts 100+k / 200+k: instance k of the parity /
+ * fast kernel tables (csrc/rt_kernel_parity.hip, rt_kernel_fast.hip).                          */
+RT_API int rt_debug_variant_count(int fast);
+
+/* Device-side evaluation of the scalar building blocks, for unit parity tests:
+ * op 0: sinf, 1: cosf, 2: pow(x, 1/2.2f), 3: 1/x, 4: sqrt(x), 5: toInt(x) (result as float),
+ * 6/7: the kernel's branch-free sinf/cosf (x >= 0), 8: the lean square root.                  */
+RT_API int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n);
+
+/* lean sqrt against the compiler's sqrtf over all 2^32 inputs; sphere test with the unchecked root
+ * against the one with sqrtf; candidate reciprocals per input exponent (out[4][256])          */
+RT_API long long rt_debug_sqrt_mismatches(void);
+RT_API long long rt_debug_hitpost_mismatches(void);
+RT_API int rt_debug_rcp_probe(unsigned long long *out1024);
+
+/* scheduling knobs (bit-invisible by test) */
+RT_API int rt_debug_set_regen_gate(rt_ctx *ctx, int gate);        /* 0 = automatic, 1 = free-running      */
+RT_API int rt_debug_set_mat_lds_limit(rt_ctx *ctx, int bytes);
+RT_API int rt_debug_set_persist(rt_ctx *ctx, int on);
+RT_API int rt_debug_set_ncus(rt_ctx *ctx, int n);
+RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
+
+/* raw diagnostic counters (section census of the stamped instances; valid after rt_get_stats) */
+RT_API int rt_debug_counters(rt_ctx *ctx, unsigned long long *out24);
+RT_API int rt_debug_counters_raw(rt_ctx *ctx, unsigned long long *out32);
+
+/* the reset this library used in round 1 (seed words restored by a copy on `hip_stream`, read back by
+ * the next launch) and a probe kernel that counts seed words differing from the default stream into
+ * counters[28] (probes run: [29]); both log their device wall-clock interval like the timelog instance */
+RT_API int rt_debug_reset_by_copy(rt_ctx *ctx, void *hip_stream, int use_memcpy);
+RT_API int rt_debug_probe_seeds(rt_ctx *ctx, void *hip_stream);
+
+/* Device wall-clock log (s_memrealtime, 100 MHz): `entries` records of 8 u64 {first start, last end,
+ * kind (1 render, 2 copy, 3 probe), user tag, stale words seen (probe), -, -, -}; every later launch of the timelog instance (mode 109) and every rt_debug_reset_by_copy /
+ * rt_debug_probe_seeds on this context takes the next record.  rt_debug_timelog_tag sets the tag
+ * stored with the following records (e.g. the frame number).  wave_entries > 0 also allocates a
+ * per-wavefront log {start, end, xcc << 32 | HW_ID} for launches of mode 109.                   */
+RT_API int rt_debug_timelog_enable(rt_ctx *ctx, uint32_t entries, uint32_t wave_entries);
+RT_API int rt_debug_timelog_tag(rt_ctx *ctx, unsigned long long tag);
+RT_API int rt_debug_timelog_read(rt_ctx *ctx, unsigned long long *out, uint32_t entries, uint32_t *used);
+RT_API int rt_debug_wavelog_read(rt_ctx *ctx, unsigned long long *out, uint32_t wave_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_DEBUG_H */

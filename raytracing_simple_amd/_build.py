@@ -1,6 +1,12 @@
-"""Build recipe of the gfx950 library (librt_hip.so): explicit hipcc commands, in-tree output.
+"""Build recipe of the gfx950 libraries: explicit hipcc commands, in-tree output.
 
-    python -m raytracing_simple_amd._build
+    python -m raytracing_simple_amd._build [--force]
+
+  librt_hip.so       the product: exactly the entry points of include/rt_api.h (hidden visibility for
+                     everything else) and only the kernel instances that ship
+  librt_hip_diag.so  the same sources with -DRT_DIAGNOSTICS=1: every A/B / verification instance, the
+                     exhaustive device-side checks, knobs and wall-clock logs of include/rt_debug.h
+                     (tests/ and tools/ only)
 
 The parity kernel translation unit and every host file are compiled with -ffp-contract=off;
 only rt_kernel_fast.hip is allowed to fuse.  Device code is generated for gfx950 only."""
@@ -8,23 +14,29 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librt_hip.so")
+OUT_DIAG = os.path.join(HERE, "librt_hip_diag.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fno-slp-vectorize",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+          "-fvisibility=hidden", "-DRT_BUILDING_LIBRARY=1",
           "-Wall", "-Wno-unused-function", "-Wno-sometimes-uninitialized", "-Wno-uninitialized"]
 UNITS = [
     # source, extra flags
     ("rt_kernel_parity.hip", ["-ffp-contract=off"]),
     ("rt_kernel_fast.hip", ["-ffp-contract=fast"]),
     ("rt_api.hip", ["-ffp-contract=off"]),
+    ("rt_multi.hip", ["-ffp-contract=off"]),
     ("rt_host.cpp", ["-ffp-contract=off"]),
 ]
-DEPS = ["rt_device.h", "rt_detmath.h", "rt_trace.inc.h", "rt_sched.inc.h", "rt_opts_reset.h", os.path.join("..", "..", "include", "rt_api.h")]
+DEPS = ["rt_device.h", "rt_internal.h", "rt_detmath.h", "rt_trace.inc.h", "rt_sched.inc.h", "rt_opts_reset.h",
+        os.path.join("..", "..", "include", "rt_api.h"), os.path.join("..", "..", "include", "rt_debug.h")]
 
 
 def hipcc():
@@ -41,50 +53,81 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build(force=False, verbose=False):
-    """Compile whatever is out of date and link librt_hip.so.  Returns its path."""
-    os.makedirs(OBJ, exist_ok=True)
-    cc = hipcc()
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def declared_symbols(*headers):
+    """Every rt_* function an include/ header declares (comments stripped)."""
+    import re
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def _version_script(path, headers):
+    """Linker version script: the export table is exactly what the headers declare (kernel stubs, HIP's
+    registration symbols and template instantiations of the C++ runtime stay local)."""
+    text = "{\n  global:\n" + "".join("    %s;\n" % n for n in declared_symbols(*headers)) + "  local: *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
+
+
+def _build_lib(cc, out, tag, defines, force, verbose, headers=("rt_api.h",)):
     deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
-    objs = []
+    jobs, objs = [], []
     for src, extra in UNITS:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJ, src + ".o")
+        op = os.path.join(OBJ, src + tag + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + deps):
-            cmd = [cc] + COMMON + extra + ["-c", sp, "-o", op]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
-    if force or _stale(OUT, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+            jobs.append([cc] + COMMON + defines + extra + ["-c", sp, "-o", op])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(lambda c: _run(c, verbose), jobs))
+    vs = _version_script(os.path.join(OBJ, "exports" + tag + ".map"), headers)
+    if force or _stale(out, objs + [vs]):
+        _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-Wl,--version-script=" + vs], verbose)
+    return out
+
+
+def build(force=False, verbose=False, diag=True):
+    """Compile whatever is out of date and link the libraries.  Returns the product library's path."""
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    _build_lib(cc, OUT, "", [], force, verbose)
+    if diag:
+        _build_lib(cc, OUT_DIAG, ".diag", ["-DRT_DIAGNOSTICS=1"], force, verbose, headers=("rt_api.h", "rt_debug.h"))
     build_harness(cc, force, verbose)
     return OUT
 
 
 def build_harness(cc, force=False, verbose=False):
-    """tools/rt_bench: the headless C++ host (the reference's Main.cpp without the window)."""
-    root = os.path.dirname(HERE)
-    src = os.path.join(root, "tools", "rt_bench.cpp")
+    """The native hosts on the C ABI: tools/rt_bench (the reference's Main.cpp without the window),
+    tools/rt_inflight (bench.py's frames-in-flight loop), tools/rt_view (the display component, built
+    only where freeglut's library exists -- its sources are syntax-checked by tests/test_adapter.py)."""
+    inc = "-I" + os.path.join(ROOT, "include")
+    link = ["-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
+    hdr = os.path.join(ROOT, "include", "rt_api.h")
+    src = os.path.join(ROOT, "tools", "rt_bench.cpp")
     exe = os.path.join(HERE, "rt_bench")
-    if force or _stale(exe, [src, OUT, os.path.join(root, "include", "rt_api.h")]):
-        cmd = [cc, "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-o", exe,
-               "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-    # tools/rt_inflight: bench.py's frames-in-flight loop as a native host program (HIP only for the final wait)
-    src2 = os.path.join(root, "tools", "rt_inflight.cpp")
+    if force or _stale(exe, [src, OUT, hdr]):
+        _run([cc, "-O2", "-std=c++17", inc, src, "-o", exe] + link, verbose)
+    src2 = os.path.join(ROOT, "tools", "rt_inflight.cpp")
     exe2 = os.path.join(HERE, "rt_inflight")
-    if force or _stale(exe2, [src2, OUT, os.path.join(root, "include", "rt_api.h")]):
-        cmd = [cc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src2, "-o", exe2,
-               "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+    if force or _stale(exe2, [src2, OUT, hdr]):
+        _run([cc, "--offload-arch=gfx950", "-O2", "-std=c++17", inc, src2, "-o", exe2] + link, verbose)
+    src3 = os.path.join(ROOT, "tools", "view_headless.cpp")
+    exe3 = os.path.join(HERE, "view_headless")
+    deps3 = [src3, OUT, hdr, os.path.join(ROOT, "adapter", "ProgressiveRenderer.hpp"), os.path.join(ROOT, "adapter", "FrameExchange.hpp")]
+    if force or _stale(exe3, deps3):
+        _run([cc, "-O2", "-std=c++17", "-pthread", inc, src3, "-o", exe3] + link, verbose)
     return exe
 
 

@@ -13,12 +13,20 @@ CAMERA_FLOATS = 15                                # rt_camera: orig,target,dir,x
 RT_MODE_PARITY, RT_MODE_FAST = 0, 1
 DIFF, SPEC, REFR = 0, 1, 2
 
-# every symbol include/rt_api.h declares (tests/test_abi.py checks the export table)
-SYMBOLS = ["rt_render", "rt_create", "rt_create_sharded", "rt_destroy", "rt_set_scene",
+# every symbol include/rt_api.h declares = the export table of librt_hip.so (tests/test_abi.py)
+SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_create_multi_on", "rt_shard_count",
+           "rt_create_sharded", "rt_destroy", "rt_set_scene", "rt_update_spheres_async",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
-           "rt_pin_output", "rt_set_pixel_write", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream", "rt_local_rows", "rt_current_sample", "rt_read_colors",
-           "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_compute_camera",
-           "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_debug_eval"]
+           "rt_pin_output", "rt_set_pixel_write", "rt_read_pixels", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream",
+           "rt_local_rows", "rt_current_sample", "rt_read_colors",
+           "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_deinterleave_rows", "rt_compute_camera",
+           "rt_default_seeds", "rt_demo_scene", "rt_read_scene"]
+# include/rt_debug.h: what librt_hip_diag.so exports on top of that
+DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
+                 "rt_debug_rcp_probe", "rt_debug_set_regen_gate", "rt_debug_set_mat_lds_limit", "rt_debug_set_persist",
+                 "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_counters", "rt_debug_counters_raw",
+                 "rt_debug_reset_by_copy", "rt_debug_probe_seeds", "rt_debug_timelog_enable", "rt_debug_timelog_tag",
+                 "rt_debug_timelog_read", "rt_debug_wavelog_read"]
 
 
 class RtError(RuntimeError):
@@ -40,27 +48,36 @@ class _Scene(C.Structure):
     _fields_ = [("spheres", C.c_void_p), ("count", C.c_uint32)]
 
 
-def lib_path():
-    return os.path.join(_HERE, "librt_hip.so")
+def lib_path(diag=False):
+    return os.path.join(_HERE, "librt_hip_diag.so" if diag else "librt_hip.so")
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
+def load_library(diag=False):
     """Load librt_hip.so (built in-tree by raytracing_simple_amd._build).  Raises if absent:
-    the HIP library IS the product, there is nothing to fall back to."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = lib_path()
+    the HIP library IS the product, there is nothing to fall back to.  diag=True loads the
+    diagnostics build instead (librt_hip_diag.so: include/rt_debug.h on top of the same ABI; tests and
+    tools only -- bench.py and the product paths never do)."""
+    if diag in _libs:
+        return _libs[diag]
+    path = lib_path(diag)
     if not os.path.exists(path):
         raise RtError(-2, f"{path} is not built; run `python -m raytracing_simple_amd._build` "
                           "(needs hipcc) -- there is no CPU fallback")
     lib = C.CDLL(path)
     vp, i32, u32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+    u64p = C.POINTER(C.c_ulonglong)
     sig = {
         "rt_render": (i32, [vp, vp, vp, i32, i32, i32]),
+        "rt_release_cache": (None, []),
+        "rt_create_multi": (i32, [C.POINTER(vp), i32, i32, i32]),
+        "rt_create_multi_on": (i32, [C.POINTER(vp), i32, i32, C.POINTER(i32), i32, i32]),
+        "rt_shard_count": (i32, [vp]),
+        "rt_update_spheres_async": (i32, [vp, u32, u32, vp, vp]),
+        "rt_read_pixels": (i32, [vp, vp]),
+        "rt_deinterleave_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "rt_create": (i32, [C.POINTER(vp), i32, i32]),
         "rt_create_sharded": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, i32]),
         "rt_destroy": (None, [vp]),
@@ -86,19 +103,39 @@ def load_library():
         "rt_default_seeds": (None, [vp, sz]),
         "rt_demo_scene": (i32, [vp, u32]),
         "rt_read_scene": (i32, [C.c_char_p, vp, u32, C.POINTER(u32), vp, vp, i32]),
-        "rt_debug_eval": (i32, [i32, vp, vp, sz]),
     }
+    if diag:
+        sig.update({
+            "rt_debug_variant_count": (i32, [i32]),
+            "rt_debug_eval": (i32, [i32, vp, vp, sz]),
+            "rt_debug_sqrt_mismatches": (C.c_longlong, []),
+            "rt_debug_hitpost_mismatches": (C.c_longlong, []),
+            "rt_debug_rcp_probe": (i32, [vp]),
+            "rt_debug_set_regen_gate": (i32, [vp, i32]),
+            "rt_debug_set_mat_lds_limit": (i32, [vp, i32]),
+            "rt_debug_set_persist": (i32, [vp, i32]),
+            "rt_debug_set_ncus": (i32, [vp, i32]),
+            "rt_debug_set_coop_min": (i32, [vp, i32]),
+            "rt_debug_counters": (i32, [vp, vp]),
+            "rt_debug_counters_raw": (i32, [vp, vp]),
+            "rt_debug_reset_by_copy": (i32, [vp, vp, i32]),
+            "rt_debug_probe_seeds": (i32, [vp, vp]),
+            "rt_debug_timelog_enable": (i32, [vp, u32, u32]),
+            "rt_debug_timelog_tag": (i32, [vp, C.c_ulonglong]),
+            "rt_debug_timelog_read": (i32, [vp, vp, u32, C.POINTER(u32)]),
+            "rt_debug_wavelog_read": (i32, [vp, vp, u32]),
+        })
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[diag] = lib
     return lib
 
 
-def _check(rc):
+def _check(rc, lib=None):
     if rc != 0:
-        raise RtError(rc, load_library().rt_last_error().decode(errors="replace"))
+        raise RtError(rc, (lib or load_library()).rt_last_error().decode(errors="replace"))
 
 
 def _ptr(a):
@@ -135,14 +172,26 @@ def render(spheres, cam, w, h, spp):
 
 
 class RtContext:
-    """One rt_ctx (= one OpenCLConfigBuffer of the reference)."""
+    """One rt_ctx (= one OpenCLConfigBuffer of the reference).
 
-    def __init__(self, w, h, device=0, rank=0, nranks=1, tile_rows=8):
-        self._lib = load_library()
+    devices=[...] makes it a multi-device context (rt_create_multi_on): the image sharded over those
+    HIP devices of this process, one RCCL gather per frame (a device listed twice = the one-GPU
+    rehearsal of that path).  diag=True binds the diagnostics library (tests / tools only)."""
+
+    def __init__(self, w, h, device=0, rank=0, nranks=1, tile_rows=8, devices=None, diag=False):
+        self._lib = load_library(diag)
         self._h = C.c_void_p()
         self.w, self.h = w, h
         self.rank, self.nranks, self.tile_rows = rank, nranks, tile_rows
-        _check(self._lib.rt_create_sharded(C.byref(self._h), w, h, device, rank, nranks, tile_rows))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            self._check(self._lib.rt_create_multi_on(C.byref(self._h), w, h, arr, len(devices), tile_rows))
+            self.rank, self.nranks = 0, 1           # the front of a multi-device context is the whole image
+        else:
+            self._check(self._lib.rt_create_sharded(C.byref(self._h), w, h, device, rank, nranks, tile_rows))
+
+    def _check(self, rc):
+        _check(rc, self._lib)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -164,17 +213,17 @@ class RtContext:
     # --- state ---------------------------------------------------------------------------
     def set_scene(self, spheres):
         sph = as_spheres(spheres)
-        _check(self._lib.rt_set_scene(self._h, _ptr(sph), len(sph)))
+        self._check(self._lib.rt_set_scene(self._h, _ptr(sph), len(sph)))
 
     def set_camera(self, cam):
         cam = as_camera(cam)
-        _check(self._lib.rt_set_camera(self._h, _ptr(cam)))
+        self._check(self._lib.rt_set_camera(self._h, _ptr(cam)))
 
     def set_mode(self, mode):
-        _check(self._lib.rt_set_mode(self._h, mode))
+        self._check(self._lib.rt_set_mode(self._h, mode))
 
     def reset(self):
-        _check(self._lib.rt_reset(self._h))
+        self._check(self._lib.rt_reset(self._h))
 
     @property
     def local_rows(self):
@@ -192,29 +241,45 @@ class RtContext:
             out = np.zeros(self.local_rows * self.w, np.uint32) if copy else None
         elif out.dtype != np.uint32 or out.size < self.local_rows * self.w or not out.flags.c_contiguous:
             raise ValueError("out must be a C-contiguous uint32 array of local_rows * w elements")
-        _check(self._lib.rt_render_pass(self._h, _ptr(out) if out is not None else None, n_samples))
+        self._check(self._lib.rt_render_pass(self._h, _ptr(out) if out is not None else None, n_samples))
         return out
 
     def set_pixel_write(self, enable):
-        _check(self._lib.rt_set_pixel_write(self._h, 1 if enable else 0))
+        self._check(self._lib.rt_set_pixel_write(self._h, 1 if enable else 0))
 
     def pin_output(self, out):
         """Page-lock `out` (the array later passed to render_pass(out=...)) for full-rate readback;
         None unpins.  The array must outlive the pin."""
         if out is None:
-            _check(self._lib.rt_pin_output(self._h, None, 0))
+            self._check(self._lib.rt_pin_output(self._h, None, 0))
         else:
-            _check(self._lib.rt_pin_output(self._h, _ptr(out), out.size))
+            self._check(self._lib.rt_pin_output(self._h, _ptr(out), out.size))
+
+    def read_pixels(self):
+        """rt_read_pixels: the up-to-date packed frame (packs it from the running average first if the
+        last launches ran with the pixel store off)."""
+        out = np.zeros(self.local_rows * self.w, np.uint32)
+        self._check(self._lib.rt_read_pixels(self._h, _ptr(out)))
+        return out
+
+    def update_spheres(self, first, spheres, stream=None):
+        """rt_update_spheres_async: replace spheres [first, first+len) of the current scene."""
+        sph = as_spheres(spheres)
+        self._check(self._lib.rt_update_spheres_async(self._h, first, len(sph), _ptr(sph), C.c_void_p(stream or 0)))
+
+    @property
+    def shard_count(self):
+        return self._lib.rt_shard_count(self._h)
 
     def reset_async(self, stream=None):
-        _check(self._lib.rt_reset_async(self._h, C.c_void_p(stream or 0)))
+        self._check(self._lib.rt_reset_async(self._h, C.c_void_p(stream or 0)))
 
     def render_async(self, n_samples, stream=None):
-        _check(self._lib.rt_render_async(self._h, n_samples, C.c_void_p(stream or 0)))
+        self._check(self._lib.rt_render_async(self._h, n_samples, C.c_void_p(stream or 0)))
 
     def set_pixel_buffer(self, dptr, count):
         """Later launches write their packed pixels to this device address (None = own buffer)."""
-        _check(self._lib.rt_set_pixel_buffer(self._h, C.c_void_p(dptr or 0), count))
+        self._check(self._lib.rt_set_pixel_buffer(self._h, C.c_void_p(dptr or 0), count))
 
     @property
     def stream(self):
@@ -223,7 +288,7 @@ class RtContext:
 
     def device_pixels(self):
         p, n = C.c_void_p(), C.c_size_t()
-        _check(self._lib.rt_device_pixels(self._h, C.byref(p), C.byref(n)))
+        self._check(self._lib.rt_device_pixels(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
     def device_pixels_array(self):
@@ -242,17 +307,17 @@ class RtContext:
 
     def read_colors(self):
         out = np.zeros(3 * self.w * self.h, np.float32)
-        _check(self._lib.rt_read_colors(self._h, _ptr(out)))
+        self._check(self._lib.rt_read_colors(self._h, _ptr(out)))
         return out
 
     def read_seeds(self):
         out = np.zeros(2 * self.w * self.h, np.uint32)
-        _check(self._lib.rt_read_seeds(self._h, _ptr(out)))
+        self._check(self._lib.rt_read_seeds(self._h, _ptr(out)))
         return out
 
     def stats(self):
         st = Stats()
-        _check(self._lib.rt_get_stats(self._h, C.byref(st)))
+        self._check(self._lib.rt_get_stats(self._h, C.byref(st)))
         return st.as_dict()
 
     # --- sharding helpers ---------------------------------------------------------------
@@ -269,9 +334,15 @@ def local_rows_of(h, rank, nranks, tile_rows):
     return np.asarray(rows, dtype=np.int64)
 
 
+def deinterleave_rows(full_ptr, gathered_ptr, w, h, nranks, tile_rows, pad_rows, device=0, stream=None):
+    """rt_deinterleave_rows on raw device pointers (the gather root's frame assembly)."""
+    _check(load_library().rt_deinterleave_rows(C.c_void_p(full_ptr), C.c_void_p(gathered_ptr), w, h, nranks, tile_rows,
+                                               pad_rows, device, C.c_void_p(stream or 0)))
+
+
 def debug_eval(op, values):
-    lib = load_library()
+    lib = load_library(diag=True)
     v = np.ascontiguousarray(values, dtype=np.float32)
     out = np.zeros_like(v)
-    _check(lib.rt_debug_eval(op, _ptr(v), _ptr(out), v.size))
+    _check(lib.rt_debug_eval(op, _ptr(v), _ptr(out), v.size), lib)
     return out

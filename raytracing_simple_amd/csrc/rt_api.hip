@@ -2,20 +2,32 @@
 // (SimpleRT/src/OpenCLConfig.cpp:398-747) re-done for one MI355X: device buffers, scene
 // tables, launch geometry, row-tile sharding, counters.  No CPU fallback: without a HIP
 // device every entry point fails with RT_ERR_NO_DEVICE.
+//
+// Ordering rule of this file: ALL device work of one context -- launches, resets, scene updates,
+// read-backs -- executes in the order the calls were made, whatever streams the caller passes:
+// when a call uses another stream than the context's previous piece of work, the library records an
+// event on the previous stream and makes the new one wait for it (chain()).  Nothing here uses the
+// null stream or a device-wide synchronisation.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
-#include "rt_device.h"
+#include "rt_internal.h"
+
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
+#endif
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace rt {
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -23,79 +35,103 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace rt
 
-#define HIP_TRY(call)                                                                       \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                                \
-    } while (0)
-
-}  // namespace
+using rt::fail;
 
 // rt_reset_async zeroes the work counters with a kernel on the caller's stream and restores NO seeds:
-// the next launch reads the pristine default stream directly (LaunchParams::seeds_in).  Reason: in
-// the multi-rank frame loop (tools/gather_stress.py: 4 processes sharing one GPU, 6 streams each, a
-// torch.distributed collective per frame) about one frame in a thousand was rendered from seeds that
-// the reset issued just before it ON THE SAME STREAM -- a device-to-device copy at first, then a copy
-// kernel -- had not restored yet: every wrong pixel equalled the frame computed from un-reset seeds,
-// and a probe kernel placed between reset and launch (RT_PROBE=1) saw whole workgroups' worth of
-// un-restored seed words.  It needs the collective's worker in the process: the same loop without
-// the gather, with several host threads, or as pure HIP (tools/ubench/stream_order.hip: dependent
-// kernels, events, waits, a copying worker thread, 4-6 processes) never showed it, so the cause is
-// not pinned down.  A frame that starts from data nobody writes cannot lose that race.
+// the next launch reads the pristine default stream directly (LaunchParams::seeds_in).
 __global__ void rt_zero_counters_kernel(unsigned long long *counters, unsigned long long *stats) {
     for (int i = threadIdx.x; i < 32; i += blockDim.x) counters[i] = 0ull;
     for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) stats[i] = 0ull;
 }
 
-// diagnostic only (rt_debug_reset_by_copy): the reset this library used before -- a copy kernel that
-// restores the seed words, which the next launch then reads back
-__global__ void rt_debug_copy_seeds_kernel(uint32_t *seeds, const uint32_t *seeds0, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) seeds[i] = seeds0[i];
+// Scene tables from the raw 44-byte records (rt_set_scene / rt_update_spheres_async), ONE workgroup:
+//   geom[i]   = { p, rad*rad }               .cl:184      emis[i] = { e, bits(refl) }
+//   colr[i]   = { c, rad }
+//   lightA[j] = { p, rad }, lightB[j] = { e, 4*pi*rad*rad }   for the j-th sphere, in scene order, that
+//   passes the reference's zero test (.cl:135-138: x and z only) -- the list SampleLights walks (.cl:249-303).
+// Binary32, one operation per source operation (this file is compiled -ffp-contract=off): the same bits
+// as the reference's `rad * rad` and `4.f * FLOAT_PI * rad * rad` (.cl:297) evaluated per use.
+__global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *sph, uint32_t n, float4 *geom, float4 *emis,
+                                                              float4 *colr, float4 *la, float4 *lb, uint32_t *n_lights_out) {
+    __shared__ uint32_t s_wave_count[4];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        bool light = false;
+        float rad = 0.f, px = 0.f, py = 0.f, pz = 0.f, ex = 0.f, ey = 0.f, ez = 0.f;
+        if (i < n) {
+            const float *r = reinterpret_cast<const float *>(sph + i);      // 11 dwords: rad, p, e, c, refl
+            rad = r[0]; px = r[1]; py = r[2]; pz = r[3]; ex = r[4]; ey = r[5]; ez = r[6];
+            geom[i] = make_float4(px, py, pz, rad * rad);
+            emis[i] = make_float4(ex, ey, ez, r[10]);                        // refl keeps its bits
+            colr[i] = make_float4(r[7], r[8], r[9], rad);
+            light = !((ex == 0.f) && (ez == 0.f));
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(light);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if ((tid & 63) == 0) s_wave_count[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (int k = 0; k < wave; ++k) off += s_wave_count[k];
+        if (light) {
+            la[off + before] = make_float4(px, py, pz, rad);
+            lb[off + before] = make_float4(ex, ey, ez, 4.f * 3.14159265358979323846f * rad * rad);
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+        __syncthreads();
+    }
+    if (tid == 0) *n_lights_out = s_base;
 }
 
-__global__ void rt_debug_probe_seeds_kernel(const uint32_t *seeds, const uint32_t *seeds0, size_t n, unsigned long long *out) {
+// rt_deinterleave_rows: full[y] = row (t/n)*tile_rows + y%tile_rows of rank t%n's block, t = y/tile_rows.
+// One thread per 16 bytes where the row length allows it (w % 4 == 0 keeps every row 16-byte aligned).
+__global__ void __launch_bounds__(256) rt_deinterleave_kernel(uint32_t *__restrict__ full, const uint32_t *__restrict__ gathered, int w,
+                                                              int h, int nranks, int tile_rows, int pad_rows, int vec) {
+    const int per_row = vec ? w / 4 : w;
+    const size_t total = (size_t)per_row * (size_t)h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)per_row), xq = (int)(i - (size_t)y * (size_t)per_row);
+        const int t = y / tile_rows, r = t % nranks, lrow = (t / nranks) * tile_rows + (y - t * tile_rows);
+        const size_t src = ((size_t)r * (size_t)pad_rows + (size_t)lrow) * (size_t)w, dst = (size_t)y * (size_t)w;
+        if (vec)
+            reinterpret_cast<uint4 *>(full + dst)[xq] = reinterpret_cast<const uint4 *>(gathered + src)[xq];
+        else
+            full[dst + xq] = gathered[src + xq];
+    }
+}
+
+#if RT_DIAGNOSTICS
+// diagnostic only (rt_debug_reset_by_copy): the reset this library used in round 1 -- a copy kernel that
+// restores the seed words, which the next launch then reads back
+__global__ void rt_debug_copy_seeds_kernel(uint32_t *seeds, const uint32_t *seeds0, size_t n, unsigned long long *tl,
+                                           unsigned long long tag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (tl && threadIdx.x == 0) atomicMin(&tl[0], t0);
+    if (tl && threadIdx.x == 0 && blockIdx.x == 0) { tl[2] = 2ull; tl[3] = tag; }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) seeds[i] = seeds0[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tl && threadIdx.x == 0) atomicMax(&tl[1], __builtin_amdgcn_s_memrealtime());
+}
+
+__global__ void rt_debug_probe_seeds_kernel(const uint32_t *seeds, const uint32_t *seeds0, size_t n, unsigned long long *out,
+                                            unsigned long long *tl, unsigned long long tag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (tl && threadIdx.x == 0) atomicMin(&tl[0], t0);
+    if (tl && threadIdx.x == 0 && blockIdx.x == 0) { tl[2] = 3ull; tl[3] = tag; }
     unsigned long long b = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b += (seeds[i] != seeds0[i]);
     if (b) atomicAdd(out, b);
+    if (b && tl) atomicAdd(&tl[4], b);                                      // stale words seen by THIS probe
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 1, 1ull);     // probes run
+    if (tl && threadIdx.x == 0) atomicMax(&tl[1], __builtin_amdgcn_s_memrealtime());
 }
-
-struct rt_ctx {
-    int device = 0;
-    int w = 0, h = 0;
-    int rank = 0, nranks = 1, tile_rows = 8, local_rows = 0;
-    uint32_t *d_seeds = nullptr;
-    uint32_t *d_seeds0 = nullptr;  // pristine default stream, for device-side resets
-    float *d_colors = nullptr;
-    uint32_t *d_pixels = nullptr;
-    uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
-    void *pinned_out = nullptr;         // host buffer page-locked by rt_pin_output, or null
-    int pixel_write = 1;                // rt_set_pixel_write
-    bool seeds_default = false;         // after rt_reset_async: the next launch reads the pristine stream
-    unsigned long long *d_counters = nullptr;
-    unsigned long long *d_stats = nullptr;      // rt::kStatReplicas x 8 partial work counters
-    float4 *d_tables = nullptr;   // geom | emis | colr | lightA | lightB, one allocation
-    size_t tables_cap = 0;        // in float4
-    rt::SceneTables scene{};
-    rt_camera cam{};
-    bool have_scene = false, have_cam = false;
-    int mode = RT_MODE_PARITY;
-    int regen_gate = 0;           // 0 = choose from the scene size
-    int mat_lds_limit = 24 * 1024;
-    int coop_min = 12;
-    int persist = 0;              // persistent-wavefront instances (tile queue + per-lane pixel hand-out)
-    int n_cus = 256;
-            // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
-    int current_sample = 0;
-    uint64_t launches = 0;
-    double last_ms = 0.0;
-    unsigned long long debug_counters[24] = {};   // diagnostic instances only
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
+#endif
 
 namespace {
 
@@ -104,32 +140,46 @@ int select_device(const rt_ctx *c) {
     return RT_OK;
 }
 
-// Everything the context does to its own buffers goes through its own stream: that stream is
-// non-blocking, so work put on the null stream (hipMemset, device-to-device hipMemcpy: both return
-// before they have run) would not be ordered against the launches that follow -- under load from
-// other host threads a frame could start on seeds and counters that were still being reset.
+// the context's work runs in issue order: `stream` waits for whatever the context queued last elsewhere
+int chain(rt_ctx *c, hipStream_t stream) {
+    if (c->last_stream != stream) {
+        HIP_TRY(hipEventRecord(c->ev_dep, c->last_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, c->ev_dep, 0));
+        c->last_stream = stream;
+        if (stream != c->stream) c->used_foreign_stream = true;
+    }
+    return RT_OK;
+}
+
+// host waits for everything the context has queued
+int wait_all(rt_ctx *c) {
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    return RT_OK;
+}
+
 int upload_default_seeds(rt_ctx *c) {
     const size_t count = 2 * (size_t)c->w * (size_t)c->h;
     std::vector<uint32_t> host(count);
     rt_default_seeds(host.data(), count);
     HIP_TRY(hipMemcpyAsync(c->d_seeds0, host.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_colors, 0, 3 * (size_t)c->w * (size_t)c->h * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));          // `host` goes out of scope; rt_create / rt_reset are blocking calls
+    HIP_TRY(hipStreamSynchronize(c->stream));          // `host` goes out of scope
     return RT_OK;
 }
 
-int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
-    if (!c->have_scene || !c->have_cam)
-        return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
-    if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
-    if (n_samples > 0x7fffffff - c->current_sample)
-        return fail(RT_ERR_ARG, "pass counter would overflow (%d + %d)", c->current_sample, n_samples);
-    if (n_samples == 0 || c->local_rows == 0) return RT_OK;
+int restore_state(rt_ctx *c) {                          // rt_create / rt_reset: blocking
+    int rc = chain(c, c->stream);
+    if (rc != RT_OK) return rc;
+    const size_t px = (size_t)c->w * (size_t)c->h;
+    HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * px * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_colors, 0, 3 * px * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
 
+rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
     rt::LaunchParams p{};
     p.scene = c->scene;
     p.cam = c->cam;
@@ -151,6 +201,22 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.inv_w = 1.f / (float)c->w;          // correctly rounded on the host as on the device (-ffp-contract=off, IEEE division)
     p.inv_h = 1.f / (float)c->h;
     p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
+    p.tiles_x = (c->w + 7) / 8;
+    p.n_tiles = p.tiles_x * ((c->local_rows + 7) / 8);
+    return p;
+}
+
+int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
+    if (!c->have_scene || !c->have_cam)
+        return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
+    if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
+    if (n_samples > 0x7fffffff - c->current_sample)
+        return fail(RT_ERR_ARG, "pass counter would overflow (%d + %d)", c->current_sample, n_samples);
+    if (n_samples == 0 || c->local_rows == 0) return RT_OK;
+    int rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+
+    rt::LaunchParams p = make_params(c, n_samples);
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     // materials ride along in LDS only while that keeps at least 6 workgroups per CU resident
     // (160 KiB / 24 KiB); larger scenes read them from L2 once per hit
@@ -161,9 +227,8 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
               (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
     hipError_t e;
     const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+#if RT_DIAGNOSTICS
     const bool persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
-    p.tiles_x = (c->w + 7) / 8;
-    p.n_tiles = p.tiles_x * ((c->local_rows + 7) / 8);
     if (persist) {
         // just enough workgroups to fill the machine; the tile queue (counters[30]) does the rest
         size_t per_cu = lds > 0 ? (160 * 1024) / (lds + 6 * 1024) : 6;
@@ -175,13 +240,21 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
         grid = dim3((unsigned)blocks, 1, 1);
         HIP_TRY(hipMemsetAsync(c->d_counters + 30, 0, sizeof(unsigned long long), stream));
     }
+    if (c->mode == 100 + rt::kParityTimelogVariant && c->d_timelog && c->timelog_used < c->timelog_cap) {
+        p.timelog = c->d_timelog;
+        p.seq = c->timelog_used++;
+        p.tl_tag = c->timelog_tag;
+        p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
+    }
     if (persist && c->mode == RT_MODE_FAST)
         e = rt::launch_fast(coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant, p, grid, lds, stream);
     else if (persist)
         e = rt::launch_parity(coop ? rt::kParityPersistCoopVariant : rt::kParityPersistVariant, p, grid, lds, stream);
-    else if (c->mode == RT_MODE_FAST) e = rt::launch_fast(coop ? rt::kFastCoopVariant : 0, p, grid, lds, stream);
     else if (c->mode >= 200) e = rt::launch_fast(c->mode - 200, p, grid, lds, stream);
     else if (c->mode >= 100) e = rt::launch_parity(c->mode - 100, p, grid, lds, stream);
+    else
+#endif
+    if (c->mode == RT_MODE_FAST) e = rt::launch_fast(coop ? rt::kFastCoopVariant : 0, p, grid, lds, stream);
     else e = rt::launch_parity(coop ? rt::kParityCoopVariant : 0, p, grid, lds, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
@@ -189,6 +262,88 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     c->current_sample += n_samples;
     c->launches += 1;
     c->seeds_default = false;           // this launch has written every seed pair the context renders
+    c->pixels_current = c->pixel_write != 0;
+    return RT_OK;
+}
+
+// ---- scene storage -------------------------------------------------------------------------
+
+bool light_test(const rt_sphere &s) { return !((s.e.x == 0.f) && (s.e.z == 0.f)); }   // .cl:135-138,266
+
+void free_scene(rt_ctx *c) {
+    (void)hipFree(c->d_spheres);
+    (void)hipFree(c->d_tables);
+    c->d_spheres = nullptr;
+    c->d_tables = nullptr;
+    c->scene_cap = 0;
+}
+
+int ensure_scene_capacity(rt_ctx *c, uint32_t count) {
+    if (count <= c->scene_cap && c->d_tables) return RT_OK;
+    uint32_t cap = 64;
+    while (cap < count) cap *= 2;
+    int rc = wait_all(c);               // nothing may still read the tables that are about to go
+    if (rc != RT_OK) return rc;
+    rt_sphere *ns = nullptr;
+    float4 *nt = nullptr;
+    HIP_TRY(hipMalloc(&ns, (size_t)cap * sizeof(rt_sphere)));
+    hipError_t e = hipMalloc(&nt, ((size_t)cap * 5 + 1) * sizeof(float4));
+    if (e != hipSuccess) {
+        (void)hipFree(ns);
+        return fail(RT_ERR_ALLOC, "scene tables for %u spheres: %s", cap, hipGetErrorString(e));
+    }
+    free_scene(c);
+    c->d_spheres = ns;
+    c->d_tables = nt;
+    c->scene_cap = cap;
+    return RT_OK;
+}
+
+int ensure_stage_capacity(rt_ctx *c, uint32_t count) {
+    if (count <= c->stage_cap) return RT_OK;
+    uint32_t cap = 64;
+    while (cap < count) cap *= 2;
+    for (int k = 0; k < 4; ++k)
+        if (c->stage_used[k]) {
+            HIP_TRY(hipEventSynchronize(c->stage_ev[k]));
+            c->stage_used[k] = false;
+        }
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->stage_cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_stage), (size_t)cap * 4 * sizeof(rt_sphere), hipHostMallocDefault));
+    c->stage_cap = cap;
+    return RT_OK;
+}
+
+// records [first, first+count) -> device, then the tables, all on `stream`
+int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *spheres, uint32_t n_total, hipStream_t stream) {
+    int rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+    if (count) {
+        rc = ensure_stage_capacity(c, count);
+        if (rc != RT_OK) return rc;
+        const int slot = c->stage_next;
+        c->stage_next = (slot + 1) & 3;
+        if (c->stage_used[slot]) HIP_TRY(hipEventSynchronize(c->stage_ev[slot]));
+        rt_sphere *stage = c->h_stage + (size_t)slot * c->stage_cap;
+        memcpy(stage, spheres, (size_t)count * sizeof(rt_sphere));
+        HIP_TRY(hipMemcpyAsync(c->d_spheres + first, stage, (size_t)count * sizeof(rt_sphere), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(c->stage_ev[slot], stream));
+        c->stage_used[slot] = true;
+        for (uint32_t i = 0; i < count; ++i) c->is_light[first + i] = light_test(spheres[i]) ? 1 : 0;
+    }
+    uint32_t nl = 0;
+    for (uint32_t i = 0; i < n_total; ++i) nl += c->is_light[i];
+    const size_t cap = c->scene_cap;
+    float4 *base = c->d_tables;
+    float4 *d_geom = base, *d_emis = base + cap, *d_colr = base + 2 * cap, *d_la = base + 3 * cap, *d_lb = base + 4 * cap;
+    if (n_total) {
+        hipLaunchKernelGGL(rt_build_tables_kernel, dim3(1), dim3(256), 0, stream, c->d_spheres, n_total, d_geom, d_emis, d_colr,
+                           d_la, d_lb, reinterpret_cast<uint32_t *>(base + 5 * cap));
+        HIP_TRY(hipGetLastError());
+    }
+    c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, n_total, nl };
     return RT_OK;
 }
 
@@ -196,13 +351,12 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
 
 extern "C" {
 
-const char *rt_last_error(void) { return g_err; }
+RT_API const char *rt_last_error(void) { return g_err; }
 
-// used by rt_host.cpp (not part of the public header)
+// used by rt_host.cpp (hidden: not part of the export table)
 void rt_host_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
 
-int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nranks,
-                      int tile_rows) {
+RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nranks, int tile_rows) {
     if (!out) return fail(RT_ERR_ARG, "out is null");
     *out = nullptr;
     if (w <= 0 || h <= 0) return fail(RT_ERR_ARG, "image size %dx%d", w, h);
@@ -243,17 +397,30 @@ int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nran
     const size_t px = (size_t)w * (size_t)h;
     auto alloc_all = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->last_stream = c->stream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
+        for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
         HIP_TRY(hipMalloc(&c->d_seeds, 2 * px * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_seeds0, 2 * px * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_colors, 3 * px * sizeof(float)));
-        HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 4) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&c->d_stats, rt::kStatReplicas * 8 * sizeof(unsigned long long)));
-        HIP_TRY(rt::prepare_parity());
-        HIP_TRY(rt::prepare_fast());
-        return upload_default_seeds(c);
+        // function attributes (dynamic-LDS limit) are per device, not per context
+        static std::mutex mu;
+        static bool prepared[64] = {};
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (device >= 64 || !prepared[device]) {
+                HIP_TRY(rt::prepare_parity());
+                HIP_TRY(rt::prepare_fast());
+                if (device < 64) prepared[device] = true;
+            }
+        }
+        int r2 = upload_default_seeds(c);
+        return r2 == RT_OK ? restore_state(c) : r2;
     };
     if (rc == RT_OK) rc = alloc_all();
     if (rc != RT_OK) {
@@ -264,11 +431,17 @@ int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nran
     return RT_OK;
 }
 
-int rt_create(rt_ctx **out, int w, int h) { return rt_create_sharded(out, w, h, 0, 0, 1, rt::kTileH); }
+RT_API int rt_create(rt_ctx **out, int w, int h) { return rt_create_sharded(out, w, h, 0, 0, 1, rt::kTileH); }
 
-void rt_destroy(rt_ctx *c) {
+RT_API void rt_destroy(rt_ctx *c) {
     if (!c) return;
+    if (c->multi) {
+        rt::multi_destroy(c);
+        delete c;
+        return;
+    }
     if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->pinned_out) (void)hipHostUnregister(c->pinned_out);
         (void)hipFree(c->d_seeds);
@@ -277,188 +450,180 @@ void rt_destroy(rt_ctx *c) {
         (void)hipFree(c->d_pixels);
         (void)hipFree(c->d_counters);
         (void)hipFree(c->d_stats);
-        (void)hipFree(c->d_tables);
+        (void)hipFree(c->d_timelog);
+        (void)hipFree(c->d_wavelog);
+        free_scene(c);
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
+        for (int k = 0; k < 4; ++k)
+            if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
 }
 
-int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
+RT_API int rt_shard_count(const rt_ctx *c) { return !c ? RT_ERR_ARG : (c->multi ? rt::multi_shards(c) : 1); }
+
+RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     if (count > 0 && !spheres) return fail(RT_ERR_ARG, "spheres is null");
     if (count > RT_MAX_SPHERES) return fail(RT_ERR_ARG, "%u spheres > RT_MAX_SPHERES (%u)", count, RT_MAX_SPHERES);
-    int rc = select_device(c);
-    if (rc != RT_OK) return rc;
-
-    // host-side table build: strict binary32 (this file is compiled -ffp-contract=off)
-    std::vector<float4> geom(count), emis(count), colr(count), la, lb;
-    for (uint32_t i = 0; i < count; ++i) {
-        const rt_sphere &s = spheres[i];
-        geom[i] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);                     // .cl:184
-        float refl_bits;
-        int32_t refl = s.refl;
-        memcpy(&refl_bits, &refl, 4);
-        emis[i] = make_float4(s.e.x, s.e.y, s.e.z, refl_bits);
-        colr[i] = make_float4(s.c.x, s.c.y, s.c.z, s.rad);
-        if (!((s.e.x == 0.f) && (s.e.z == 0.f))) {                                     // .cl:135-138,266
-            la.push_back(make_float4(s.p.x, s.p.y, s.p.z, s.rad));
-            lb.push_back(make_float4(s.e.x, s.e.y, s.e.z,
-                                     4.f * 3.14159265358979323846f * s.rad * s.rad));  // .cl:297
-        }
-    }
-    const uint32_t nl = (uint32_t)la.size();
-    const size_t need = 3 * (size_t)count + 2 * (size_t)nl + 1;
-    // ordered after any launch still reading the old tables
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipDeviceSynchronize());
-    if (need > c->tables_cap) {
-        (void)hipFree(c->d_tables);
-        c->d_tables = nullptr;
-        c->tables_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_tables, need * sizeof(float4)));
-        c->tables_cap = need;
-    }
-    float4 *base = c->d_tables;
-    float4 *d_geom = base, *d_emis = base + count, *d_colr = base + 2 * (size_t)count;
-    float4 *d_la = base + 3 * (size_t)count, *d_lb = d_la + nl;
-    if (count) {
-        HIP_TRY(hipMemcpy(d_geom, geom.data(), count * sizeof(float4), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_emis, emis.data(), count * sizeof(float4), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_colr, colr.data(), count * sizeof(float4), hipMemcpyHostToDevice));
-    }
-    if (nl) {
-        HIP_TRY(hipMemcpy(d_la, la.data(), nl * sizeof(float4), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_lb, lb.data(), nl * sizeof(float4), hipMemcpyHostToDevice));
-    }
-    c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, count, nl };
+    // everything that can refuse the scene is checked before the current one is touched
+    uint32_t nl = 0;
+    for (uint32_t i = 0; i < count; ++i) nl += light_test(spheres[i]) ? 1u : 0u;
     if (rt::lds_bytes(count, nl, false) > 152 * 1024)
         return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(count, nl, false));
+    if (c->multi) return rt::multi_set_scene(c, spheres, count);
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = ensure_scene_capacity(c, count);
+    if (rc != RT_OK) return rc;
+    c->is_light.assign(c->scene_cap, 0);
+    rc = upload_spheres(c, 0, count, spheres, count, c->stream);
+    if (rc != RT_OK) {
+        c->have_scene = false;          // the tables are in an unknown state
+        return rc;
+    }
     c->have_scene = true;
     return RT_OK;
 }
 
-int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
+RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *spheres, void *hip_stream) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (!c->have_scene && !c->multi) return fail(RT_ERR_STATE, "rt_set_scene must precede rt_update_spheres_async");
+    if (count > 0 && !spheres) return fail(RT_ERR_ARG, "spheres is null");
+    if (c->multi) return rt::multi_update_spheres(c, first, count, spheres);
+    const uint32_t n = c->scene.n_spheres;
+    if (first > n || count > n - first) return fail(RT_ERR_ARG, "spheres [%u, %u) of a scene of %u", first, first + count, n);
+    // the light list may grow: check the LDS budget with the new flags before anything is queued
+    uint32_t nl = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        nl += (i >= first && i < first + count) ? (light_test(spheres[i - first]) ? 1u : 0u) : c->is_light[i];
+    if (rt::lds_bytes(n, nl, false) > 152 * 1024)
+        return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(n, nl, false));
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    return upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
+}
+
+RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
-    c->cam = *cam;
+    if (c->multi) return rt::multi_set_camera(c, cam);
+    c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;
     return RT_OK;
 }
 
-int rt_set_mode(rt_ctx *c, int mode) {
+RT_API int rt_set_mode(rt_ctx *c, int mode) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
-    // 100+k / 200+k: A/B instances of the parity / fast arithmetic (not part of the contract)
-    const bool ab = (mode >= 100 && mode < 100 + rt::parity_variant_count()) ||
-                    (mode >= 200 && mode < 200 + rt::fast_variant_count());
-    if (mode != RT_MODE_PARITY && mode != RT_MODE_FAST && !ab) return fail(RT_ERR_ARG, "mode %d", mode);
+    bool ok = mode == RT_MODE_PARITY || mode == RT_MODE_FAST;
+#if RT_DIAGNOSTICS
+    // 100+k / 200+k: A/B instances of the parity / fast arithmetic (rt_debug.h; not part of the contract)
+    ok = ok || (mode >= 100 && mode < 100 + rt::parity_variant_count()) || (mode >= 200 && mode < 200 + rt::fast_variant_count());
+#endif
+    if (!ok) return fail(RT_ERR_ARG, "mode %d", mode);
+    if (c->multi) return rt::multi_set_mode(c, mode);
     c->mode = mode;
     return RT_OK;
 }
 
-int rt_reset(rt_ctx *c) {
+RT_API int rt_reset(rt_ctx *c) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return rt::multi_reset(c, false);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipDeviceSynchronize());
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
     c->current_sample = 0;
     c->launches = 0;
     c->last_ms = 0.0;
     c->seeds_default = false;
-    return upload_default_seeds(c);
+    c->pixels_current = true;
+    return restore_state(c);
 }
 
-int rt_reset_async(rt_ctx *c, void *hip_stream) {
+RT_API int rt_reset_async(rt_ctx *c, void *hip_stream) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return rt::multi_reset(c, true);
     int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = chain(c, (hipStream_t)hip_stream);
     if (rc != RT_OK) return rc;
     hipLaunchKernelGGL(rt_zero_counters_kernel, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, c->d_counters, c->d_stats);
     HIP_TRY(hipGetLastError());
     c->seeds_default = true;            // the next launch reads d_seeds0
     c->current_sample = 0;
+    c->launches = 0;
+    c->last_ms = 0.0;
     return RT_OK;
 }
 
-int rt_debug_reset_by_copy(rt_ctx *c, void *hip_stream, int use_memcpy) {
+RT_API int rt_render_async(rt_ctx *c, int n_samples, void *hip_stream) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
-    int rc = select_device(c);
-    if (rc != RT_OK) return rc;
-    const size_t n = 2 * (size_t)c->w * (size_t)c->h;
-    if (use_memcpy) {
-        HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
-    } else {
-        hipLaunchKernelGGL(rt_debug_copy_seeds_kernel, dim3(1024), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0, n);
-        HIP_TRY(hipGetLastError());
-    }
-    c->seeds_default = false;
-    c->current_sample = 0;
-    return RT_OK;
-}
-
-// diagnostic: a kernel on `hip_stream` that counts the seed words differing from the default stream
-// into counters[28] (and the number of probes into counters[29]); read them with rt_debug_counters_raw
-int rt_debug_probe_seeds(rt_ctx *c, void *hip_stream) {
-    if (!c) return fail(RT_ERR_ARG, "ctx is null");
-    int rc = select_device(c);
-    if (rc != RT_OK) return rc;
-    hipLaunchKernelGGL(rt_debug_probe_seeds_kernel, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0,
-                       2 * (size_t)c->w * (size_t)c->h, c->d_counters + 28);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
-}
-
-int rt_debug_counters_raw(rt_ctx *c, unsigned long long *out32) {
-    if (!c || !out32) return fail(RT_ERR_ARG, "null argument");
-    int rc = select_device(c);
-    if (rc != RT_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out32, c->d_counters, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return RT_OK;
-}
-
-int rt_render_async(rt_ctx *c, int n_samples, void *hip_stream) {
-    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return rt::multi_render(c, nullptr, n_samples, false);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     return launch(c, n_samples, (hipStream_t)hip_stream);
 }
 
-int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
+RT_API int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return rt::multi_render(c, out_host, n_samples, true);
     int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = chain(c, c->stream);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     rc = launch(c, n_samples, c->stream);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    // the launch is complete before the readback is issued (not merely queued behind it: see
-    // rt_reset_kernel for why this library does not lean on copy-after-kernel ordering)
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (out_host && c->local_rows > 0) {
+    if (out_host && c->local_rows > 0)
         HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels,
-                               (size_t)c->local_rows * c->w * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+                               (size_t)c->local_rows * c->w * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->last_ms = ms;
     return RT_OK;
 }
 
-int rt_set_pixel_write(rt_ctx *c, int enable) {
+RT_API int rt_set_pixel_write(rt_ctx *c, int enable) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return rt::multi_set_pixel_write(c, enable);
     c->pixel_write = enable ? 1 : 0;
     return RT_OK;
 }
 
-int rt_pin_output(rt_ctx *c, uint32_t *out_host, size_t count) {
+RT_API int rt_read_pixels(rt_ctx *c, uint32_t *out_host) {
+    if (!c || !out_host) return fail(RT_ERR_ARG, "null argument");
+    if (c->multi) return rt::multi_read_pixels(c, out_host);
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    if (c->local_rows == 0) return RT_OK;
+    rc = chain(c, c->stream);
+    if (rc != RT_OK) return rc;
+    if (!c->pixels_current && c->current_sample > 0) {
+        rt::LaunchParams p = make_params(c, 0);
+        hipError_t e = (c->mode == RT_MODE_FAST || c->mode >= 200) ? rt::launch_pack_fast(p, c->stream) : rt::launch_pack_parity(p, c->stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "pack kernel launch failed: %s", hipGetErrorString(e));
+        c->pixels_current = true;
+    }
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels,
+                           (size_t)c->local_rows * c->w * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+RT_API int rt_pin_output(rt_ctx *c, uint32_t *out_host, size_t count) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return rt::multi_pin_output(c, out_host, count);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     if (c->pinned_out) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        rc = wait_all(c);
+        if (rc != RT_OK) return rc;
         (void)hipHostUnregister(c->pinned_out);
         c->pinned_out = nullptr;
     }
@@ -470,8 +635,9 @@ int rt_pin_output(rt_ctx *c, uint32_t *out_host, size_t count) {
     return RT_OK;
 }
 
-int rt_set_pixel_buffer(rt_ctx *c, void *dptr, size_t count) {
+RT_API int rt_set_pixel_buffer(rt_ctx *c, void *dptr, size_t count) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (c->multi) return fail(RT_ERR_ARG, "rt_set_pixel_buffer: a multi-device context assembles its frame in its own buffer");
     if (dptr && count < (size_t)c->local_rows * (size_t)c->w)
         return fail(RT_ERR_ARG, "pixel buffer of %zu < %zu elements", count, (size_t)c->local_rows * (size_t)c->w);
     c->d_pixels_ext = static_cast<uint32_t *>(dptr);
@@ -481,46 +647,52 @@ int rt_set_pixel_buffer(rt_ctx *c, void *dptr, size_t count) {
 // The context's own stream (hipStream_t, non-blocking): what rt_render_pass launches on.  Callers
 // that keep several contexts in flight can launch each on its own stream through
 // rt_render_async(ctx, n, rt_stream(ctx)).
-void *rt_stream(rt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+RT_API void *rt_stream(rt_ctx *c) { return !c ? nullptr : (c->multi ? rt::multi_stream(c) : (void *)c->stream); }
 
-int rt_device_pixels(rt_ctx *c, void **dptr, size_t *count) {
+RT_API int rt_device_pixels(rt_ctx *c, void **dptr, size_t *count) {
     if (!c || !dptr || !count) return fail(RT_ERR_ARG, "null argument");
+    if (c->multi) return rt::multi_device_pixels(c, dptr, count);
     *dptr = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
     *count = (size_t)c->local_rows * (size_t)c->w;
     return RT_OK;
 }
 
-int rt_local_rows(const rt_ctx *c) { return c ? c->local_rows : RT_ERR_ARG; }
-int rt_current_sample(const rt_ctx *c) { return c ? c->current_sample : RT_ERR_ARG; }
+RT_API int rt_local_rows(const rt_ctx *c) { return c ? c->local_rows : RT_ERR_ARG; }
+RT_API int rt_current_sample(const rt_ctx *c) { return c ? c->current_sample : RT_ERR_ARG; }
 
-int rt_read_colors(rt_ctx *c, float *out_host) {
+RT_API int rt_read_colors(rt_ctx *c, float *out_host) {
     if (!c || !out_host) return fail(RT_ERR_ARG, "null argument");
+    if (c->multi) return rt::multi_read_colors(c, out_host);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
-    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
+    rc = chain(c, c->stream);           // behind everything the context has queued, on whatever stream
+    if (rc != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_host, c->d_colors, 3 * (size_t)c->w * c->h * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
-int rt_read_seeds(rt_ctx *c, uint32_t *out_host) {
+RT_API int rt_read_seeds(rt_ctx *c, uint32_t *out_host) {
     if (!c || !out_host) return fail(RT_ERR_ARG, "null argument");
+    if (c->multi) return rt::multi_read_seeds(c, out_host);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
+    rc = chain(c, c->stream);
+    if (rc != RT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(out_host, c->seeds_default ? c->d_seeds0 : c->d_seeds, 2 * (size_t)c->w * c->h * sizeof(uint32_t),
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
-int rt_get_stats(rt_ctx *c, rt_stats *out) {
+RT_API int rt_get_stats(rt_ctx *c, rt_stats *out) {
     if (!c || !out) return fail(RT_ERR_ARG, "null argument");
+    if (c->multi) return rt::multi_get_stats(c, out);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
+    rc = chain(c, c->stream);
+    if (rc != RT_OK) return rc;
     unsigned long long v[32];
-    HIP_TRY(hipDeviceSynchronize());   // also covers rt_render_async on a caller's stream
     HIP_TRY(hipMemcpyAsync(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost, c->stream));
     unsigned long long part[rt::kStatReplicas * 8], sum[5] = { 0, 0, 0, 0, 0 };
     HIP_TRY(hipMemcpyAsync(part, c->d_stats, sizeof part, hipMemcpyDeviceToHost, c->stream));
@@ -538,54 +710,275 @@ int rt_get_stats(rt_ctx *c, rt_stats *out) {
     return RT_OK;
 }
 
+RT_API int rt_deinterleave_rows(uint32_t *full, const uint32_t *gathered, int w, int h, int nranks, int tile_rows, int pad_rows,
+                                int device, void *hip_stream) {
+    if (!full || !gathered) return fail(RT_ERR_ARG, "null argument");
+    if (w <= 0 || h <= 0 || nranks < 1 || tile_rows <= 0) return fail(RT_ERR_ARG, "image %dx%d, %d ranks, tiles of %d rows", w, h, nranks, tile_rows);
+    const int n_tiles = (h + tile_rows - 1) / tile_rows, need = ((n_tiles + nranks - 1) / nranks) * tile_rows;
+    if (pad_rows < need && pad_rows < ((n_tiles - 1) / nranks) * tile_rows + (h - (n_tiles - 1) * tile_rows))
+        return fail(RT_ERR_ARG, "pad_rows %d is less than a rank's row count", pad_rows);
+    HIP_TRY(hipSetDevice(device));
+    const int vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(gathered)) % 16 == 0);
+    const size_t total = (size_t)(vec ? w / 4 : w) * (size_t)h;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rt_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, full, gathered, w, h, nranks,
+                       tile_rows, pad_rows, vec);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---- rt_render: the one-shot call, with the device state of recent sizes kept ----------------
+namespace {
+struct CacheEntry {
+    int w = 0, h = 0;
+    rt_ctx *ctx = nullptr;
+    uint32_t *h_pix = nullptr;          // page-locked, w*h
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    unsigned long long stamp = 0;
+};
+constexpr int kCacheSlots = 4;
+CacheEntry g_cache[kCacheSlots];
+unsigned long long g_cache_clock = 0;
+std::mutex g_cache_mu;
+
+void cache_drop(CacheEntry &e) {
+    if (e.ctx) {
+        (void)hipSetDevice(e.ctx->device);
+        rt_destroy(e.ctx);
+    }
+    if (e.h_pix) (void)hipHostFree(e.h_pix);
+    for (auto &v : e.ev)
+        if (v) (void)hipEventDestroy(v);
+    e = CacheEntry{};
+}
+
+int cache_get(int w, int h, CacheEntry **out) {
+    int victim = 0;
+    for (int k = 0; k < kCacheSlots; ++k) {
+        if (g_cache[k].ctx && g_cache[k].w == w && g_cache[k].h == h) {
+            *out = &g_cache[k];
+            return RT_OK;
+        }
+        if (g_cache[k].stamp < g_cache[victim].stamp) victim = k;
+    }
+    CacheEntry &e = g_cache[victim];
+    cache_drop(e);
+    int rc = rt_create(&e.ctx, w, h);
+    if (rc != RT_OK) return rc;
+    e.w = w;
+    e.h = h;
+    hipError_t he = hipHostMalloc(reinterpret_cast<void **>(&e.h_pix), (size_t)w * h * sizeof(uint32_t), hipHostMallocDefault);
+    for (int k = 0; k < 4 && he == hipSuccess; ++k) he = hipEventCreateWithFlags(&e.ev[k], hipEventDisableTiming);
+    if (he != hipSuccess) {
+        cache_drop(e);
+        return fail(RT_ERR_ALLOC, "rt_render staging: %s", hipGetErrorString(he));
+    }
+    *out = &e;
+    return RT_OK;
+}
+}  // namespace
+
+RT_API void rt_release_cache(void) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (auto &e : g_cache) cache_drop(e);
+}
+
+RT_API int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w, int h, int spp) {
+    if (!scene || !cam || !out) return fail(RT_ERR_ARG, "null argument");
+    if (spp < 0) return fail(RT_ERR_ARG, "spp < 0");
+    if (w <= 0 || h <= 0) return fail(RT_ERR_ARG, "image size %dx%d", w, h);
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    CacheEntry *e = nullptr;
+    int rc = cache_get(w, h, &e);
+    if (rc != RT_OK) return rc;
+    e->stamp = ++g_cache_clock;
+    rt_ctx *c = e->ctx;
+    auto run = [&]() -> int {
+        // a fresh OpenCLConfigBuffer: pass 0, default seed stream (read in place), parity mode, own pixel buffer
+        int r = rt_reset_async(c, c->stream);
+        if (r == RT_OK) r = rt_set_mode(c, RT_MODE_PARITY);
+        if (r == RT_OK) r = rt_set_pixel_write(c, 1);
+        if (r == RT_OK) r = rt_set_pixel_buffer(c, nullptr, 0);
+        if (r == RT_OK) r = rt_set_scene(c, scene->spheres, scene->count);
+        if (r == RT_OK) r = rt_set_camera(c, cam);
+        if (r == RT_OK) r = rt_render_async(c, spp, c->stream);
+        if (r != RT_OK) return r;
+        if (spp == 0) {                 // no pass ran: getPixels() of a fresh backend is the zero-filled buffer
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            memset(out, 0, (size_t)w * h * sizeof(uint32_t));
+            return RT_OK;
+        }
+        // read-back in four row blocks through page-locked staging: block k+1 crosses the bus while block k is
+        // copied into the caller's (pageable) buffer
+        const size_t total = (size_t)w * h;
+        size_t off[5];
+        for (int k = 0; k <= 4; ++k) off[k] = ((size_t)h * k / 4) * (size_t)w;
+        for (int k = 0; k < 4; ++k) {
+            if (off[k + 1] > off[k])
+                HIP_TRY(hipMemcpyAsync(e->h_pix + off[k], c->d_pixels + off[k], (off[k + 1] - off[k]) * sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(e->ev[k], c->stream));
+        }
+        for (int k = 0; k < 4; ++k) {
+            HIP_TRY(hipEventSynchronize(e->ev[k]));
+            if (off[k + 1] > off[k]) memcpy(out + off[k], e->h_pix + off[k], (off[k + 1] - off[k]) * sizeof(uint32_t));
+        }
+        (void)total;
+        return RT_OK;
+    };
+    rc = run();
+    if (rc != RT_OK) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        cache_drop(*e);                 // never reuse a context that failed half-way
+        memcpy(g_err, keep, sizeof keep);
+    }
+    return rc;
+}
+
+#if RT_DIAGNOSTICS
+// =============================== diagnostics build only (rt_debug.h) ===========================
+
+RT_API int rt_debug_variant_count(int fast) { return fast ? rt::fast_variant_count() : rt::parity_variant_count(); }
+
+static int dbg_set_gate(rt_ctx *c, int v) { c->regen_gate = v; return RT_OK; }
+static int dbg_set_matlds(rt_ctx *c, int v) { c->mat_lds_limit = v; return RT_OK; }
+static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT_OK; }
+static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
+static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
+static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }
+
 // tuning knob (not part of the contract): 0 = automatic, 1 = free-running, n = gate of n lanes
-int rt_debug_set_regen_gate(rt_ctx *c, int gate) {
+RT_API int rt_debug_set_regen_gate(rt_ctx *c, int gate) {
     if (!c || gate < 0 || gate > 64) return fail(RT_ERR_ARG, "gate %d", gate);
-    c->regen_gate = gate;
-    return RT_OK;
+    return dbg_apply(c, dbg_set_gate, gate);
 }
-
-int rt_debug_set_mat_lds_limit(rt_ctx *c, int bytes) {
+RT_API int rt_debug_set_mat_lds_limit(rt_ctx *c, int bytes) {
     if (!c || bytes < 0) return fail(RT_ERR_ARG, "bytes %d", bytes);
-    c->mat_lds_limit = bytes;
-    return RT_OK;
+    return dbg_apply(c, dbg_set_matlds, bytes);
 }
-
-int rt_debug_set_persist(rt_ctx *c, int on) {
+RT_API int rt_debug_set_persist(rt_ctx *c, int on) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
-    c->persist = on ? 1 : 0;
-    return RT_OK;
+    return dbg_apply(c, dbg_set_persist, on);
 }
-
-int rt_debug_set_ncus(rt_ctx *c, int n) {      // shrink the persistent grid (tests of the tile queue)
+RT_API int rt_debug_set_ncus(rt_ctx *c, int n) {      // shrink the persistent grid (tests of the tile queue)
     if (!c || n < 1) return fail(RT_ERR_ARG, "n %d", n);
-    c->n_cus = n;
-    return RT_OK;
+    return dbg_apply(c, dbg_set_ncus, n);
 }
-
-int rt_debug_set_coop_min(rt_ctx *c, int min_spheres) {
+RT_API int rt_debug_set_coop_min(rt_ctx *c, int min_spheres) {
     if (!c || min_spheres < 0) return fail(RT_ERR_ARG, "min_spheres %d", min_spheres);
-    c->coop_min = min_spheres;
-    return RT_OK;
+    return dbg_apply(c, dbg_set_coop, min_spheres);
 }
 
-// diagnostic: section cycle sums of a stamped instance (valid after rt_get_stats)
-int rt_debug_counters(rt_ctx *c, unsigned long long *out24) {
-    if (!c || !out24) return fail(RT_ERR_ARG, "null argument");
+// section cycle sums of a stamped instance (valid after rt_get_stats)
+RT_API int rt_debug_counters(rt_ctx *c, unsigned long long *out24) {
+    if (!c || !out24 || c->multi) return fail(RT_ERR_ARG, "null argument / multi-device context");
     memcpy(out24, c->debug_counters, sizeof c->debug_counters);
     return RT_OK;
 }
 
-int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out, int w, int h, int spp) {
-    if (!scene || !cam || !out) return fail(RT_ERR_ARG, "null argument");
-    if (spp < 0) return fail(RT_ERR_ARG, "spp < 0");
-    rt_ctx *c = nullptr;
-    int rc = rt_create(&c, w, h);
-    if (rc == RT_OK) rc = rt_set_scene(c, scene->spheres, scene->count);
-    if (rc == RT_OK) rc = rt_set_camera(c, cam);
-    if (rc == RT_OK) rc = rt_render_pass(c, out, spp);
-    rt_destroy(c);
-    return rc;
+RT_API int rt_debug_counters_raw(rt_ctx *c, unsigned long long *out32) {
+    if (!c || !out32 || c->multi) return fail(RT_ERR_ARG, "null argument / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = chain(c, c->stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out32, c->d_counters, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static unsigned long long *timelog_next(rt_ctx *c) {
+    if (!c->d_timelog || c->timelog_used >= c->timelog_cap) return nullptr;
+    return c->d_timelog + 8 * (size_t)(c->timelog_used++);
+}
+
+// NOTE: deliberately NOT chained (no event dependency added by the library): this is the round-1 reset,
+// kept to reproduce and study the ordering failure recorded in DESIGN.md section 3
+RT_API int rt_debug_reset_by_copy(rt_ctx *c, void *hip_stream, int use_memcpy) {
+    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    const size_t n = 2 * (size_t)c->w * (size_t)c->h;
+    if (use_memcpy) {
+        HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    } else {
+        unsigned long long *tl = timelog_next(c);
+        hipLaunchKernelGGL(rt_debug_copy_seeds_kernel, dim3(1024), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0, n, tl,
+                           c->timelog_tag);
+        HIP_TRY(hipGetLastError());
+    }
+    c->seeds_default = false;
+    c->current_sample = 0;
+    return RT_OK;
+}
+
+// a kernel on `hip_stream` that counts the seed words differing from the default stream
+// into counters[28] (and the number of probes into counters[29]); read them with rt_debug_counters_raw
+RT_API int rt_debug_probe_seeds(rt_ctx *c, void *hip_stream) {
+    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    unsigned long long *tl = timelog_next(c);
+    hipLaunchKernelGGL(rt_debug_probe_seeds_kernel, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0,
+                       2 * (size_t)c->w * (size_t)c->h, c->d_counters + 28, tl, c->timelog_tag);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+RT_API int rt_debug_timelog_enable(rt_ctx *c, uint32_t entries, uint32_t wave_entries) {
+    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    (void)hipFree(c->d_timelog);
+    (void)hipFree(c->d_wavelog);
+    c->d_timelog = c->d_wavelog = nullptr;
+    c->timelog_cap = c->timelog_used = c->wavelog_cap = 0;
+    if (entries) {
+        HIP_TRY(hipMalloc(&c->d_timelog, (size_t)entries * 8 * sizeof(unsigned long long)));
+        std::vector<unsigned long long> init((size_t)entries * 8, 0ull);
+        for (uint32_t i = 0; i < entries; ++i) init[8 * (size_t)i] = ~0ull;
+        HIP_TRY(hipMemcpy(c->d_timelog, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        c->timelog_cap = entries;
+    }
+    if (wave_entries) {
+        HIP_TRY(hipMalloc(&c->d_wavelog, (size_t)wave_entries * 3 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_wavelog, 0, (size_t)wave_entries * 3 * sizeof(unsigned long long)));
+        c->wavelog_cap = wave_entries;
+    }
+    return RT_OK;
+}
+
+RT_API int rt_debug_timelog_tag(rt_ctx *c, unsigned long long tag) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    c->timelog_tag = tag;
+    return RT_OK;
+}
+
+RT_API int rt_debug_timelog_read(rt_ctx *c, unsigned long long *out, uint32_t entries, uint32_t *used) {
+    if (!c || !out || c->multi) return fail(RT_ERR_ARG, "null argument / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    const uint32_t n = entries < c->timelog_cap ? entries : c->timelog_cap;
+    if (n) HIP_TRY(hipMemcpy(out, c->d_timelog, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (used) *used = c->timelog_used;
+    return RT_OK;
+}
+
+RT_API int rt_debug_wavelog_read(rt_ctx *c, unsigned long long *out, uint32_t wave_entries) {
+    if (!c || !out || c->multi) return fail(RT_ERR_ARG, "null argument / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    const uint32_t n = wave_entries < c->wavelog_cap ? wave_entries : c->wavelog_cap;
+    if (n) HIP_TRY(hipMemcpy(out, c->d_wavelog, (size_t)n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 // exhaustive device-side check of the lean correctly-rounded sqrt: mismatches over all 2^32 inputs
@@ -601,12 +994,12 @@ static long long sqrt_check(int which) {
     if (e != hipSuccess) return fail(RT_ERR_HIP, "sqrt check %d: %s", which, hipGetErrorString(e));
     return (long long)h;
 }
-long long rt_debug_sqrt_mismatches(void) { return sqrt_check(0); }
+RT_API long long rt_debug_sqrt_mismatches(void) { return sqrt_check(0); }
 // sphere test with the unchecked square root against the one with sqrtf, tiny discriminants
-long long rt_debug_hitpost_mismatches(void) { return sqrt_check(1); }
+RT_API long long rt_debug_hitpost_mismatches(void) { return sqrt_check(1); }
 
 // mismatches of the candidate lean reciprocals per input exponent: out[4][256]
-int rt_debug_rcp_probe(unsigned long long *out1024) {
+RT_API int rt_debug_rcp_probe(unsigned long long *out1024) {
     if (!out1024) return fail(RT_ERR_ARG, "null argument");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device");
@@ -620,7 +1013,7 @@ int rt_debug_rcp_probe(unsigned long long *out1024) {
     return RT_OK;
 }
 
-int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
+RT_API int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
     if ((!in_host || !out_host) && n) return fail(RT_ERR_ARG, "null argument");
     if (op < 0 || op > 8) return fail(RT_ERR_ARG, "op %d", op);
     int n_dev = 0;
@@ -638,5 +1031,6 @@ int rt_debug_eval(int op, const float *in_host, float *out_host, size_t n) {
     if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_eval: %s", hipGetErrorString(e));
     return RT_OK;
 }
+#endif   // RT_DIAGNOSTICS
 
 }  // extern "C"

@@ -52,6 +52,12 @@ struct LaunchParams {
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
     float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
+    // diagnostics build only (null in the product library): launch sequence number and the buffers the
+    // instrumented instance logs device wall-clock intervals into (tools/gather_stress.py, tools/wave_timeline.py)
+    unsigned long long *timelog;   // [seq][8]: min start, max end of the launch (s_memrealtime, 100 MHz), kind, tag, ...
+    unsigned long long tl_tag;
+    unsigned long long *wavelog;   // [workgroup*4 + wave][3]: start, end, xcc_id << 32 | HW_ID
+    uint32_t seq;
 };
 
 // LDS bytes the kernels need for a scene
@@ -62,13 +68,20 @@ inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, 
     return (b + 15) & ~(size_t)15;
 }
 
-// variant 0 = the shipped instance; higher indices are A/B shapes (mode 100+k / 200+k)
+// Final-frame pack kernels (rt_read_pixels): pixels[lrow*w + x] = toInt of the colour plane, with the
+// arithmetic of the mode that renders (.cl:34,594-596), for frames whose launches skipped the pixel store.
+hipError_t launch_pack_parity(const LaunchParams &p, hipStream_t stream);
+hipError_t launch_pack_fast(const LaunchParams &p, hipStream_t stream);
+
+// variant 0 = the shipped instance; higher indices are A/B shapes (mode 100+k / 200+k) that exist in
+// the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1) only
 hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
 constexpr int kParityCoopVariant = 4;   // index of the cooperative-shadow instance in each table
 constexpr int kFastCoopVariant = 3;
 constexpr int kParityPersistVariant = 6, kParityPersistCoopVariant = 7;
 constexpr int kFastPersistVariant = 4, kFastPersistCoopVariant = 5;
+constexpr int kParityTimelogVariant = 9;
 int parity_variant_count();
 int fast_variant_count();
 hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream, int which = 0);

@@ -1,0 +1,93 @@
+// rt_internal.h -- what the translation units of the library share behind the C ABI: the context
+// record, error reporting, and the hooks of the multi-device context (rt_multi.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "rt_device.h"
+
+struct rt_multi;                    // rt_multi.hip
+
+struct rt_ctx {
+    int device = 0;
+    int w = 0, h = 0;
+    int rank = 0, nranks = 1, tile_rows = 8, local_rows = 0;
+    rt_multi *multi = nullptr;          // non-null: this record is the front of a multi-device context
+    uint32_t *d_seeds = nullptr;
+    uint32_t *d_seeds0 = nullptr;       // pristine default stream, for device-side resets
+    float *d_colors = nullptr;
+    uint32_t *d_pixels = nullptr;
+    uint32_t *d_pixels_ext = nullptr;   // caller-owned target of rt_set_pixel_buffer, or null
+    void *pinned_out = nullptr;         // host buffer page-locked by rt_pin_output, or null
+    int pixel_write = 1;                // rt_set_pixel_write
+    bool pixels_current = true;         // the packed pixel buffer holds the frame of the running average
+    bool seeds_default = false;         // after rt_reset_async: the next launch reads the pristine stream
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_stats = nullptr;      // rt::kStatReplicas x 8 partial work counters
+    // scene: raw records + the tables the device-side build kernel derives from them, one allocation
+    rt_sphere *d_spheres = nullptr;
+    float4 *d_tables = nullptr;         // geom | emis | colr | lightA | lightB, each `scene_cap` entries
+    uint32_t scene_cap = 0;
+    std::vector<unsigned char> is_light;   // host mirror of the light test per sphere (sizes the light list)
+    rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
+    uint32_t stage_cap = 0;             // records per slot
+    int stage_next = 0;
+    hipEvent_t stage_ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool stage_used[4] = { false, false, false, false };
+    rt::SceneTables scene{};
+    rt_camera cam{};
+    bool have_scene = false, have_cam = false;
+    int mode = RT_MODE_PARITY;
+    int regen_gate = 0;                 // 0 = choose from the scene size
+    int mat_lds_limit = 24 * 1024;
+    int coop_min = 12;                  // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
+    int persist = 0;                    // diagnostics: persistent-wavefront instances
+    int n_cus = 256;
+    int current_sample = 0;
+    uint64_t launches = 0;
+    double last_ms = 0.0;
+    unsigned long long debug_counters[24] = {};   // diagnostic instances only
+    hipStream_t stream = nullptr;       // the context's own (non-blocking) stream
+    hipStream_t last_stream = nullptr;  // stream of the most recent launch / update (what readers wait for)
+    bool used_foreign_stream = false;   // some launch went to a caller's stream
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
+    // diagnostics build: device wall-clock logs
+    unsigned long long *d_timelog = nullptr, *d_wavelog = nullptr;
+    uint32_t timelog_cap = 0, timelog_used = 0, wavelog_cap = 0;
+    unsigned long long timelog_tag = 0;
+};
+
+namespace rt {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return rt::fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                               \
+    } while (0)
+
+// multi-device context (rt_multi.hip); `front` is the rt_ctx whose `multi` points at the record
+void multi_destroy(rt_ctx *front);
+int multi_set_scene(rt_ctx *front, const rt_sphere *spheres, uint32_t count);
+int multi_update_spheres(rt_ctx *front, uint32_t first, uint32_t count, const rt_sphere *spheres);
+int multi_set_camera(rt_ctx *front, const rt_camera *cam);
+int multi_set_mode(rt_ctx *front, int mode);
+int multi_reset(rt_ctx *front, bool async);
+int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking);
+int multi_set_pixel_write(rt_ctx *front, int enable);
+int multi_read_pixels(rt_ctx *front, uint32_t *out_host);
+int multi_read_colors(rt_ctx *front, float *out_host);
+int multi_read_seeds(rt_ctx *front, uint32_t *out_host);
+int multi_get_stats(rt_ctx *front, rt_stats *out);
+int multi_device_pixels(rt_ctx *front, void **dptr, size_t *count);
+int multi_pin_output(rt_ctx *front, uint32_t *out_host, size_t count);
+void *multi_stream(rt_ctx *front);
+int multi_shards(const rt_ctx *front);
+int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg);
+
+}  // namespace rt

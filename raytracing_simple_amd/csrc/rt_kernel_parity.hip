@@ -2,22 +2,30 @@
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
 //   [0] rt_trace_parity        shipped: small scenes
 //   [4] rt_trace_parity_coop   shipped: scenes with >= 12 spheres (cooperative any-hit)
-// the rest are A/B and diagnostic shapes of the same arithmetic (mode 100+k, tools/ab_bench.py).
+// Everything else exists only in the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1):
+// A/B and verification shapes of the same arithmetic (mode 100+k, tools/ab_bench.py) and the
+// exhaustive device-side checks of the lean square root / reciprocal.
 #pragma clang fp contract(off)
 #define RT_FAST 0
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
+#endif
 
 #define RT_NS parity
 #define RT_KERNEL_NAME rt_trace_parity
+#define RT_PACK_KERNEL_NAME rt_pack_parity
 #define RT_OPT_LEAN_SQRT 1
 #define RT_OPT_MINWAVES 6            /* <= 80 VGPRs: 6 wavefronts per SIMD */
 #include "rt_trace.inc.h"
+#if RT_DIAGNOSTICS
 #undef RT_OPT_MINWAVES
 #define RT_OPT_MINWAVES 1
 #define RT_SCHED_KERNEL_NAME rt_sched_parity
 #include "rt_sched.inc.h"
+#endif
 #include "rt_opts_reset.h"
 
-#define RT_VARIANT_KERNEL 1          /* the scalar-op eval kernel exists once, above */
+#define RT_VARIANT_KERNEL 1          /* the pack / scalar-op kernels exist once, above */
 
 #define RT_NS parity_coop
 #define RT_KERNEL_NAME rt_trace_parity_coop
@@ -27,6 +35,7 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#if RT_DIAGNOSTICS
 #define RT_NS parity_coopv           /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coopv
 #define RT_OPT_COOP 2
@@ -61,35 +70,59 @@
 #define RT_NS parity_r0              /* A/B: the shipped shape without its newest change */
 #define RT_KERNEL_NAME rt_trace_parity_r0
 #define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_GLOSS_ID 0
+#define RT_OPT_AB_OLD 1
 #define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
+
+#define RT_NS parity_tl              /* the shipped shape + device wall-clock logging (P.timelog / P.wavelog) */
+#define RT_KERNEL_NAME rt_trace_parity_tl
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_TIMELOG 1
+#define RT_OPT_MINWAVES 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+#endif   // RT_DIAGNOSTICS
 
 namespace rt {
 
 using KernelFn = void (*)(const LaunchParams);
 static KernelFn const kParityKernels[] = {
     parity::rt_trace_parity,            // 0
+#if RT_DIAGNOSTICS
     parity_a5::rt_trace_parity_a5,      // 1  census
     parity::rt_sched_parity,            // 2  stage-scheduled (in-register queue) A/B
     parity_a5::rt_sched_parity_a5,      // 3  its census
+#else
+    nullptr, nullptr, nullptr,
+#endif
     parity_coop::rt_trace_parity_coop,  // 4  = kParityCoopVariant
+#if RT_DIAGNOSTICS
     parity_coopv::rt_trace_parity_coopv,  // 5
     parity_persist::rt_trace_parity_persist,            // 6 = kParityPersistVariant
     parity_persist_coop::rt_trace_parity_persist_coop,  // 7 = kParityPersistCoopVariant
     parity_r0::rt_trace_parity_r0,                      // 8
+    parity_tl::rt_trace_parity_tl,                      // 9 = kParityTimelogVariant
+#endif
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
 int parity_variant_count() { return kParityCount; }
 
 hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
-    if (variant < 0 || variant >= kParityCount) return hipErrorInvalidValue;
+    if (variant < 0 || variant >= kParityCount || !kParityKernels[variant]) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kParityKernels[variant], grid, dim3(kBlockThreads), lds, stream, p);
     return hipGetLastError();
 }
 
+hipError_t launch_pack_parity(const LaunchParams &p, hipStream_t stream) {
+    if (p.local_rows <= 0 || p.w <= 0) return hipSuccess;
+    hipLaunchKernelGGL(parity::rt_pack_parity, dim3((unsigned)((p.w + 63) / 64), (unsigned)((p.local_rows + 3) / 4)),
+                       dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+#if RT_DIAGNOSTICS
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(parity::rt_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -110,9 +143,11 @@ hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream) {
     hipLaunchKernelGGL(parity::rt_rcp_probe_kernel, dim3(256 * 16), dim3(256), 0, stream, d_hist);
     return hipGetLastError();
 }
+#endif
 
 hipError_t prepare_parity() {
     for (KernelFn k : kParityKernels) {
+        if (!k) continue;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         if (e != hipSuccess) return e;

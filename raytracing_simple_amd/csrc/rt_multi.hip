@@ -1,0 +1,417 @@
+// rt_multi.hip -- one context on several GPUs of one process (rt_create(w,h,ngpus); 8e).
+//
+// The reference has no multi-device code; its host (SimpleRT/src/Main.cpp:29-102) drives ONE
+// backend object through Config::updateRendering (Config.cpp:73-81) and reads ONE pixel buffer
+// (OpenCLConfig.cpp:407-515 is what execute() must still look like to it).  A multi-device context
+// keeps exactly that face: the image is sharded by interleaved row tiles (tile t -> device t % n),
+// every device renders its rows with an ordinary sharded context on its own stream, and each frame
+// ends with ONE gather into the first device over RCCL/xGMI --
+//     ncclGroupStart;  root: ncclRecv x (n-1);  every other device: ncclSend;  ncclGroupEnd   (ncclUint32)
+// -- seven point-to-point transfers over seven distinct links into the root, no ring; then the
+// de-interleave kernel (rt_deinterleave_rows) and one copy to the host.  The root's own rows are
+// rendered straight into its receive slot, so they are never copied.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, the copy already in the process if there is one):
+// hosts that never ask for a multi-device context do not load it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "rt_internal.h"
+
+using rt::fail;
+
+namespace {
+
+// ---- the slice of the RCCL API this file uses (rccl.h: ncclResult_t = int, ncclComm_t = opaque pointer) ----
+typedef void *rcclComm;
+struct Rccl {
+    void *handle = nullptr;
+    int (*CommInitAll)(rcclComm *, int, const int *) = nullptr;
+    int (*CommDestroy)(rcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, rcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, rcclComm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kRcclUint32 = 3;          // ncclUint32 (rccl.h: ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3)
+
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.handle) return RT_OK;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;                  // a copy the process already has (torch's)
+    for (const char *n : names) {
+        if (h) break;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!h) return fail(RT_ERR_NO_DEVICE, "librccl.so.1 cannot be loaded (%s): a multi-device context needs RCCL", dlerror());
+    Rccl r;
+    r.handle = h;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString)
+        return fail(RT_ERR_NO_DEVICE, "librccl.so.1 lacks one of ncclCommInitAll/ncclGroupStart/ncclSend/ncclRecv/...");
+    g_rccl = r;
+    return RT_OK;
+}
+
+#define RCCL_TRY(call)                                                                                  \
+    do {                                                                                                \
+        int r_ = (call);                                                                                \
+        if (r_ != 0) return fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r_), \
+                                 __FILE__, __LINE__);                                                   \
+    } while (0)
+
+}  // namespace
+
+struct rt_multi {
+    int n = 0;
+    int w = 0, h = 0, tile_rows = 8, pad_rows = 0;
+    bool emulated = false;              // a device is listed twice: D2D copies stand in for ncclSend/ncclRecv
+    std::vector<int> devices;
+    std::vector<rt_ctx *> shard;        // shard[r] = rt_create_sharded(w, h, devices[r], r, n, tile_rows)
+    std::vector<rcclComm> comm;         // one per device (ncclCommInitAll), empty when emulated
+    uint32_t *d_gathered = nullptr;     // root: [n][pad_rows][w], rank r's block at r * pad_rows * w
+    uint32_t *d_full = nullptr;         // root: [h][w], the assembled frame
+    hipEvent_t ev_ready = nullptr;      // emulation: a shard's render done, on its device
+    uint32_t *pinned_out = nullptr;
+    double last_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+namespace {
+
+int rows_of(int h, int rank, int n, int tile_rows) {
+    const int n_tiles = (h + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int t = rank; t < n_tiles; t += n) rows += (t * tile_rows + tile_rows <= h) ? tile_rows : (h - t * tile_rows);
+    return rows;
+}
+
+// the frame-end gather + assembly, queued behind the renders; root stream ends up holding everything
+int gather_and_assemble(rt_multi *m) {
+    rt_ctx *root = m->shard[0];
+    const size_t block = (size_t)m->pad_rows * (size_t)m->w;
+    if (m->n > 1 && !m->emulated) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int r = 1; r < m->n; ++r) {
+            const size_t count = (size_t)m->shard[r]->local_rows * (size_t)m->w;
+            if (!count) continue;
+            HIP_TRY(hipSetDevice(m->devices[0]));
+            RCCL_TRY(g_rccl.Recv(m->d_gathered + (size_t)r * block, count, kRcclUint32, r, m->comm[0], root->stream));
+            HIP_TRY(hipSetDevice(m->devices[r]));
+            RCCL_TRY(g_rccl.Send(m->shard[r]->d_pixels, count, kRcclUint32, 0, m->comm[r], m->shard[r]->stream));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    } else if (m->n > 1) {
+        // one-GPU rehearsal: the receive slot is filled by a device-to-device copy on the ROOT's stream, which
+        // first waits for the sending shard's render (what ncclRecv's pairing with ncclSend does on real links)
+        for (int r = 1; r < m->n; ++r) {
+            const size_t count = (size_t)m->shard[r]->local_rows * (size_t)m->w;
+            if (!count) continue;
+            HIP_TRY(hipSetDevice(m->devices[r]));
+            HIP_TRY(hipEventRecord(m->ev_ready, m->shard[r]->last_stream));
+            HIP_TRY(hipSetDevice(m->devices[0]));
+            HIP_TRY(hipStreamWaitEvent(root->stream, m->ev_ready, 0));
+            HIP_TRY(hipMemcpyAsync(m->d_gathered + (size_t)r * block, m->shard[r]->d_pixels, count * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, root->stream));
+        }
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    return rt_deinterleave_rows(m->d_full, m->d_gathered, m->w, m->h, m->n, m->tile_rows, m->pad_rows, m->devices[0], root->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, int ngpus, int tile_rows) {
+    if (!out) return fail(RT_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (w <= 0 || h <= 0) return fail(RT_ERR_ARG, "image size %dx%d", w, h);
+    if (ngpus < 1 || ngpus > 64 || !devices) return fail(RT_ERR_ARG, "ngpus %d", ngpus);
+    if (tile_rows == 0) tile_rows = rt::kTileH;
+    if (tile_rows < 0 || tile_rows % rt::kTileH != 0) return fail(RT_ERR_ARG, "tile_rows must be a positive multiple of %d", rt::kTileH);
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    bool repeated = false;
+    for (int i = 0; i < ngpus; ++i) {
+        if (devices[i] < 0 || devices[i] >= n_dev) return fail(RT_ERR_ARG, "device %d of %d", devices[i], n_dev);
+        for (int j = 0; j < i; ++j) repeated = repeated || devices[j] == devices[i];
+    }
+
+    rt_ctx *front = new (std::nothrow) rt_ctx();
+    rt_multi *m = new (std::nothrow) rt_multi();
+    if (!front || !m) {
+        delete front;
+        delete m;
+        return fail(RT_ERR_ALLOC, "host allocation failed");
+    }
+    front->multi = m;
+    front->w = w;
+    front->h = h;
+    front->device = devices[0];
+    front->tile_rows = tile_rows;
+    front->local_rows = h;              // the whole image
+    m->n = ngpus;
+    m->w = w;
+    m->h = h;
+    m->tile_rows = tile_rows;
+    m->emulated = repeated;
+    m->devices.assign(devices, devices + ngpus);
+    for (int r = 0; r < ngpus; ++r) m->pad_rows = rows_of(h, r, ngpus, tile_rows) > m->pad_rows ? rows_of(h, r, ngpus, tile_rows) : m->pad_rows;
+
+    auto build = [&]() -> int {
+        if (!m->emulated) {
+            int rc = load_rccl();
+            if (rc != RT_OK) return rc;
+            m->comm.assign(ngpus, nullptr);
+            RCCL_TRY(g_rccl.CommInitAll(m->comm.data(), ngpus, m->devices.data()));      // also for ngpus = 1: a communicator of one
+        }
+        for (int r = 0; r < ngpus; ++r) {
+            rt_ctx *s = nullptr;
+            int rc = rt_create_sharded(&s, w, h, devices[r], r, ngpus, tile_rows);
+            if (rc != RT_OK) return rc;
+            m->shard.push_back(s);
+        }
+        HIP_TRY(hipSetDevice(devices[0]));
+        HIP_TRY(hipMalloc(&m->d_gathered, ((size_t)ngpus * m->pad_rows * w + 4) * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&m->d_full, ((size_t)w * h + 4) * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(m->d_gathered, 0, (size_t)ngpus * m->pad_rows * w * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(m->d_full, 0, (size_t)w * h * sizeof(uint32_t)));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
+        // the root renders its own rows straight into its receive slot
+        return rt_set_pixel_buffer(m->shard[0], m->d_gathered, (size_t)m->pad_rows * w);
+    };
+    int rc = build();
+    if (rc != RT_OK) {
+        char keep[512];
+        snprintf(keep, sizeof keep, "%s", rt_last_error());
+        rt_destroy(front);
+        fail(rc, "%s", keep);
+        return rc;
+    }
+    *out = front;
+    return RT_OK;
+}
+
+RT_API int rt_create_multi(rt_ctx **out, int w, int h, int ngpus) {
+    if (ngpus < 1 || ngpus > 64) return fail(RT_ERR_ARG, "ngpus %d", ngpus);
+    int devices[64];
+    for (int i = 0; i < ngpus; ++i) devices[i] = i;
+    return rt_create_multi_on(out, w, h, devices, ngpus, rt::kTileH);
+}
+
+}  // extern "C"
+
+namespace rt {
+
+void multi_destroy(rt_ctx *front) {
+    rt_multi *m = front->multi;
+    if (!m) return;
+    for (rt_ctx *s : m->shard) rt_destroy(s);           // waits for each shard's stream
+    if (!m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess) {
+        if (m->pinned_out) (void)hipHostUnregister(m->pinned_out);
+        (void)hipFree(m->d_gathered);
+        (void)hipFree(m->d_full);
+        if (m->ev_ready) (void)hipEventDestroy(m->ev_ready);
+    }
+    for (rcclComm c : m->comm)
+        if (c) (void)g_rccl.CommDestroy(c);
+    delete m;
+    front->multi = nullptr;
+}
+
+int multi_shards(const rt_ctx *front) { return front->multi->n; }
+
+#define EACH_SHARD(expr)                          \
+    do {                                          \
+        for (rt_ctx * s : front->multi->shard) {  \
+            int rc_ = (expr);                     \
+            if (rc_ != RT_OK) return rc_;         \
+        }                                         \
+        return RT_OK;                             \
+    } while (0)
+
+int multi_set_scene(rt_ctx *front, const rt_sphere *spheres, uint32_t count) { EACH_SHARD(rt_set_scene(s, spheres, count)); }
+int multi_update_spheres(rt_ctx *front, uint32_t first, uint32_t count, const rt_sphere *spheres) {
+    EACH_SHARD(rt_update_spheres_async(s, first, count, spheres, s->stream));
+}
+int multi_set_camera(rt_ctx *front, const rt_camera *cam) { EACH_SHARD(rt_set_camera(s, cam)); }
+int multi_set_mode(rt_ctx *front, int mode) { EACH_SHARD(rt_set_mode(s, mode)); }
+int multi_set_pixel_write(rt_ctx *front, int enable) { EACH_SHARD(rt_set_pixel_write(s, enable)); }
+int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg) { EACH_SHARD(fn(s, arg)); }
+
+int multi_reset(rt_ctx *front, bool async) {
+    rt_multi *m = front->multi;
+    m->launches = 0;
+    m->last_ms = 0.0;
+    front->current_sample = 0;
+    EACH_SHARD(async ? rt_reset_async(s, s->stream) : rt_reset(s));
+}
+
+void *multi_stream(rt_ctx *front) { return (void *)front->multi->shard[0]->stream; }
+
+int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking) {
+    rt_multi *m = front->multi;
+    if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
+    // every device starts its rows before any is waited for
+    for (int r = 0; r < m->n; ++r) {
+        rt_ctx *s = m->shard[r];
+        HIP_TRY(hipSetDevice(s->device));
+        if (blocking) HIP_TRY(hipEventRecord(s->ev0, s->stream));
+        int rc = rt_render_async(s, n_samples, s->stream);
+        if (rc != RT_OK) return rc;
+        if (blocking) HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    }
+    front->current_sample = m->shard[0]->current_sample;
+    if (n_samples > 0) m->launches += 1;
+    const bool frame_wanted = m->shard[0]->pixel_write != 0 && n_samples > 0;
+    if (frame_wanted) {
+        int rc = gather_and_assemble(m);
+        if (rc != RT_OK) return rc;
+    }
+    if (!blocking) return RT_OK;
+    rt_ctx *root = m->shard[0];
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    if (out_host)
+        HIP_TRY(hipMemcpyAsync(out_host, m->d_full, (size_t)m->w * m->h * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
+    double worst = 0.0;
+    for (int r = 0; r < m->n; ++r) {
+        rt_ctx *s = m->shard[r];
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        float ms = 0.f;
+        if (n_samples > 0 && s->local_rows > 0) HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        s->last_ms = ms;
+        worst = ms > worst ? ms : worst;
+    }
+    m->last_ms = worst;                 // the frame's kernel time = its slowest shard
+    return RT_OK;
+}
+
+int multi_read_pixels(rt_ctx *front, uint32_t *out_host) {
+    rt_multi *m = front->multi;
+    rt_ctx *root = m->shard[0];
+    const size_t block = (size_t)m->pad_rows * (size_t)m->w;
+    // shards whose last launches skipped the pixel store pack their rows now; then the usual gather
+    bool stale = false;
+    for (rt_ctx *s : m->shard) stale = stale || (!s->pixels_current && s->current_sample > 0);
+    if (stale) {
+        std::vector<uint32_t> tmp;
+        for (int r = 0; r < m->n; ++r) {
+            rt_ctx *s = m->shard[r];
+            if (s->local_rows == 0) continue;
+            // rt_read_pixels packs into the shard's pixel buffer (the root's is its receive slot); the host copy is a by-product
+            tmp.resize((size_t)s->local_rows * m->w);
+            int rc = rt_read_pixels(s, tmp.data());
+            if (rc != RT_OK) return rc;
+        }
+        int rc = gather_and_assemble(m);
+        if (rc != RT_OK) return rc;
+    }
+    (void)block;
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    for (int r = 1; r < m->n; ++r) {                    // async renders on the other devices
+        HIP_TRY(hipSetDevice(m->devices[r]));
+        HIP_TRY(hipStreamSynchronize(m->shard[r]->stream));
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipMemcpyAsync(out_host, m->d_full, (size_t)m->w * m->h * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    return RT_OK;
+}
+
+// colour plane / seeds: every shard holds full-size buffers in which only its own rows are live
+static void rows_to(const rt_multi *m, int r, const void *src, void *dst, size_t bytes_per_px, bool flipped) {
+    const int n_tiles = (m->h + m->tile_rows - 1) / m->tile_rows;
+    const size_t row_bytes = (size_t)m->w * bytes_per_px;
+    for (int t = r; t < n_tiles; t += m->n)
+        for (int y = t * m->tile_rows; y < (t + 1) * m->tile_rows && y < m->h; ++y) {
+            const size_t row = flipped ? (size_t)(m->h - 1 - y) : (size_t)y;     // .cl:579: the colour plane is y-flipped
+            memcpy(static_cast<char *>(dst) + row * row_bytes, static_cast<const char *>(src) + row * row_bytes, row_bytes);
+        }
+}
+
+int multi_read_colors(rt_ctx *front, float *out_host) {
+    rt_multi *m = front->multi;
+    std::vector<float> tmp((size_t)3 * m->w * m->h);
+    for (int r = 0; r < m->n; ++r) {
+        int rc = rt_read_colors(m->shard[r], tmp.data());
+        if (rc != RT_OK) return rc;
+        rows_to(m, r, tmp.data(), out_host, 12, true);
+    }
+    return RT_OK;
+}
+
+int multi_read_seeds(rt_ctx *front, uint32_t *out_host) {
+    rt_multi *m = front->multi;
+    std::vector<uint32_t> tmp((size_t)2 * m->w * m->h);
+    for (int r = 0; r < m->n; ++r) {
+        int rc = rt_read_seeds(m->shard[r], tmp.data());
+        if (rc != RT_OK) return rc;
+        rows_to(m, r, tmp.data(), out_host, 8, false);
+    }
+    return RT_OK;
+}
+
+int multi_get_stats(rt_ctx *front, rt_stats *out) {
+    rt_multi *m = front->multi;
+    rt_stats sum{};
+    for (rt_ctx *s : m->shard) {
+        rt_stats st;
+        int rc = rt_get_stats(s, &st);
+        if (rc != RT_OK) return rc;
+        sum.samples += st.samples;
+        sum.closest_rays += st.closest_rays;
+        sum.shadow_rays += st.shadow_rays;
+        sum.sphere_tests += st.sphere_tests;
+        sum.rng_draws += st.rng_draws;
+    }
+    sum.launches = m->launches;
+    sum.last_kernel_ms = m->last_ms;
+    *out = sum;
+    return RT_OK;
+}
+
+int multi_device_pixels(rt_ctx *front, void **dptr, size_t *count) {
+    *dptr = front->multi->d_full;
+    *count = (size_t)front->multi->w * (size_t)front->multi->h;
+    return RT_OK;
+}
+
+int multi_pin_output(rt_ctx *front, uint32_t *out_host, size_t count) {
+    rt_multi *m = front->multi;
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    if (m->pinned_out) {
+        HIP_TRY(hipStreamSynchronize(m->shard[0]->stream));
+        (void)hipHostUnregister(m->pinned_out);
+        m->pinned_out = nullptr;
+    }
+    if (!out_host) return RT_OK;
+    if (count < (size_t)m->w * (size_t)m->h) return fail(RT_ERR_ARG, "output buffer of %zu < %zu elements", count, (size_t)m->w * (size_t)m->h);
+    HIP_TRY(hipHostRegister(out_host, count * sizeof(uint32_t), hipHostRegisterDefault));
+    m->pinned_out = out_host;
+    return RT_OK;
+}
+
+}  // namespace rt

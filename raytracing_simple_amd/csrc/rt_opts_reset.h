@@ -17,3 +17,6 @@
 #undef RT_OPT_JOINT_SKIP
 #undef RT_OPT_ANY_JOINT
 #undef RT_OPT_GLOSS_ID
+#undef RT_OPT_TIMELOG
+#undef RT_OPT_AB_OLD
+#undef RT_PACK_KERNEL_NAME

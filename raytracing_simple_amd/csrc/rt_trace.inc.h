@@ -47,6 +47,18 @@
 #ifndef RT_OPT_WAVE_TILE_W
 #define RT_OPT_WAVE_TILE_W 8
 #endif
+// RT_OPT_TIMELOG: diagnostic instance only -- device wall-clock (s_memrealtime) of the launch's first
+// start and last end into P.timelog[P.seq], and of every wavefront into P.wavelog (when non-null)
+#ifndef RT_OPT_TIMELOG
+#define RT_OPT_TIMELOG 0
+#endif
+// RT_OPT_AB_OLD: the `parity_r0` A/B instance = the shipped shape minus its newest change (tools/ab_bench.py)
+#ifndef RT_OPT_AB_OLD
+#define RT_OPT_AB_OLD 0
+#endif
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
+#endif
 // RT_OPT_COOP: shadow rays of a wavefront share the idle lanes (coop_any); for large scenes
 #ifndef RT_OPT_COOP
 #define RT_OPT_COOP 0
@@ -596,6 +608,14 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     // ---- pixel of this lane ---------------------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
     (void)wave;
+#if RT_OPT_TIMELOG
+    const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+    if (P.timelog && tid == 0) atomicMin(&P.timelog[8 * (size_t)P.seq], tl_start);
+    if (P.timelog && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        P.timelog[8 * (size_t)P.seq + 2] = 1ull;
+        P.timelog[8 * (size_t)P.seq + 3] = P.tl_tag;
+    }
+#endif
 #if RT_OPT_PERSIST
     // pixels are handed out inside the loop; nothing is owned yet
     int x = 0, lrow = 0, y = 0;
@@ -624,16 +644,17 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
 
-    const size_t gid = (size_t)y * (size_t)P.w + (size_t)x;                 // .cl:560-563
-    const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;      // .cl:579
-
     uint32_t s0 = 0, s1 = 0;
     V3 acc = mk(0.f, 0.f, 0.f);
     int s = P.first_sample;
     const int s_end = valid ? P.first_sample + P.n_samples : P.first_sample;
     if (valid) {
-        s0 = P.seeds_in[2 * gid];
-        s1 = P.seeds_in[2 * gid + 1];
+        // (the two 64-bit indices are formed again after the loop instead of staying live through it)
+        const size_t gid = (size_t)y * (size_t)P.w + (size_t)x;             // .cl:560-563
+        const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;  // .cl:579
+        const uint2 sd = *reinterpret_cast<const uint2 *>(P.seeds_in + 2 * gid);
+        s0 = sd.x;
+        s1 = sd.y;
         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
     }
 #endif
@@ -1009,15 +1030,30 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     }
 
 #if !RT_OPT_PERSIST
-    if (valid && P.n_samples > 0) {
-        P.colors[3 * ci] = acc.x;
-        P.colors[3 * ci + 1] = acc.y;
-        P.colors[3 * ci + 2] = acc.z;
-        if (!P.skip_pixels)                                                // (wave-uniform)
-            P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =              // .cl:594-596
+    // The arguments the epilogue needs are read from the kernel-argument segment AGAIN here (a fresh
+    // scalar load behind an opaque pointer) instead of staying live in SGPRs through the loop: the loop
+    // already fills the scalar file, and keeping them cost SGPR spills and with them a private segment.
+#if RT_OPT_AB_OLD
+    const LaunchParams &Q = P;
+#else
+    const __attribute__((address_space(4))) LaunchParams *qp =
+        (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; epilogue arguments re-read" : "+s"(qp));
+    const __attribute__((address_space(4))) LaunchParams &Q = *qp;
+#endif
+    if (valid && Q.n_samples > 0) {
+        int xe = x, ye = y, le = lrow;
+        asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
+        const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;           // .cl:560-563
+        const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;   // .cl:579
+        float *colors = Q.colors;
+        colors[3 * ci] = acc.x;
+        colors[3 * ci + 1] = acc.y;
+        colors[3 * ci + 2] = acc.z;
+        if (!Q.skip_pixels)                                                // (wave-uniform)
+            Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =               // .cl:594-596
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
-        P.seeds[2 * gid] = s0;                                             // .cl:598-599
-        P.seeds[2 * gid + 1] = s1;
+        *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);   // .cl:598-599
     }
 
 #endif
@@ -1025,7 +1061,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 #if RT_OPT_PERSIST
     uint32_t n_done = c_samples;
 #else
-    uint32_t n_done = valid ? (uint32_t)P.n_samples : 0u;
+    uint32_t n_done = valid ? (uint32_t)Q.n_samples : 0u;
 #endif
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);
@@ -1047,15 +1083,50 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     __syncthreads();
     if (tid < 5) {
         const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
+#if RT_OPT_PERSIST
         atomicAdd(&P.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
+#else
+        atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
+#endif
     }
 #if RT_OPT_STAMPS
     __syncthreads();
     if (tid < 12) atomicAdd(&P.counters[8 + tid], s_census[tid]);
 #endif
+#if RT_OPT_TIMELOG
+    {
+        const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime();
+        if (P.timelog && tid == 0) atomicMax(&P.timelog[8 * (size_t)P.seq + 1], tl_end);
+        if (P.wavelog && lane == 0) {
+            const size_t wi = ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 4 + (size_t)wave) * 3;
+            uint32_t hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            P.wavelog[wi] = tl_start;
+            P.wavelog[wi + 1] = tl_end;
+            P.wavelog[wi + 2] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#endif
 }
 
-#if !RT_FAST && !defined(RT_VARIANT_KERNEL)
+#if !defined(RT_VARIANT_KERNEL)
+// The packed frame from the colour plane (.cl:34,594-596) with this mode's toInt, for frames whose
+// launches ran with the pixel store switched off (rt_set_pixel_write(ctx, 0) ... rt_read_pixels).
+// One thread per local pixel; rows map to image rows as in the render kernel.
+extern "C" __global__ void RT_PACK_KERNEL_NAME(const LaunchParams P) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lrow = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tile = lrow / P.tile_rows;
+    const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
+    if (x >= P.w || lrow >= P.local_rows || y >= P.h) return;
+    const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;
+    const float r = P.colors[3 * ci], g = P.colors[3 * ci + 1], b = P.colors[3 * ci + 2];
+    P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] = (uint32_t)(to_int(r) | (to_int(g) << 8) | (to_int(b) << 16));
+}
+#endif
+
+#if !RT_FAST && !defined(RT_VARIANT_KERNEL) && RT_DIAGNOSTICS
 // every binary32 bit pattern: ieee_sqrt_lean against the compiler's correctly rounded sqrtf
 extern "C" __global__ void rt_sqrt_check_kernel(unsigned long long *mismatches) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;

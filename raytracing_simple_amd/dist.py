@@ -88,9 +88,23 @@ class FrameGatherer:
         return self._full[k] if self._full else None
 
     def _assemble(self, k):
-        """De-interleave the gathered blocks into the image with at most three strided copies
-        (tile t of the image is local tile t // n of rank t % n): all complete groups of n
-        full-height tiles at once, the last incomplete group, the short tile at the bottom."""
+        """De-interleave the gathered blocks into the image on the gather root: the library's HIP kernel
+        (rt_deinterleave_rows, include/rt_api.h) on the current stream for device buffers.  Host tensors
+        (the gloo rehearsals of the CPU test-suite, which have no device) go through _assemble_strided."""
+        if self.rank != self.dst:
+            return None
+        st, full = self._stacked[k], self._full[k]
+        if st.is_cuda:
+            from . import api
+            api.deinterleave_rows(full.data_ptr(), st.data_ptr(), self.w, self.h, self.nranks, self.tile_rows, self.pad,
+                                  device=st.device.index or 0, stream=torch.cuda.current_stream(st.device).cuda_stream)
+            return full
+        return self._assemble_strided(k)
+
+    def _assemble_strided(self, k):
+        """The same permutation with at most three strided copies (tile t of the image is local tile
+        t // n of rank t % n): all complete groups of n full-height tiles at once, the last incomplete
+        group, the short tile at the bottom.  Host tensors, and the cross-check of the kernel in tests."""
         if self.rank != self.dst:
             return None
         n, tr, w, h = self.nranks, self.tile_rows, self.w, self.h

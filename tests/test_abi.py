@@ -4,6 +4,7 @@ oracle and with the reference-generated pins.  No device compute here."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -18,14 +19,38 @@ def _gpu_present():
     return os.path.exists("/dev/kfd")
 
 
-def test_library_exports_every_declared_symbol():
-    text = open(os.path.join(ROOT, "include", "rt_api.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    declared = sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+def _exports(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_library_exports_exactly_the_declared_symbols():
+    """librt_hip.so exports what include/rt_api.h declares and NOTHING else (no rt_debug_*, no kernel
+    stubs, no C++ runtime instantiations); librt_hip_diag.so adds exactly include/rt_debug.h."""
+    from raytracing_simple_amd import _build
+    declared = _build.declared_symbols("rt_api.h")
     assert declared == sorted(api.SYMBOLS)
     lib = api.load_library()
     for name in declared:
         assert hasattr(lib, name), name
+    assert _exports(api.lib_path()) == declared
+    debug = sorted(set(_build.declared_symbols("rt_debug.h")) - set(declared))
+    assert debug == sorted(api.DEBUG_SYMBOLS)
+    assert _exports(api.lib_path(diag=True)) == sorted(declared + debug)
+    assert not any(n.startswith("rt_debug") for n in _exports(api.lib_path()))
+
+
+def test_no_built_binaries_are_tracked():
+    """Built artefacts stay out of history (.gitignore policy): no ELF file in the index."""
+    files = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True)
+    if files.returncode != 0:
+        pytest.skip("not a git checkout (GPU box snapshot)")
+    elf = []
+    for f in files.stdout.split():
+        p = os.path.join(ROOT, f)
+        if os.path.isfile(p) and open(p, "rb").read(4) == b"\x7fELF":
+            elf.append(f)
+    assert elf == []
 
 
 def test_struct_layouts_match_reference_sizes():
@@ -146,3 +171,21 @@ def test_ppm_writer_flips_rows(tmp_path):
     assert raw.startswith(b"P6\n2 3\n255\n")
     body = np.frombuffer(raw[len(b"P6\n2 3\n255\n"):], np.uint8).reshape(3, 2, 3)
     assert body[0, 0, 0] == 4 and body[2, 1, 0] == 1       # top row of the file = buffer row 2
+
+
+def test_committed_scn_files_equal_the_generators():
+    """the synthetic BASELINE configurations exist as committed .scn files (the reference's wire
+    format, Utility.cpp:90-160) so that the C++ hosts -- tools/rt_bench, the reference's own Main.cpp
+    through the adapter -- can run all five configurations; they must be the generators' bytes."""
+    from raytracing_simple_amd import scenes
+    d = os.path.join(ROOT, "raytracing_simple_amd", "scenes_scn")
+    for name, maker in (("c3_random_1024.scn", lambda: scenes.random_spheres(1024)),
+                        ("c5_mirror_box_64.scn", lambda: scenes.mirror_box(64)),
+                        ("c16_demo_plus_10.scn", lambda: scenes.demo_plus(16))):
+        sph, orig, target = maker()
+        got, o2, t2 = host.read_scene(os.path.join(d, name), reference_doubling=False)
+        assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(sph).view(np.uint8)), name
+        assert np.array_equal(np.float32(orig), np.float32(o2)) and np.array_equal(np.float32(target), np.float32(t2))
+        doubled, _, _ = host.read_scene(os.path.join(d, name), reference_doubling=True)     # what the reference's loader hands over
+        assert len(doubled) == 2 * len(sph) and not doubled[: len(sph)].view(np.uint8).any()
+        assert np.array_equal(doubled[len(sph):].view(np.uint8), got.view(np.uint8))

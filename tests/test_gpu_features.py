@@ -1,0 +1,246 @@
+"""Round-2 rows of the scope table, each against the oracle through the C ABI: the multi-device context
+(shards -> one gather -> de-interleave kernel), device-resident scene updates (8f-4),
+rt_read_pixels, the cached one-shot rt_render."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from raytracing_simple_amd import api, host, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(ctx, px):
+    return {"pixels": px, "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+
+
+def _assert_same(got, want):
+    assert np.array_equal(got["pixels"], want["pixels"])
+    assert np.array_equal(got["colors"].view(np.uint32), want["colors"].view(np.uint32))
+    assert np.array_equal(got["seeds"], want["seeds"])
+    g, o = got["stats"], want["stats"]
+    assert (g["samples"], g["closest_rays"], g["shadow_rays"], g["sphere_tests"], g["rng_draws"]) == \
+           (o["samples"], o["closest_calls"], o["shadow_calls"], o["sphere_tests"], o["rng_draws"])
+
+
+# ---- multi-device context ----------------------------------------------------------------------------
+@pytest.mark.parametrize("devices,tile_rows,w,h", [
+    ([0], 8, 160, 96),                  # ngpus = 1: the RCCL path itself, a communicator of one
+    ([0, 0], 8, 160, 96),               # one-GPU rehearsal: shards -> D2D stand-in for the recv -> de-interleave kernel
+    ([0, 0, 0], 16, 97, 61),            # ragged: w % 4 != 0 (scalar de-interleave), short last tile, uneven tile counts
+    ([0] * 8, 8, 256, 200),
+    ([0] * 8, 8, 64, 24),               # more shards than row tiles: five shards own nothing
+])
+def test_multi_device_context_equals_the_oracle(devices, tile_rows, w, h):
+    sph, orig, target = scenes.demo_plus(16)
+    cam = host.compute_camera(orig, target, w, h)
+    spp = 5
+    want = O.render(sph, cam, w, h, spp)
+    with api.RtContext(w, h, devices=devices, tile_rows=tile_rows) as ctx:
+        assert ctx.shard_count == len(devices) and ctx.local_rows == h
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+        # progressive: the same frame in three launches after a reset, the middle one without pixel stores
+        ctx.reset()
+        ctx.render_pass(2)
+        ctx.set_pixel_write(False)
+        ctx.render_pass(2)
+        assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, 4)["pixels"])      # packed on demand, then gathered
+        ctx.set_pixel_write(True)
+        _assert_same(_state(ctx, ctx.render_pass(1)), want)
+        # asynchronous reset + fast mode round trip leave the parity result untouched
+        ctx.reset_async()
+        ctx.set_mode(api.RT_MODE_FAST)
+        fast = ctx.render_pass(spp)
+        assert host.psnr(fast, want["pixels"]) >= 45.0
+        ctx.reset()
+        ctx.set_mode(api.RT_MODE_PARITY)
+        _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+
+
+def test_multi_device_context_at_full_size_equals_the_single_device_frame():
+    """C2 (1080p, 64 spp) on 8 emulated shards = the unsharded frame, bit for bit, counters included."""
+    w, h, spp = 1920, 1080, 64
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    with api.RtContext(w, h) as one:
+        one.set_scene(sph); one.set_camera(cam)
+        want = _state(one, one.render_pass(spp))
+    with api.RtContext(w, h, devices=[0] * 8) as ctx:
+        ctx.set_scene(sph); ctx.set_camera(cam)
+        got = _state(ctx, ctx.render_pass(spp))
+    assert np.array_equal(got["pixels"], want["pixels"])
+    assert np.array_equal(got["colors"].view(np.uint32), want["colors"].view(np.uint32))
+    assert np.array_equal(got["seeds"], want["seeds"])
+    assert {k: v for k, v in got["stats"].items() if k not in ("launches", "last_kernel_ms")} == \
+           {k: v for k, v in want["stats"].items() if k not in ("launches", "last_kernel_ms")}
+
+
+def test_multi_device_argument_checks():
+    lib = api.load_library()
+    h_ = C.c_void_p()
+    assert lib.rt_create_multi(C.byref(h_), 64, 64, 0) == -1
+    assert lib.rt_create_multi(C.byref(h_), 64, 64, 99) == -1                 # more devices than the box has
+    arr = (C.c_int * 2)(0, 7)
+    assert lib.rt_create_multi_on(C.byref(h_), 64, 64, arr, 2, 8) == -1
+    arr = (C.c_int * 2)(0, 0)
+    assert lib.rt_create_multi_on(C.byref(h_), 64, 64, arr, 2, 12) == -1      # tile_rows % 8
+    with api.RtContext(32, 32, devices=[0, 0]) as ctx:
+        with pytest.raises(api.RtError):
+            ctx.set_pixel_buffer(1234, 32 * 32)                              # a multi-device context owns its frame buffer
+
+
+@pytest.mark.parametrize("w,h,n,tr", [(1920, 1080, 8, 8), (97, 61, 3, 16), (64, 24, 8, 8), (640, 360, 2, 8), (33, 17, 1, 8)])
+def test_deinterleave_kernel_equals_the_row_permutation(w, h, n, tr):
+    import torch
+    from raytracing_simple_amd import dist as rdist
+    dev = torch.device("cuda", 0)
+    pad = rdist.max_local_rows(h, n, tr)
+    rng = np.random.default_rng(w * h + n)
+    parts = [rng.integers(0, 2 ** 31, (pad, w), dtype=np.int64).astype(np.int32) for _ in range(n)]
+    stacked = torch.tensor(np.stack(parts), device=dev)
+    full = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    api.deinterleave_rows(full.data_ptr(), stacked.data_ptr(), w, h, n, tr, pad, device=0,
+                          stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = rdist.assemble_numpy([p.view(np.uint32) for p in parts], h, w, n, tr)
+    assert np.array_equal(full.cpu().numpy().view(np.uint32).reshape(-1), want)
+
+
+# ---- device-resident scene updates ----------------------------------------------------------------------
+def test_moving_spheres_and_camera_equal_the_oracle_frame_by_frame():
+    """Eight frames of an animation: two spheres move (one of them the light: the light list and its 4 pi r^2
+    are rebuilt on the device), a third changes material and starts to emit half-way (the light list grows),
+    the camera orbits.  Every frame restarts from the default seed stream and must equal the oracle."""
+    w, h, spp = 128, 80, 3
+    sph, orig, target = scenes.demo_plus(16)
+    sph = sph.copy()
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        for f in range(8):
+            sph["p"][3] += np.float32([1.5, 0.25, -0.75])                      # a diffuse sphere
+            lights = [i for i in range(len(sph)) if sph["e"][i][0] != 0 or sph["e"][i][2] != 0]
+            sph["p"][lights[0]] += np.float32([-0.5, 0.5, 0.25])               # the light itself
+            sph["rad"][lights[0]] *= np.float32(1.03)
+            ctx.update_spheres(3, sph[3:4], ctx.stream)
+            ctx.update_spheres(lights[0], sph[lights[0]:lights[0] + 1], ctx.stream)
+            if f == 4:
+                sph["refl"][7] = api.SPEC
+                sph["e"][9] = (3.0, 2.0, 1.0)                                  # a second light appears
+                ctx.update_spheres(7, sph[7:10], ctx.stream)
+            o = np.float32(orig) + np.float32([3.0 * f, 1.0 * f, -2.0 * f])
+            cam = host.compute_camera(tuple(float(v) for v in o), target, w, h)
+            ctx.set_camera(cam)
+            ctx.reset_async(ctx.stream)
+            ctx.render_async(spp, ctx.stream)
+            got = _state(ctx, ctx.read_pixels())
+            _assert_same(got, O.render(sph, cam, w, h, spp))
+
+
+def test_update_spheres_argument_checks_and_refused_scene_keeps_the_old_one():
+    w, h = 48, 32
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    want = O.render(sph, cam, w, h, 2)["pixels"]
+    with api.RtContext(w, h) as ctx:
+        with pytest.raises(api.RtError):
+            ctx.update_spheres(0, sph[:1])                                     # no scene yet
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        with pytest.raises(api.RtError):
+            ctx.update_spheres(5, sph[:2])                                     # runs past the end
+        too_many = np.zeros(8193, api.SPHERE_DT)
+        with pytest.raises(api.RtError):
+            ctx.set_scene(too_many)
+        lit = np.zeros(8000, api.SPHERE_DT)
+        lit["e"][:] = 1.0                                                      # 8000 lights: the light list alone overflows the LDS
+        with pytest.raises(api.RtError):
+            ctx.set_scene(lit)
+        assert np.array_equal(ctx.render_pass(2), want)                        # the Demo scene is still in place
+
+
+def test_scene_replaced_between_frames_without_a_device_wide_wait():
+    """rt_set_scene while another context keeps the GPU busy: ordered on the context's own work only."""
+    w, h = 96, 64
+    a, b = scenes.demo_plus(16), scenes.random_spheres(96)
+    with api.RtContext(w, h) as ctx, api.RtContext(640, 360) as busy:
+        busy.set_scene(host.demo_scene())
+        busy.set_camera(host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 640, 360))
+        for rnd in range(6):
+            busy.render_async(16, busy.stream)
+            sph, orig, target = (a, b)[rnd % 2]
+            cam = host.compute_camera(orig, target, w, h)
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            ctx.reset_async(ctx.stream)
+            ctx.render_async(2, ctx.stream)
+            assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, 2)["pixels"])
+
+
+# ---- rt_read_pixels --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [api.RT_MODE_PARITY, api.RT_MODE_FAST])
+def test_read_pixels_packs_the_frame_the_skipped_launches_left_behind(mode):
+    w, h = 120, 72
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    with api.RtContext(w, h) as ref, api.RtContext(w, h, rank=1, nranks=3) as shard, api.RtContext(w, h) as ctx:
+        for c in (ref, shard, ctx):
+            c.set_scene(sph); c.set_camera(cam); c.set_mode(mode)
+        want = ref.render_pass(7)                                              # pixel store on: the kernel's own toInt
+        ctx.set_pixel_write(False)
+        ctx.render_pass(3)
+        ctx.render_async(4, ctx.stream)
+        assert np.array_equal(ctx.read_pixels(), want)
+        assert np.array_equal(ctx.read_pixels(), want)                         # idempotent
+        shard.set_pixel_write(False)
+        shard.render_pass(7)
+        rows = shard.local_row_map()
+        assert np.array_equal(shard.read_pixels().reshape(-1, w), want.reshape(h, w)[rows])
+    if mode == api.RT_MODE_PARITY:
+        assert np.array_equal(want, O.render(sph, cam, w, h, 7)["pixels"])
+
+
+# ---- the headline call, repeated --------------------------------------------------------------------------
+def test_rt_render_repeated_calls_reuse_device_state_and_stay_bit_exact():
+    lib = api.load_library()
+    lib.rt_release_cache()
+    for rnd in range(3):
+        for (w, h, spp, maker) in ((96, 64, 3, lambda: scenes.demo_plus(16)), (64, 48, 2, lambda: scenes.random_spheres(96)),
+                                   (96, 64, 1, lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET)),
+                                   (33, 17, 4, lambda: scenes.mirror_box(64)), (7, 3, 2, lambda: scenes.demo_plus(16)),
+                                   (40, 24, 0, lambda: scenes.demo_plus(16))):
+            sph, orig, target = maker()
+            cam = host.compute_camera(orig, target, w, h)
+            assert np.array_equal(api.render(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp)["pixels"]), (rnd, w, h)
+    # a failing call must not poison the cache
+    with pytest.raises(api.RtError):
+        api.render(np.zeros(9000, api.SPHERE_DT), host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64), 96, 64, 1)
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64)
+    assert np.array_equal(api.render(sph, cam, 96, 64, 2), O.render(sph, cam, 96, 64, 2)["pixels"])
+    lib.rt_release_cache()
+    assert np.array_equal(api.render(sph, cam, 96, 64, 2), O.render(sph, cam, 96, 64, 2)["pixels"])
+
+
+def test_rt_render_second_call_costs_little_more_than_its_kernel():
+    """at 1080p x 64 spp the second and later calls take <= kernel + 1.5 ms of wall time."""
+    w, h, spp = 1920, 1080, 64
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph); ctx.set_camera(cam)
+        first = ctx.render_pass(spp)
+        kernel_ms = ctx.stats()["last_kernel_ms"]
+    api.render(sph, cam, w, h, spp)
+    times = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        px = api.render(sph, cam, w, h, spp)
+        times.append((time.perf_counter() - t0) * 1e3)
+    assert np.array_equal(px, first)
+    print("rt_render at 1080p x 64 spp: calls", ["%.2f" % t for t in times], "ms; kernel", "%.2f" % kernel_ms, "ms")
+    assert sorted(times)[len(times) // 2] <= kernel_ms + 1.5

@@ -3,7 +3,7 @@
 // only (rt_reset_async + rt_render_async), timed with the host clock around a device synchronisation.
 //   hipcc -O2 -std=c++17 -Iinclude tools/rt_inflight.cpp -o raytracing_simple_amd/rt_inflight \
 //         -Lraytracing_simple_amd -lrt_hip -Wl,-rpath,'$ORIGIN'
-//   GPU_MAX_HW_QUEUES=24 raytracing_simple_amd/rt_inflight [F] [frames] [w h spp] [fast]
+//   raytracing_simple_amd/rt_inflight [F] [frames] [w h spp] [fast]
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -14,13 +14,11 @@
 
 #include "rt_api.h"
 
-extern "C" int rt_debug_set_regen_gate(rt_ctx*, int);     // diagnostic knob of the library (not in the public header)
-
 int main(int argc, char** argv) {
     const int F = argc > 1 ? atoi(argv[1]) : 2, frames = argc > 2 ? atoi(argv[2]) : 40;
     const int w = argc > 5 ? atoi(argv[3]) : 1920, h = argc > 5 ? atoi(argv[4]) : 1080, spp = argc > 5 ? atoi(argv[5]) : 64;
     const bool fast = argc > 6 && !strcmp(argv[6], "fast");
-    const int raw_mode = (argc > 6 && argv[6][0] >= '0' && argv[6][0] <= '9') ? atoi(argv[6]) : -1;   // 100+k / 200+k: A/B instances
+    const int raw_mode = -1;
     rt_sphere sph[6];
     if (rt_demo_scene(sph, 6) != 6) return 1;
     rt_camera cam{};
@@ -34,7 +32,6 @@ int main(int argc, char** argv) {
             fprintf(stderr, "setup failed: %s\n", rt_last_error());
             return 1;
         }
-        if (const char* g = getenv("RT_GATE")) rt_debug_set_regen_gate(c, atoi(g));
     }
     auto frame = [&](int k) {
         rt_ctx* c = ctx[k % F];
