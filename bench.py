@@ -4,30 +4,37 @@
 A step = ONE FRAME of BASELINE.json configs[1]: Demo scene (6 spheres), 1920x1080, 64 samples
 per pixel (= 64 passes of the reference's Config::updateRendering()), from the default seed
 stream, rendered by the HIP path through the C ABI.  Inputs (seeds, scene tables, camera) are
-resident in HBM before the timed region.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) the image is sharded by interleaved 8-row tiles and each frame ends with
-one RCCL gather of the packed pixels to rank 0 (issued asynchronously: frame k's gather overlaps
-frame k+1's render, two send buffers); total work is fixed, so scaling is "strong".
+resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode parity|fast] [--no-cpu]
 
-Prints ONE JSON line (rank 0).  `value` = rays (primary + shadow) of all ranks / wall time of the
-K timed steps (max over ranks), in Mray/s.
+N > 1: one process per GPU (torch.distributed over RCCL); the image is sharded by interleaved 8-row
+tiles and each frame ends with one gather of the packed pixels to rank 0 and the library's
+de-interleave kernel there.  Started as the driver starts it (torch.distributed.run, WORLD_SIZE set)
+this file is one rank; started plainly (`python bench.py --gpus 8`) it launches the N ranks itself, as
+child processes, before anything touches a GPU.  Total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0).  The headline -- `value`, `ms_per_step` -- is ONE FRAME AT A TIME: frame
+k+1 starts when frame k is complete (at N > 1: gathered and assembled on rank 0), which is the
+"ms/frame" BASELINE.json's metric names and the regime the `roofline` object and the rocprof summaries
+describe (kernel time <= step time).  `frames_in_flight` beside it is the throughput of the same K
+frames with F of them in flight on separate streams (a renderer serving several views).  Every gathered
+frame of every region is compared with the unsharded frame on the device.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-# Before HIP starts: a hardware queue of its own for every stream in the process (frames in flight, the
-# collective's streams, torch's).  With the default of 4 two frames shared a queue and did not overlap
-# at all; and whenever streams SHARED queues (4, 8 or 16 queues for the ten-odd streams of a rank) the
-# multi-rank frame loop with a torch.distributed collective in the process showed its ordering failure
-# (DESIGN.md section 3, tools/gather_stress.py); with 24 it never did, and nothing runs slower.
+# Performance only, and only for the frames-in-flight figure: HIP gives a process 4 hardware queues and lets
+# further streams share them; two frames on one queue do not overlap at all.  Results never depend on it
+# (tools/gather_stress.py runs the N > 1 frame loop clean without it; DESIGN.md section 3 has the story of the
+# round-1 failure this variable used to paper over).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 W, H, SPP = 1920, 1080, 64            # the headline workload (BASELINE.json configs[1]); --workload changes them
 TILE_ROWS = 8
@@ -54,7 +61,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(spheres, cam):
+def cpu_baseline(spheres, cam, w, h, spp, reference_too=True):
     """The reference's CPU path on the host cores, same workload, same run: the reference's own
     kernel compiled as host C++ (oracle/_ref, kind "reference") when that build travelled with the
     snapshot, and the oracle (the CPU restatement, kind "port") -- the headline is the reference
@@ -63,28 +70,83 @@ def cpu_baseline(spheres, cam):
     import _oracle as O
     cores = host_cores()
     t0 = time.time()
-    out = O.render(spheres, cam, W, H, SPP, threads=cores)
+    out = O.render(spheres, cam, w, h, spp, threads=cores)
     dt = time.time() - t0
     st = out["stats"]
     rays = st["samples"] + st["shadow_calls"]
     where = f"on {cores} threads (host shows {os.cpu_count()} CPUs; cgroup quota / affinity grant {cores})"
     port = {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"full workload: {W}x{H} x {SPP} spp, {rays} rays in {dt:.2f} s "
+            "sample": f"full workload: {w}x{h} x {spp} spp, {rays} rays in {dt:.2f} s "
                       f"({st['samples'] / dt / 1e6:.1f} Msample/s) {where}",
             "ms_per_frame": round(dt * 1e3, 1)}
-    if not O.ref_available():
+    if not (reference_too and O.ref_available()):
         return port, out
     import numpy as np
     t0 = time.time()
-    ref = O.ref_render_mt(spheres, cam, W, H, SPP, cores)
+    ref = O.ref_render_mt(spheres, cam, w, h, spp, cores)
     dt = time.time() - t0
     base = {"value": round(rays / dt / 1e6, 2), "unit": "Mray/s", "cores": cores, "kind": "reference",
-            "sample": f"the reference's kernel source compiled as host C++ (oracle/_ref), full workload: {W}x{H} x {SPP} "
+            "sample": f"the reference's kernel source compiled as host C++ (oracle/_ref), full workload: {w}x{h} x {spp} "
                       f"passes, {rays} rays in {dt:.2f} s {where}",
             "ms_per_frame": round(dt * 1e3, 1),
             "equals_port_bit_exact": bool(np.array_equal(ref["pixels"], out["pixels"])),
             "port": {k: port[k] for k in ("value", "ms_per_frame", "kind")}}
     return base, out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes BEFORE this
+    process touches a GPU, pass their output through, leave with their exit code."""
+    import socket
+    import torch                      # device_count() does not initialise the GPU on this image
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("RT_BENCH_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} HIP device(s); nothing is measured on fewer "
+                         "GPUs than asked for (RT_BENCH_SINGLE_DEVICE=1 rehearses the ranks on one device, with gloo)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def inproc_child(args):
+    """The in-library multi-device path (rt_create_multi: one process, one stream per device, ncclSend/ncclRecv
+    gather inside librt_hip.so, de-interleave kernel) on the same workload: K frames one at a time
+    through rt_render_pass, the last one compared with a one-device render.  Run by rank 0 as a child process
+    after the ranks' own measurement; prints one JSON object."""
+    import numpy as np
+    from raytracing_simple_amd import api, host
+    n = args.inproc_child
+    spheres, cam = host.demo_scene(), host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, W, H)
+    mode = api.RT_MODE_FAST if args.mode == "fast" else api.RT_MODE_PARITY
+    with api.RtContext(W, H) as one:
+        one.set_scene(spheres); one.set_camera(cam); one.set_mode(mode)
+        want = one.render_pass(SPP)
+    devices = list(range(n)) if os.environ.get("RT_BENCH_SINGLE_DEVICE") != "1" else [0] * n
+    with api.RtContext(W, H, devices=devices, tile_rows=TILE_ROWS) as ctx:
+        ctx.set_scene(spheres); ctx.set_camera(cam); ctx.set_mode(mode)
+        for _ in range(max(args.warmup, 2)):
+            ctx.reset_async(); ctx.render_pass(SPP, copy=False)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.reset_async(); ctx.render_pass(SPP, copy=False)         # frame assembled on device 0 when this returns
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.reset_async(); got = ctx.render_pass(SPP)               # ... and copied to the host
+        dt_host = time.perf_counter() - t0
+        st = ctx.stats()
+    rays = st["samples"] + st["shadow_rays"]
+    print(json.dumps({"n_gpus": n, "path": "rt_create_multi: one process, in-library gather"
+                      + (" (one-GPU rehearsal: D2D copies stand in for ncclSend/ncclRecv)" if len(set(devices)) < n else " (ncclSend/ncclRecv over xGMI)"),
+                      "steps": args.steps, "ms_per_frame": round(dt / args.steps * 1e3, 4), "value": round(rays * args.steps / dt / 1e6, 1),
+                      "unit": "Mray/s", "ms_per_frame_with_host_copy": round(dt_host / args.steps * 1e3, 4),
+                      "slowest_shard_kernel_ms": round(st["last_kernel_ms"], 4),
+                      "frame_equals_single_device": bool(np.array_equal(got, want))}), flush=True)
+    return 0
 
 
 def main():
@@ -97,27 +159,34 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5"], default="c2",
                     help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="independent frames kept in flight per rank (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
+                    help="frames kept in flight per rank in the throughput region (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
+    ap.add_argument("--no-extras", action="store_true", help="headline regions only (profiling runs)")
+    ap.add_argument("--inproc-child", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.inproc_child:
+        return inproc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+
+    import numpy as np
     import torch                       # plumbing: streams, events, torch.distributed (RCCL)
     import torch.distributed as dist
 
-    from raytracing_simple_amd import api, host
+    from raytracing_simple_amd import api, host, scenes
     from raytracing_simple_amd import dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    # rehearsal knobs for a one-GPU box (never set by the driver): every rank on device 0,
-    # gloo instead of RCCL
+    # rehearsal knobs for a one-GPU box (never set by the driver): every rank on device 0, gloo instead of RCCL
     if os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
-    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl" if os.environ.get("RT_BENCH_SINGLE_DEVICE") != "1" else "gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -127,7 +196,6 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     global W, H, SPP
-    from raytracing_simple_amd import scenes
     workloads = {
         "c2": ("C2: Demo scene (6 spheres)", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 1920, 1080, 64),
         "c16": ("north-star target scene: Demo + 10 spheres (16)", lambda: scenes.demo_plus(16), 1920, 1080, 64),
@@ -140,47 +208,59 @@ def main():
     cam = host.compute_camera(cam_orig, cam_target, W, H)
     mode = api.RT_MODE_FAST if args.mode == "fast" else api.RT_MODE_PARITY
 
-    # Frames in flight.  A step is one frame; the K timed frames are independent (each restarts
-    # from the default seed stream), so several can be in flight on separate streams, each with
-    # its own seed/colour state -- what a renderer serving several views does.  One wavefront
-    # needs about a millisecond for its 64 pixels x 64 spp: a single frame leaves the machine
-    # partly idle while its last wavefronts finish (about 15 % at N = 1), and a 1/8 shard (4050
-    # wavefronts for 6144 wavefront slots) cannot fill a GPU at all.  F frames in flight fill
-    # those holes.  The single-stream figure is measured too (N = 1) and is the one the roofline
-    # and the rocprof summaries refer to.
+    # F contexts, one HIP stream each (the contexts' own: created back to back they land on distinct hardware
+    # queues, which streams from torch's pool did not always do)
     F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world <= 2 else (3 if world <= 4 else 6))
-    ctxs = []
-    for _ in range(F):
-        c = api.RtContext(W, H, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
-        c.set_scene(spheres)
-        c.set_camera(cam)
-        c.set_mode(mode)
-        ctxs.append(c)
-    ctx = ctxs[0]
 
-    main_stream = torch.cuda.current_stream()
-    # each context's own HIP stream, wrapped for torch: they are created back to back and land on
-    # distinct hardware queues, which streams from torch's pool did not always do (two pool streams
-    # on one queue = no overlap at all; measured)
+    def make_contexts(sph, camera, count):
+        out = []
+        for _ in range(count):
+            c = api.RtContext(W, H, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
+            c.set_scene(sph)
+            c.set_camera(camera)
+            c.set_mode(mode)
+            out.append(c)
+        return out
+
+    ctxs = make_contexts(spheres, cam, F)
+    ctx = ctxs[0]
     side_streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
-    gather = None
+
+    gather, want_dev, mismatch = None, None, None
     if world > 1:
         gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=2 * F)
-        torch.cuda.synchronize()        # its zero-fills ran on torch's stream; the contexts' streams are non-blocking
+        if rank == 0:
+            # the frame every gathered frame must equal: an unsharded render on this GPU
+            with api.RtContext(W, H, device=local_rank) as whole:
+                whole.set_scene(spheres); whole.set_camera(cam); whole.set_mode(mode)
+                want_dev = torch.from_numpy(whole.render_pass(SPP).view(np.int32).reshape(H, W).copy()).to(dev)
+            mismatch = torch.zeros((), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()        # the set-up ran on torch's stream; the contexts' streams are non-blocking
         gather.gather(0)                # plumbing, not a step: RCCL builds its communicator and point-to-point
-        torch.cuda.synchronize()        # channels on first use (seconds); keep that out of the timed region even with --warmup 0
+        torch.cuda.synchronize()        # channels on first use (seconds); keep that out of every timed region
         dist.barrier()
     frame_no = [0]
+    frames_checked = [0]
 
-    def step(in_flight, ev=None, do_gather=True):
+    def collect(k):
+        """Frame k's gather is complete and assembled (rank 0): compare it with the unsharded frame ON THE DEVICE,
+        then poison the buffers so that a frame that is NOT written again would show."""
+        full = gather.wait(k)
+        if rank == 0 and full is not None and gather.pending_check[k % gather.slots]:
+            mismatch.add_((full != want_dev).sum())
+            full.fill_(-1)
+            gather.pending_check[k % gather.slots] = False
+            frames_checked[0] += 1
+
+    def step(contexts, streams, in_flight, ev=None):
         k = frame_no[0]
         frame_no[0] += 1
-        c = ctxs[k % in_flight]
-        st = main_stream if in_flight == 1 else side_streams[k % in_flight]
+        c, st = contexts[k % in_flight], streams[k % in_flight]
         with torch.cuda.stream(st):
-            if gather is not None and do_gather:
-                gather.wait(k)                                  # slot free again (its last gather)
+            if gather is not None:
+                collect(k)                                      # slot free again (the frame that used it 2F frames ago)
                 buf = gather.local_slot(k)
+                buf.fill_(-1)                                   # poison: every pixel must come from THIS frame's launch
                 c.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
             c.reset_async(st.cuda_stream)
             if ev:
@@ -188,14 +268,20 @@ def main():
             c.render_async(SPP, st.cuda_stream)
             if ev:
                 ev[1].record(st)
-            if gather is not None and do_gather:
+            if gather is not None:
                 gather.gather(k, async_op=True)                 # queued behind the launch, not waited for
+                gather.pending_check[k % gather.slots] = True
+                if in_flight == 1:
+                    collect(k)                                  # one frame at a time: complete before the next one starts
+                    st.synchronize()
         return c
 
     def drain():
         if gather is not None:
-            for k in range(2 * F):
-                gather.wait(k)
+            for k in range(frame_no[0] - 2 * F, frame_no[0]):
+                if k >= 0:
+                    with torch.cuda.stream(side_streams[0]):
+                        collect(k)
 
     def sync():
         torch.cuda.synchronize()
@@ -203,12 +289,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(in_flight, steps, warmup, with_events=True, do_gather=True):
+    def timed_region(contexts, streams, in_flight, steps, warmup, with_events=True):
         """W untimed + exactly `steps` timed frames; barrier + synchronize on both sides.
         Per-launch HIP events only where asked: an event pair around every launch costs the
         overlapped region its overlap (measured), and a per-launch duration means little there."""
         for _ in range(warmup):
-            step(in_flight, None, do_gather)
+            step(contexts, streams, in_flight)
         drain()
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                   for _ in range(steps)] if with_events else None
@@ -216,172 +302,216 @@ def main():
         t0 = time.perf_counter()
         last = None
         for k in range(steps):
-            last = step(in_flight, events[k] if events else None, do_gather)
-        drain()                                             # every frame gathered and assembled
+            last = step(contexts, streams, in_flight, events[k] if events else None)
+        drain()                                             # every frame gathered, assembled and checked
         sync()
         elapsed = time.perf_counter() - t0
-        kernel_ms = (sum(a.elapsed_time(b) for a, b in events) / max(steps, 1)) if events else elapsed / max(steps, 1) * 1e3
+        kernel_ms = (sum(a.elapsed_time(b) for a, b in events) / max(steps, 1)) if events else None
         return elapsed, kernel_ms, last
-
-    single = None
-    if world == 1:
-        el1, k1, last1 = timed_region(1, args.steps, args.warmup)
-        single = {"elapsed": el1, "kernel_ms": k1, "ctx": last1}
-    else:
-        # per-launch duration of this rank's shard for the roofline object: a few launches one at a
-        # time, no gather, outside the headline's timed region
-        _, k1, _ = timed_region(1, min(args.steps, 8), 1, with_events=True, do_gather=False)
-        shard_kernel_ms = k1
-    if F == 1 and single is not None:
-        elapsed, kernel_ms, last_ctx = single["elapsed"], single["kernel_ms"], single["ctx"]
-    else:
-        elapsed, kernel_ms, last_ctx = timed_region(F, args.steps, args.warmup, with_events=False)
-        if world > 1:
-            kernel_ms = shard_kernel_ms
-
-    frame_ok = None
-    if world > 1 and rank == 0:
-        # the gathered frame of the last step against an unsharded render on this GPU
-        with api.RtContext(W, H, device=local_rank) as whole:
-            whole.set_scene(spheres)
-            whole.set_camera(cam)
-            whole.set_mode(mode)
-            want = whole.render_pass(SPP)
-        got = gather.wait(frame_no[0] - 1).cpu().numpy().astype("uint32").reshape(-1)
-        frame_ok = bool((got == want).all())
-
-    last_pixels = last_ctx.render_pass(0, copy=True) if world == 1 else None   # the last TIMED frame (checked against the oracle below)
 
     def frame_counters(c):
         """Exact ray / test counts of one frame of this rank (the same for every frame): from one more,
-        synchronous render after a synchronous reset, so that they do not depend on how the timed
-        region's asynchronous resets were ordered."""
+        synchronous render after a synchronous reset, outside every timed region."""
         c.set_pixel_buffer(0, 0)
         c.reset()
         c.render_pass(SPP, copy=False)
         return c.stats()
 
-    st = frame_counters(last_ctx)
+    def all_ranks(values, op):
+        t = torch.tensor(values, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=op)
+        return [float(v) for v in t.tolist()]
 
-    # the other arithmetic mode on the same workload, single stream, outside the headline's
-    # timed region (N = 1 only; reported beside `value`, never instead of it)
-    other = None
-    if world == 1:
+    # ---- the headline: one frame at a time -------------------------------------------------------------
+    if gather is not None:
+        gather.pending_check = [False] * gather.slots
+    el1, kernel_ms, last1 = timed_region(ctxs, side_streams, 1, args.steps, args.warmup, with_events=True)
+    last_pixels = last1.read_pixels() if world == 1 else None       # the last TIMED frame (checked against the oracle below)
+    # ---- the same K frames with F in flight (throughput) ------------------------------------------------
+    elF = None
+    if F > 1 and not args.no_extras:
+        elF, _, _ = timed_region(ctxs, side_streams, F, args.steps, args.warmup, with_events=False)
+    st = frame_counters(ctx)
+
+    samples, closest, shadow, tests = (int(v) for v in all_ranks([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],
+                                                                  dist.ReduceOp.SUM if world > 1 else None))
+    el1_max, kernel_ms_max = all_ranks([el1, kernel_ms], dist.ReduceOp.MAX if world > 1 else None)
+    elF_max = all_ranks([elF], dist.ReduceOp.MAX if world > 1 else None)[0] if elF is not None else None
+    frames_ok = None
+    if world > 1:
+        bad = int(mismatch.item()) if rank == 0 else 0
+        frames_ok = {"frames_checked": frames_checked[0], "wrong_pixels": bad} if rank == 0 else None
+
+    # ---- extras, N = 1, outside the headline's timed regions -------------------------------------------
+    other, target, in_library = None, None, None
+    if world == 1 and not args.no_extras:
+        # the other arithmetic mode on the same workload
         other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
         for c in ctxs:
             c.set_mode(other_mode)
-        el_o, _, last_o = timed_region(F, 8, 2, with_events=False)
-        px_o = last_o.render_pass(0, copy=True)
-        st_o = frame_counters(last_o)
-        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "frames_in_flight": F,
-                 "ms_per_step": round(el_o / 8 * 1e3, 4),
-                 "value": round((st_o["samples"] + st_o["shadow_rays"]) * 8 / el_o / 1e6, 1), "unit": "Mray/s",
+        el_o1, k_o1, last_o = timed_region(ctxs, side_streams, 1, 8, 2, with_events=True)
+        px_o = last_o.read_pixels()
+        el_oF, _, _ = timed_region(ctxs, side_streams, F, 8, 2, with_events=False)
+        st_o = frame_counters(ctxs[0])
+        rays_o = st_o["samples"] + st_o["shadow_rays"]
+        other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "ms_per_step": round(el_o1 / 8 * 1e3, 4),
+                 "value": round(rays_o * 8 / el_o1 / 1e6, 1), "unit": "Mray/s", "kernel_ms": round(k_o1, 4),
+                 "frames_in_flight": {"frames": F, "ms_per_step": round(el_oF / 8 * 1e3, 4), "value": round(rays_o * 8 / el_oF / 1e6, 1)},
                  "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2)}
         for c in ctxs:
             c.set_mode(mode)
+        # the north-star target workload (16-sphere scene, 1080p x 64 spp, >= 10 Gray/s asked), driver-timed
+        if args.workload == "c2":
+            sph16, o16, t16 = scenes.demo_plus(16)
+            cam16 = host.compute_camera(o16, t16, W, H)
+            c16 = make_contexts(sph16, cam16, F)
+            s16 = [torch.cuda.ExternalStream(c.stream, device=dev) for c in c16]
+            k16 = max(5, args.steps // 2)
+            el16, kms16, last16 = timed_region(c16, s16, 1, k16, 2, with_events=True)
+            px16 = last16.read_pixels()
+            el16F, _, _ = timed_region(c16, s16, F, k16, 2, with_events=False)
+            st16 = frame_counters(c16[0])
+            rays16 = st16["samples"] + st16["shadow_rays"]
+            tf16 = FLOP_PER_SPHERE_TEST * st16["sphere_tests"] / (kms16 * 1e-3) / 1e12
+            target = {"workload": "north-star target: Demo + 10 spheres (16), 1920x1080, 64 spp, default seed stream",
+                      "asked_Mray_s": 10000.0, "steps": k16, "ms_per_step": round(el16 / k16 * 1e3, 4),
+                      "value": round(rays16 * k16 / el16 / 1e6, 1), "unit": "Mray/s", "kernel": "rt_trace_parity_coop", "kernel_ms": round(kms16, 4),
+                      "roofline": {"bound": "valu-fp32", "achieved": round(tf16, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(tf16 / FP32_VECTOR_PEAK_TFLOPS, 5)},
+                      "frames_in_flight": {"frames": F, "ms_per_step": round(el16F / k16 * 1e3, 4), "value": round(rays16 * k16 / el16F / 1e6, 1)}}
+            if not args.no_cpu and mode == api.RT_MODE_PARITY:
+                base16, cpu16 = cpu_baseline(sph16, cam16, W, H, SPP, reference_too=False)
+                target["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(px16, cpu16["pixels"]))
+                target["cpu_port_ms_per_frame"] = base16["ms_per_frame"]
+            for c in c16:
+                c.close()
+        # the in-library multi-device context with a communicator of one: what the frame-end gather path costs
+        # when it has nothing to move (the N-GPU figure comes from the N > 1 runs)
+        try:
+            with api.RtContext(W, H, devices=[local_rank], tile_rows=TILE_ROWS) as m1:
+                m1.set_scene(spheres); m1.set_camera(cam); m1.set_mode(mode)
+                for _ in range(2):
+                    m1.reset_async(); m1.render_pass(SPP, copy=False)
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    m1.reset_async(); m1.render_pass(SPP, copy=False)
+                dt = time.perf_counter() - t0
+                in_library = {"path": "rt_create_multi(ngpus=1): RCCL communicator of one, de-interleave kernel, blocking rt_render_pass",
+                              "ms_per_frame": round(dt / 8 * 1e3, 4), "frame_equals_headline": bool(np.array_equal(m1.read_pixels(), last_pixels))}
+        except api.RtError as e:
+            in_library = {"error": str(e)}
 
-    counts = torch.tensor([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],
-                          dtype=torch.int64, device=dev)
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    k_max = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
-    samples, closest, shadow, tests = (int(v) for v in counts.tolist())
-    elapsed = float(t_max.item())
-    kernel_ms_max = float(k_max.item())
-
-    if rank == 0:
-        rays = samples + shadow                      # primary + shadow, the metric's ray count
-        ms_per_step = elapsed / args.steps * 1e3
-        value = rays * args.steps / elapsed / 1e6
-        # roofline of the dominant (only) kernel, per launch, from this rank's launches; at N = 1
-        # from the single-stream region, where launches do not overlap (what rocprof sees too)
-        roof_kernel_ms = single["kernel_ms"] if single is not None else kernel_ms
-        my_tests = st["sphere_tests"]
-        flops = FLOP_PER_SPHERE_TEST * my_tests
-        achieved_tflops = flops / (roof_kernel_ms * 1e-3) / 1e12
-        my_pixels = ctx.local_rows * W
-        alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 16 * len(spheres) * 3 + 60
-        traffic, executed = None, None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if world == 1 and args.workload == "c2" and os.path.exists(prof):
-            try:
-                pm = json.load(open(prof)).get(args.mode, {})
-                traffic = pm.get("hbm_bytes_per_launch")
-                if pm.get("valu_insts_per_launch"):
-                    # what the VALU actually issues (PMC of the committed profile, same command): the
-                    # time its instructions need at full issue rate, and how much of a step that is
-                    floor_ms = pm["valu_busy_frac_single_stream"] * pm["profiled_kernel_ms"]
-                    executed = {"valu_insts_per_launch": pm["valu_insts_per_launch"],
-                                "active_lane_frac": pm["active_lane_frac"],
-                                "valu_issue_floor_ms": round(floor_ms, 4),
-                                "valu_busy_frac_one_frame_at_a_time": round(floor_ms / roof_kernel_ms, 4),
-                                "valu_busy_frac_headline": round(floor_ms / ms_per_step, 4),
-                                "l2_hit_rate": pm.get("l2_hit_rate"),
-                                "source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes, tools/profile_gpu.sh)"}
-            except (OSError, ValueError, KeyError):
-                traffic, executed = None, None
-        line = {
-            "metric": "Mray/s (primary+shadow) at 1080p 64spp" if args.workload == "c2"
-                      else f"Mray/s (primary+shadow) at {W}x{H} {SPP}spp",
-            "value": round(value, 1),
-            "unit": "Mray/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{wl_name}, {W}x{H}, {SPP} spp, default seed stream",
-                       "mode": args.mode, "collective": None if world == 1 else f"gather to rank 0 ({backend})",
-                       "frames_in_flight": F,
-                       "gathered_frame_equals_unsharded": frame_ok, "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
-                       "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
-                       "Mray_s_all_rays": round((closest + shadow) * args.steps / elapsed / 1e6, 1),
-                       "Msample_s": round(samples * args.steps / elapsed / 1e6, 1)},
-            "roofline": {
-                "bound": "valu-fp32",
-                "kernel": "rt_trace_" + args.mode + ("_coop" if len(spheres) >= 12 else ""),
-                "achieved": round(achieved_tflops, 3),
-                "peak": FP32_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, 5),
-                "traffic": traffic,
-                "launches_overlap": False,
-                "kernel_ms": round(roof_kernel_ms, 4),
-                "step_ms_max_rank": round(kernel_ms_max, 4),
-                "algorithmic_flops_per_launch": flops,
-                "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
-                        "achieved": round(alg_bytes / (roof_kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(alg_bytes / (roof_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
-            },
-        }
-        if executed is not None:
-            line["roofline"]["executed"] = executed
-        if single is not None and F > 1:
-            line["single_stream"] = {"frames_in_flight": 1, "ms_per_step": round(single["elapsed"] / args.steps * 1e3, 4),
-                                     "value": round(rays * args.steps / single["elapsed"] / 1e6, 1), "unit": "Mray/s"}
-        if other is not None:
-            line["other_mode"] = other
-        if world == 1 and not args.no_cpu:
-            base, cpu_out = cpu_baseline(spheres, cam)
-            line["cpu_baseline"] = base
-            if args.mode == "parity":
-                import numpy as np
-                line["config"]["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(last_pixels, cpu_out["pixels"]))
-        print(json.dumps(line), flush=True)
-
+    my_local_rows = ctx.local_rows
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     for c in ctxs:
         c.close()
+    if rank != 0:
+        return 0
+
+    if world > 1 and not args.no_extras and args.workload == "c2":
+        # the in-library path on the same GPUs, as a child process (the ranks have released their communicator);
+        # never allowed to take the headline down with it
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        try:
+            time.sleep(2.0)
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--inproc-child", str(world), "--steps", str(max(5, args.steps // 2)),
+                                  "--warmup", "2", "--mode", args.mode], env=env, capture_output=True, text=True, timeout=240)
+            lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            in_library = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": (res.stderr or res.stdout)[-400:]}
+        except (subprocess.TimeoutExpired, ValueError, OSError) as e:
+            in_library = {"error": repr(e)[:400]}
+
+    rays = samples + shadow                      # primary + shadow, the metric's ray count
+    ms_per_step = el1_max / args.steps * 1e3
+    value = rays * args.steps / el1_max / 1e6
+    # roofline of the dominant (only) kernel, per launch, from this rank's launches in the headline region
+    # (HIP events on the stream the kernel is launched on; launches do not overlap there)
+    my_tests = st["sphere_tests"]
+    flops = FLOP_PER_SPHERE_TEST * my_tests
+    achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
+    my_pixels = my_local_rows * W
+    alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 44 * len(spheres) + 60
+    traffic, executed = None, None
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world == 1 and args.workload == "c2" and os.path.exists(prof):
+        try:
+            pm = json.load(open(prof)).get(args.mode, {})
+            traffic = pm.get("hbm_bytes_per_launch")
+            if pm.get("valu_insts_per_launch"):
+                # what the VALU actually issues (PMC of the committed profile, same command): the
+                # time its instructions need at full issue rate, and how much of a step that is
+                floor_ms = pm["valu_busy_frac_single_stream"] * pm["profiled_kernel_ms"]
+                executed = {"valu_insts_per_launch": pm["valu_insts_per_launch"],
+                            "active_lane_frac": pm["active_lane_frac"],
+                            "valu_issue_floor_ms": round(floor_ms, 4),
+                            "valu_busy_frac": round(floor_ms / kernel_ms, 4),
+                            "l2_hit_rate": pm.get("l2_hit_rate"),
+                            "source": pm.get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes, tools/profile_gpu.sh)")}
+        except (OSError, ValueError, KeyError):
+            traffic, executed = None, None
+    line = {
+        "metric": "Mray/s (primary+shadow) at 1080p 64spp" if args.workload == "c2"
+                  else f"Mray/s (primary+shadow) at {W}x{H} {SPP}spp",
+        "value": round(value, 1),
+        "unit": "Mray/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{wl_name}, {W}x{H}, {SPP} spp, default seed stream",
+                   "mode": args.mode, "regime": "one frame at a time (ms_per_step = ms/frame)",
+                   "collective": None if world == 1 else f"gather to rank 0 ({backend}) + de-interleave kernel",
+                   "every_gathered_frame_equals_unsharded": None if frames_ok is None else frames_ok["wrong_pixels"] == 0,
+                   "gathered_frames_checked": None if frames_ok is None else frames_ok["frames_checked"],
+                   "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
+                   "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
+                   "Mray_s_all_rays": round((closest + shadow) * args.steps / el1_max / 1e6, 1),
+                   "Msample_s": round(samples * args.steps / el1_max / 1e6, 1)},
+        "roofline": {
+            "bound": "valu-fp32",
+            "kernel": "rt_trace_" + args.mode + ("_coop" if len(spheres) >= 12 else ""),
+            "achieved": round(achieved_tflops, 3),
+            "peak": FP32_VECTOR_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, 5),
+            "traffic": traffic,
+            "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_max_rank": round(kernel_ms_max, 4),
+            "algorithmic_flops_per_launch": flops,
+            "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                    "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
+        },
+    }
+    if executed is not None:
+        line["roofline"]["executed"] = executed
+    if elF_max is not None:
+        line["frames_in_flight"] = {"frames": F, "ms_per_step": round(elF_max / args.steps * 1e3, 4),
+                                    "value": round(rays * args.steps / elF_max / 1e6, 1), "unit": "Mray/s",
+                                    "note": "the same K frames, F in flight on separate streams: throughput, not ms/frame"}
+    if target is not None:
+        line["north_star_target"] = target
+    if other is not None:
+        line["other_mode"] = other
+    if in_library is not None:
+        line["in_library_multi_gpu"] = in_library
+    if world == 1 and not args.no_cpu:
+        base, cpu_out = cpu_baseline(spheres, cam, W, H, SPP)
+        line["cpu_baseline"] = base
+        if args.mode == "parity":
+            line["config"]["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(last_pixels, cpu_out["pixels"]))
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

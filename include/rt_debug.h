@@ -35,6 +35,8 @@ RT_API int rt_debug_set_mat_lds_limit(rt_ctx *ctx, int bytes);
 RT_API int rt_debug_set_persist(rt_ctx *ctx, int on);
 RT_API int rt_debug_set_ncus(rt_ctx *ctx, int n);
 RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
+RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order                */
+RT_API int rt_debug_read_tile_order(rt_ctx *ctx, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid);
 
 /* raw diagnostic counters (section census of the stamped instances; valid after rt_get_stats) */
 RT_API int rt_debug_counters(rt_ctx *ctx, unsigned long long *out24);
@@ -43,8 +45,9 @@ RT_API int rt_debug_counters_raw(rt_ctx *ctx, unsigned long long *out32);
 /* the reset this library used in round 1 (seed words restored by a copy on `hip_stream`, read back by
  * the next launch) and a probe kernel that counts seed words differing from the default stream into
  * counters[28] (probes run: [29]); both log their device wall-clock interval like the timelog instance */
-RT_API int rt_debug_reset_by_copy(rt_ctx *ctx, void *hip_stream, int use_memcpy);
-RT_API int rt_debug_probe_seeds(rt_ctx *ctx, void *hip_stream);
+RT_API int rt_debug_reset_by_copy(rt_ctx *ctx, void *hip_stream, int flags);   /* bit 0: hipMemcpyAsync instead of the copy kernel; bit 1: the kernel's waves end with an agent-scope release; bit 2: write-through (sc1) stores */
+RT_API int rt_debug_probe_seeds(rt_ctx *ctx, void *hip_stream, int flags);     /* bit 0: the probe's waves start with an agent-scope acquire */
+RT_API int rt_debug_sidelog_read(rt_ctx *ctx, uint32_t seq, unsigned long long *blocklog1024, uint32_t *stalelog64);
 
 /* Device wall-clock log (s_memrealtime, 100 MHz): `entries` records of 8 u64 {first start, last end,
  * kind (1 render, 2 copy, 3 probe), user tag, stale words seen (probe), -, -, -}; every later launch of the timelog instance (mode 109) and every rt_debug_reset_by_copy /

@@ -41,9 +41,25 @@ using rt::fail;
 
 // rt_reset_async zeroes the work counters with a kernel on the caller's stream and restores NO seeds:
 // the next launch reads the pristine default stream directly (LaunchParams::seeds_in).
+// (Every store of the kernels in this file is a write-through store, rt_device.h st_wt.)
 __global__ void rt_zero_counters_kernel(unsigned long long *counters, unsigned long long *stats) {
-    for (int i = threadIdx.x; i < 32; i += blockDim.x) counters[i] = 0ull;
-    for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) stats[i] = 0ull;
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) rt::st_wt(counters + i, 0ull);
+    for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) rt::st_wt(stats + i, 0ull);
+}
+
+// rt_create / rt_reset: seeds = the pristine default stream, colour plane, pixels and counters zero
+// (OpenCLConfig.cpp:613-682), as ONE kernel with write-through stores instead of runtime copies and fills.
+__global__ void __launch_bounds__(256) rt_restore_kernel(unsigned long long *seeds, const unsigned long long *seeds0, size_t n_pairs,
+                                                         uint32_t *colors, size_t n_colors, uint32_t *pixels, size_t n_pixels,
+                                                         unsigned long long *counters, unsigned long long *stats) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = first; i < n_pairs; i += stride) rt::st_wt(seeds + i, seeds0[i]);
+    for (size_t i = first; i < n_colors; i += stride) rt::st_wt(colors + i, 0u);
+    for (size_t i = first; i < n_pixels; i += stride) rt::st_wt(pixels + i, 0u);
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 32; i += blockDim.x) rt::st_wt(counters + i, 0ull);
+        for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) rt::st_wt(stats + i, 0ull);
+    }
 }
 
 // Scene tables from the raw 44-byte records (rt_set_scene / rt_update_spheres_async), ONE workgroup:
@@ -67,9 +83,9 @@ __global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *s
         if (i < n) {
             const float *r = reinterpret_cast<const float *>(sph + i);      // 11 dwords: rad, p, e, c, refl
             rad = r[0]; px = r[1]; py = r[2]; pz = r[3]; ex = r[4]; ey = r[5]; ez = r[6];
-            geom[i] = make_float4(px, py, pz, rad * rad);
-            emis[i] = make_float4(ex, ey, ez, r[10]);                        // refl keeps its bits
-            colr[i] = make_float4(r[7], r[8], r[9], rad);
+            rt::st_wt(geom + i, make_float4(px, py, pz, rad * rad));
+            rt::st_wt(emis + i, make_float4(ex, ey, ez, r[10]));              // refl keeps its bits
+            rt::st_wt(colr + i, make_float4(r[7], r[8], r[9], rad));
             light = !((ex == 0.f) && (ez == 0.f));
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(light);
@@ -79,53 +95,118 @@ __global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *s
         uint32_t off = s_base;
         for (int k = 0; k < wave; ++k) off += s_wave_count[k];
         if (light) {
-            la[off + before] = make_float4(px, py, pz, rad);
-            lb[off + before] = make_float4(ex, ey, ez, 4.f * 3.14159265358979323846f * rad * rad);
+            rt::st_wt(la + off + before, make_float4(px, py, pz, rad));
+            rt::st_wt(lb + off + before, make_float4(ex, ey, ez, 4.f * 3.14159265358979323846f * rad * rad));
         }
         __syncthreads();
         if (tid == 0) s_base += s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
         __syncthreads();
     }
-    if (tid == 0) *n_lights_out = s_base;
+    if (tid == 0) rt::st_wt(n_lights_out, (uint32_t)s_base);
+}
+
+// Heavy-first order of the 32x8 tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a
+// counting sort over 1024 cost classes (largest first; the order inside a class does not matter).
+__global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *cost, uint32_t *order, uint32_t n) {
+    __shared__ unsigned s_max;
+    __shared__ unsigned s_hist[1024];
+    const unsigned tid = threadIdx.x;
+    if (tid == 0) s_max = 1u;
+    s_hist[tid] = 0u;
+    __syncthreads();
+    unsigned m = 0;
+    for (uint32_t i = tid; i < n; i += 1024) m = cost[i] > m ? cost[i] : m;
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const unsigned long long top = s_max;
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[1023u - (unsigned)((unsigned long long)cost[i] * 1023ull / top)], 1u);
+    __syncthreads();
+    if (tid == 0) {                     // exclusive prefix over the classes, most expensive class first
+        unsigned run = 0;
+        for (int k = 0; k < 1024; ++k) {
+            const unsigned c_ = s_hist[k];
+            s_hist[k] = run;
+            run += c_;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned pos = atomicAdd(&s_hist[1023u - (unsigned)((unsigned long long)cost[i] * 1023ull / top)], 1u);
+        rt::st_wt(order + pos, (uint32_t)i);
+    }
 }
 
 // rt_deinterleave_rows: full[y] = row (t/n)*tile_rows + y%tile_rows of rank t%n's block, t = y/tile_rows.
-// One thread per 16 bytes where the row length allows it (w % 4 == 0 keeps every row 16-byte aligned).
+// One thread per 8 bytes where the row length allows it (w % 2 == 0 keeps every row 8-byte aligned).
 __global__ void __launch_bounds__(256) rt_deinterleave_kernel(uint32_t *__restrict__ full, const uint32_t *__restrict__ gathered, int w,
                                                               int h, int nranks, int tile_rows, int pad_rows, int vec) {
-    const int per_row = vec ? w / 4 : w;
+    const int per_row = vec ? w / 2 : w;
     const size_t total = (size_t)per_row * (size_t)h;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / (size_t)per_row), xq = (int)(i - (size_t)y * (size_t)per_row);
         const int t = y / tile_rows, r = t % nranks, lrow = (t / nranks) * tile_rows + (y - t * tile_rows);
         const size_t src = ((size_t)r * (size_t)pad_rows + (size_t)lrow) * (size_t)w, dst = (size_t)y * (size_t)w;
         if (vec)
-            reinterpret_cast<uint4 *>(full + dst)[xq] = reinterpret_cast<const uint4 *>(gathered + src)[xq];
+            rt::st_wt(reinterpret_cast<unsigned long long *>(full + dst) + xq, reinterpret_cast<const unsigned long long *>(gathered + src)[xq]);
         else
-            full[dst + xq] = gathered[src + xq];
+            rt::st_wt(full + dst + xq, gathered[src + xq]);
     }
 }
 
 #if RT_DIAGNOSTICS
 // diagnostic only (rt_debug_reset_by_copy): the reset this library used in round 1 -- a copy kernel that
-// restores the seed words, which the next launch then reads back
+// restores the seed words, which the next launch then reads back.  Logs into its timelog record (tl) the
+// device wall-clock of its first start / last end and the number of workgroups that ran, and per workgroup
+// (blocklog) its start time and the XCD it ran on.  flags bit 1: every wave ends with an explicit
+// agent-scope release (buffer_wbl2 sc1 + wait), i.e. the shader itself writes its XCD's L2 back instead
+// of leaving that to the end-of-kernel action of the command processor.  flags bit 2: write-through stores; bit 3: atomic exchanges instead of stores.
 __global__ void rt_debug_copy_seeds_kernel(uint32_t *seeds, const uint32_t *seeds0, size_t n, unsigned long long *tl,
-                                           unsigned long long tag) {
+                                           unsigned long long tag, unsigned long long *blocklog, int flags) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     if (tl && threadIdx.x == 0) atomicMin(&tl[0], t0);
     if (tl && threadIdx.x == 0 && blockIdx.x == 0) { tl[2] = 2ull; tl[3] = tag; }
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) seeds[i] = seeds0[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (flags & 8) __hip_atomic_exchange(seeds + i, seeds0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // memory-side read-modify-write
+        else if (flags & 4) rt::st_wt(seeds + i, seeds0[i]);                // write-through (global_store ... sc1)
+        else seeds[i] = seeds0[i];
+    }
     __builtin_amdgcn_s_waitcnt(0);
-    if (tl && threadIdx.x == 0) atomicMax(&tl[1], __builtin_amdgcn_s_memrealtime());
+    if (flags & 2) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (threadIdx.x == 0) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (blocklog && (flags & 8)) __hip_atomic_exchange(&blocklog[blockIdx.x], (t0 << 4) | (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (blocklog) blocklog[blockIdx.x] = (t0 << 4) | (xcc & 15u);
+        if (tl) atomicAdd(&tl[5], 1ull);                                    // workgroups that ran
+        if (tl) atomicMax(&tl[1], __builtin_amdgcn_s_memrealtime());
+    }
 }
 
+// flags bit 0: every wave starts with an explicit agent-scope acquire (buffer_inv sc1 + wait) before it reads
 __global__ void rt_debug_probe_seeds_kernel(const uint32_t *seeds, const uint32_t *seeds0, size_t n, unsigned long long *out,
-                                            unsigned long long *tl, unsigned long long tag) {
+                                            unsigned long long *tl, unsigned long long tag, uint32_t *stalelog, int flags) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     if (tl && threadIdx.x == 0) atomicMin(&tl[0], t0);
     if (tl && threadIdx.x == 0 && blockIdx.x == 0) { tl[2] = 3ull; tl[3] = tag; }
+    if (flags & 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long b = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b += (seeds[i] != seeds0[i]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (seeds[i] != seeds0[i]) {
+            b += 1;
+            if (stalelog) {                                                  // first 63 stale words: index | reader's XCD << 28
+                const uint32_t k = atomicAdd(&stalelog[0], 1u);
+                if (k < 63u) stalelog[1 + k] = (uint32_t)i | (xcc << 28);
+            }
+        }
+    }
     if (b) atomicAdd(out, b);
     if (b && tl) atomicAdd(&tl[4], b);                                      // stale words seen by THIS probe
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out + 1, 1ull);     // probes run
@@ -170,11 +251,12 @@ int restore_state(rt_ctx *c) {                          // rt_create / rt_reset:
     int rc = chain(c, c->stream);
     if (rc != RT_OK) return rc;
     const size_t px = (size_t)c->w * (size_t)c->h;
-    HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, 2 * px * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_colors, 0, 3 * px * sizeof(float), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_pixels, 0, (size_t)c->local_rows * (size_t)c->w * sizeof(uint32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, rt::kStatReplicas * 8 * sizeof(unsigned long long), c->stream));
+    size_t blocks = (3 * px + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rt_restore_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, reinterpret_cast<unsigned long long *>(c->d_seeds),
+                       reinterpret_cast<const unsigned long long *>(c->d_seeds0), px, reinterpret_cast<uint32_t *>(c->d_colors), 3 * px,
+                       c->d_pixels, (size_t)c->local_rows * (size_t)c->w, c->d_counters, c->d_stats);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RT_OK;
 }
@@ -227,6 +309,17 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
               (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
     hipError_t e;
     const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+    // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
+    // same scene and camera walks the tiles in descending order of cost (sorted on the device, once)
+    if (c->use_order && c->d_tile_cost && (size_t)grid.x * grid.y == c->n_tiles) {
+        p.tile_cost = c->d_tile_cost;
+        if (c->cost_valid && !c->order_valid && n_samples >= 8) {
+            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, c->n_tiles);
+            HIP_TRY(hipGetLastError());
+            c->order_valid = true;
+        }
+        if (c->order_valid) p.order = c->d_order;
+    }
 #if RT_DIAGNOSTICS
     const bool persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
     if (persist) {
@@ -261,6 +354,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
                     hipGetErrorString(e), grid.x, grid.y, lds);
     c->current_sample += n_samples;
     c->launches += 1;
+    if (p.tile_cost && n_samples >= 4) c->cost_valid = true;
     c->seeds_default = false;           // this launch has written every seed pair the context renders
     c->pixels_current = c->pixel_write != 0;
     return RT_OK;
@@ -408,6 +502,11 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
         HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 4) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&c->d_stats, rt::kStatReplicas * 8 * sizeof(unsigned long long)));
+        c->n_tiles = (uint32_t)(((w + rt::kTileW - 1) / rt::kTileW) * ((rows + rt::kTileH - 1) / rt::kTileH));
+        if (c->n_tiles) {
+            HIP_TRY(hipMalloc(&c->d_tile_cost, (size_t)c->n_tiles * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(&c->d_order, (size_t)c->n_tiles * sizeof(uint32_t)));
+        }
         // function attributes (dynamic-LDS limit) are per device, not per context
         static std::mutex mu;
         static bool prepared[64] = {};
@@ -450,8 +549,12 @@ RT_API void rt_destroy(rt_ctx *c) {
         (void)hipFree(c->d_pixels);
         (void)hipFree(c->d_counters);
         (void)hipFree(c->d_stats);
+        (void)hipFree(c->d_tile_cost);
+        (void)hipFree(c->d_order);
         (void)hipFree(c->d_timelog);
         (void)hipFree(c->d_wavelog);
+        (void)hipFree(c->d_blocklog);
+        (void)hipFree(c->d_stalelog);
         free_scene(c);
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -476,11 +579,17 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     if (rt::lds_bytes(count, nl, false) > 152 * 1024)
         return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(count, nl, false));
     if (c->multi) return rt::multi_set_scene(c, spheres, count);
+    // the very scene the context already holds (a host that sets it before every frame): nothing to do
+    if (c->have_scene && count == c->scene.n_spheres && c->h_spheres.size() == count &&
+        (count == 0 || memcmp(c->h_spheres.data(), spheres, (size_t)count * sizeof(rt_sphere)) == 0))
+        return RT_OK;
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     rc = ensure_scene_capacity(c, count);
     if (rc != RT_OK) return rc;
     c->is_light.assign(c->scene_cap, 0);
+    c->h_spheres.assign(spheres, spheres + count);
+    c->cost_valid = c->order_valid = false;
     rc = upload_spheres(c, 0, count, spheres, count, c->stream);
     if (rc != RT_OK) {
         c->have_scene = false;          // the tables are in an unknown state
@@ -505,12 +614,15 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
         return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(n, nl, false));
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
+    if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
+    c->cost_valid = c->order_valid = false;
     return upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
 }
 
 RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
     if (c->multi) return rt::multi_set_camera(c, cam);
+    if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) c->cost_valid = c->order_valid = false;
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;
     return RT_OK;
@@ -718,8 +830,8 @@ RT_API int rt_deinterleave_rows(uint32_t *full, const uint32_t *gathered, int w,
     if (pad_rows < need && pad_rows < ((n_tiles - 1) / nranks) * tile_rows + (h - (n_tiles - 1) * tile_rows))
         return fail(RT_ERR_ARG, "pad_rows %d is less than a rank's row count", pad_rows);
     HIP_TRY(hipSetDevice(device));
-    const int vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(gathered)) % 16 == 0);
-    const size_t total = (size_t)(vec ? w / 4 : w) * (size_t)h;
+    const int vec = (w % 2 == 0) && ((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(gathered)) % 8 == 0);
+    const size_t total = (size_t)(vec ? w / 2 : w) * (size_t)h;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(rt_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, full, gathered, w, h, nranks,
@@ -847,6 +959,7 @@ static int dbg_set_matlds(rt_ctx *c, int v) { c->mat_lds_limit = v; return RT_OK
 static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT_OK; }
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
+static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
 static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }
 
 // tuning knob (not part of the contract): 0 = automatic, 1 = free-running, n = gate of n lanes
@@ -865,6 +978,24 @@ RT_API int rt_debug_set_persist(rt_ctx *c, int on) {
 RT_API int rt_debug_set_ncus(rt_ctx *c, int n) {      // shrink the persistent grid (tests of the tile queue)
     if (!c || n < 1) return fail(RT_ERR_ARG, "n %d", n);
     return dbg_apply(c, dbg_set_ncus, n);
+}
+RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour)
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    return dbg_apply(c, dbg_set_order, on);
+}
+// the tile order in use (valid = 0: none, tiles run in their natural order) and the per-tile costs of the last launch
+RT_API int rt_debug_read_tile_order(rt_ctx *c, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid) {
+    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    const uint32_t n = cap < c->n_tiles ? cap : c->n_tiles;
+    if (order_out && n) HIP_TRY(hipMemcpy(order_out, c->d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (cost_out && n) HIP_TRY(hipMemcpy(cost_out, c->d_tile_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (n_tiles) *n_tiles = c->n_tiles;
+    if (valid) *valid = c->order_valid ? 1 : 0;
+    return RT_OK;
 }
 RT_API int rt_debug_set_coop_min(rt_ctx *c, int min_spheres) {
     if (!c || min_spheres < 0) return fail(RT_ERR_ARG, "min_spheres %d", min_spheres);
@@ -889,24 +1020,27 @@ RT_API int rt_debug_counters_raw(rt_ctx *c, unsigned long long *out32) {
     return RT_OK;
 }
 
-static unsigned long long *timelog_next(rt_ctx *c) {
+static unsigned long long *timelog_next(rt_ctx *c, uint32_t *seq_out) {
     if (!c->d_timelog || c->timelog_used >= c->timelog_cap) return nullptr;
+    *seq_out = c->timelog_used;
     return c->d_timelog + 8 * (size_t)(c->timelog_used++);
 }
 
 // NOTE: deliberately NOT chained (no event dependency added by the library): this is the round-1 reset,
 // kept to reproduce and study the ordering failure recorded in DESIGN.md section 3
-RT_API int rt_debug_reset_by_copy(rt_ctx *c, void *hip_stream, int use_memcpy) {
+RT_API int rt_debug_reset_by_copy(rt_ctx *c, void *hip_stream, int flags) {
     if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     const size_t n = 2 * (size_t)c->w * (size_t)c->h;
-    if (use_memcpy) {
+    if (flags & 1) {
         HIP_TRY(hipMemcpyAsync(c->d_seeds, c->d_seeds0, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
     } else {
-        unsigned long long *tl = timelog_next(c);
+        uint32_t seq = 0;
+        unsigned long long *tl = timelog_next(c, &seq);
+        unsigned long long *bl = (tl && c->d_blocklog) ? c->d_blocklog + (size_t)seq * 1024 : nullptr;
         hipLaunchKernelGGL(rt_debug_copy_seeds_kernel, dim3(1024), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0, n, tl,
-                           c->timelog_tag);
+                           c->timelog_tag, bl, flags);
         HIP_TRY(hipGetLastError());
     }
     c->seeds_default = false;
@@ -916,13 +1050,15 @@ RT_API int rt_debug_reset_by_copy(rt_ctx *c, void *hip_stream, int use_memcpy) {
 
 // a kernel on `hip_stream` that counts the seed words differing from the default stream
 // into counters[28] (and the number of probes into counters[29]); read them with rt_debug_counters_raw
-RT_API int rt_debug_probe_seeds(rt_ctx *c, void *hip_stream) {
+RT_API int rt_debug_probe_seeds(rt_ctx *c, void *hip_stream, int flags) {
     if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    unsigned long long *tl = timelog_next(c);
+    uint32_t seq = 0;
+    unsigned long long *tl = timelog_next(c, &seq);
+    uint32_t *sl = (tl && c->d_stalelog) ? c->d_stalelog + (size_t)seq * 64 : nullptr;
     hipLaunchKernelGGL(rt_debug_probe_seeds_kernel, dim3(256), dim3(256), 0, (hipStream_t)hip_stream, c->d_seeds, c->d_seeds0,
-                       2 * (size_t)c->w * (size_t)c->h, c->d_counters + 28, tl, c->timelog_tag);
+                       2 * (size_t)c->w * (size_t)c->h, c->d_counters + 28, tl, c->timelog_tag, sl, flags);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -935,9 +1071,16 @@ RT_API int rt_debug_timelog_enable(rt_ctx *c, uint32_t entries, uint32_t wave_en
     if (rc != RT_OK) return rc;
     (void)hipFree(c->d_timelog);
     (void)hipFree(c->d_wavelog);
-    c->d_timelog = c->d_wavelog = nullptr;
+    (void)hipFree(c->d_blocklog);
+    (void)hipFree(c->d_stalelog);
+    c->d_timelog = c->d_wavelog = c->d_blocklog = nullptr;
+    c->d_stalelog = nullptr;
     c->timelog_cap = c->timelog_used = c->wavelog_cap = 0;
     if (entries) {
+        HIP_TRY(hipMalloc(&c->d_blocklog, (size_t)entries * 1024 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_blocklog, 0, (size_t)entries * 1024 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&c->d_stalelog, (size_t)entries * 64 * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(c->d_stalelog, 0, (size_t)entries * 64 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_timelog, (size_t)entries * 8 * sizeof(unsigned long long)));
         std::vector<unsigned long long> init((size_t)entries * 8, 0ull);
         for (uint32_t i = 0; i < entries; ++i) init[8 * (size_t)i] = ~0ull;
@@ -967,6 +1110,19 @@ RT_API int rt_debug_timelog_read(rt_ctx *c, unsigned long long *out, uint32_t en
     const uint32_t n = entries < c->timelog_cap ? entries : c->timelog_cap;
     if (n) HIP_TRY(hipMemcpy(out, c->d_timelog, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (used) *used = c->timelog_used;
+    return RT_OK;
+}
+
+// the per-workgroup log of copy record `seq` (1024 u64: start << 4 | xcc) and the stale-word log of probe
+// record `seq` (64 u32: count, then index | reader xcc << 28)
+RT_API int rt_debug_sidelog_read(rt_ctx *c, uint32_t seq, unsigned long long *blocklog1024, uint32_t *stalelog64) {
+    if (!c || c->multi || seq >= c->timelog_cap) return fail(RT_ERR_ARG, "null / multi-device context / record %u", seq);
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    if (blocklog1024) HIP_TRY(hipMemcpy(blocklog1024, c->d_blocklog + (size_t)seq * 1024, 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (stalelog64) HIP_TRY(hipMemcpy(stalelog64, c->d_stalelog + (size_t)seq * 64, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -52,6 +52,8 @@ struct LaunchParams {
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
     float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
+    const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order
+    uint32_t *tile_cost;    // per tile: wall-clock ticks (10 ns) of its slowest wavefront, written by every launch (or null)
     // diagnostics build only (null in the product library): launch sequence number and the buffers the
     // instrumented instance logs device wall-clock intervals into (tools/gather_stress.py, tools/wave_timeline.py)
     unsigned long long *timelog;   // [seq][8]: min start, max end of the launch (s_memrealtime, 100 MHz), kind, tag, ...
@@ -89,5 +91,25 @@ hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream);
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);
 hipError_t prepare_parity();    // raise the dynamic-LDS limit (called once per context)
 hipError_t prepare_fast();
+
+#if defined(__HIPCC__)
+// Write-through stores (global_store ... sc1; 8 bytes at most per store).  Every byte a kernel of this
+// library leaves for a later consumer -- seeds, colour plane, pixels, scene tables, assembled frames -- is
+// stored this way: it goes to memory at once and leaves NO dirty line in the XCD's L2.  Reason (DESIGN.md
+// section 3, profiles/r02_stale_seed_*): when a compute queue is descheduled in the middle of a kernel (four
+// processes time-sliced on one GPU), plain stores of the workgroups of one XCD that had already finished were
+// lost -- the dirty lines never reached memory, although every AQL packet carried the barrier bit and
+// agent-scope release/acquire.  Atomics and write-through stores are not held in that L2 and survived.
+__device__ __forceinline__ void st_wt(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_wt(float4 *p, float4 v) {          // two 8-byte stores (p is 16-byte aligned)
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    st_wt(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32));
+    st_wt(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32));
+}
+#endif
 
 }  // namespace rt

@@ -31,6 +31,12 @@ struct rt_ctx {
     float4 *d_tables = nullptr;         // geom | emis | colr | lightA | lightB, each `scene_cap` entries
     uint32_t scene_cap = 0;
     std::vector<unsigned char> is_light;   // host mirror of the light test per sphere (sizes the light list)
+    std::vector<rt_sphere> h_spheres;      // host mirror of the records (an identical rt_set_scene uploads nothing)
+    // heavy-first tile order (rt_trace.inc.h): per-tile cost of the last launch, and the order derived from it
+    uint32_t *d_tile_cost = nullptr, *d_order = nullptr;
+    uint32_t n_tiles = 0;
+    bool cost_valid = false, order_valid = false;
+    int use_order = 1;
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
     uint32_t stage_cap = 0;             // records per slot
     int stage_next = 0;
@@ -54,7 +60,8 @@ struct rt_ctx {
     bool used_foreign_stream = false;   // some launch went to a caller's stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
     // diagnostics build: device wall-clock logs
-    unsigned long long *d_timelog = nullptr, *d_wavelog = nullptr;
+    unsigned long long *d_timelog = nullptr, *d_wavelog = nullptr, *d_blocklog = nullptr;
+    uint32_t *d_stalelog = nullptr;
     uint32_t timelog_cap = 0, timelog_used = 0, wavelog_cap = 0;
     unsigned long long timelog_tag = 0;
 };

@@ -108,19 +108,15 @@ def test_display_hand_off_frames_are_whole_frames_of_the_sequence(tmp_path):
         summary, seen = lines[-1], lines[:-1]
         assert summary["failed"] == 0 and summary["last_pass"] == passes and summary["frames_seen"] == len(seen) >= 2
         assert "Mray/s" in summary["caption"] and "pass" in summary["caption"]
-        hashes = {}
-        colors, seeds = None, None
-        # the oracle's frame after every pass count that was seen (one progressive run, hashed as the tool hashes)
-        need = sorted({f["pass"] for f in seen})
-        state = None
-        done = 0
-        for p in need:
-            state = O.render(sph, cam, w, h, p - done, first_sample=done, seeds_in=None if state is None else state["seeds"],
+        # the oracle's frame after every pass (one progressive run, hashed as the tool hashes)
+        hashes, state = {}, None
+        for p in range(1, passes + 1):
+            state = O.render(sph, cam, w, h, 1, first_sample=p - 1, seeds_in=None if state is None else state["seeds"],
                              colors_in=None if state is None else state["colors"])
-            done = p
             hashes[p] = O.fnv(state["pixels"])
-        for f in seen:
-            assert f["fnv"] == hashes[f["pass"]], f
+        by_hash = {v: k for k, v in hashes.items()}
+        wrong = [(f["pass"], by_hash.get(f["fnv"], "no frame of the sequence")) for f in seen if f["fnv"] != hashes[f["pass"]]]
+        assert not wrong, "frames (published as pass, actually pass): %s of %d seen" % (wrong[:10], len(seen))
 
 
 @pytest.mark.gpu

@@ -610,7 +610,7 @@ def test_multi_rank_frame_loop_every_frame_checked():
                          env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("gather stress:")]
-    assert lines and lines[-1].endswith("-> 0 wrong frames"), res.stdout[-3000:]
+    assert lines and lines[-1].endswith("-> 0 wrong frames []"), res.stdout[-3000:]
 
 
 @pytest.mark.parametrize("w,h,nranks", [(33, 17, 1), (31, 8, 1), (64, 9, 3), (200, 120, 4), (7, 3, 2), (1920, 7, 1)])

@@ -42,23 +42,25 @@ def main():
     ap.add_argument("--mat-lds", type=int, default=-1, help="override the LDS byte limit for staging materials")
     ap.add_argument("--skip-pixels", action="store_true", help="launches leave the packed pixels alone (rt_set_pixel_write 0)")
     ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
+    ap.add_argument("--orders", default="", help="comma list of 0/1: natural tile order / heavy tiles first")
     args = ap.parse_args()
     modes = [int(m) for m in args.modes.split(",")]
     gates = [int(g) for g in args.gates.split(",")] if args.gates else [None]
     persists = [int(g) for g in args.persist.split(",")] if args.persist else [None]
-    variants = [(m, g, q) for m in modes for g in gates for q in persists]
+    orders = [int(g) for g in args.orders.split(",")] if args.orders else [None]
+    variants = [(m, g, q, o) for m in modes for g in gates for q in persists for o in orders]
     for cname in args.configs.split(","):
         maker, w, h, spp = CONFIGS[cname]
         if args.spp:
             spp = args.spp
         sph, orig, target = maker()
         cam = host.compute_camera(orig, target, w, h)
-        with api.RtContext(w, h) as ctx:
+        with api.RtContext(w, h, diag=True) as ctx:
             ctx.set_scene(sph)
             ctx.set_camera(cam)
             times = {v: [] for v in variants}
             pix, stats = {}, {}
-            lib = api.load_library()
+            lib = api.load_library(diag=True)
             if args.mat_lds >= 0:
                 lib.rt_debug_set_mat_lds_limit(ctx._h, args.mat_lds)
             if args.coop_min >= 0:
@@ -67,11 +69,16 @@ def main():
                 ctx.set_pixel_write(False)
             for r in range(args.rounds + 1):
                 for v in variants:
-                    m, g, q = v
+                    m, g, q, o = v
                     ctx.set_mode(m)
                     lib.rt_debug_set_regen_gate(ctx._h, 0 if g is None else g)
                     if q is not None:
                         lib.rt_debug_set_persist(ctx._h, q)
+                    if o is not None:
+                        lib.rt_debug_set_tile_order(ctx._h, o)
+                        if o:                               # (the order is dropped when the knob moves: one untimed launch sorts again)
+                            ctx.reset()
+                            ctx.render_pass(spp)
                     ctx.reset()
                     px = ctx.render_pass(spp)
                     st = ctx.stats()
@@ -81,12 +88,12 @@ def main():
                         times[v].append(st["last_kernel_ms"])
             base = pix[variants[0]]
             for v in variants:
-                m, g, q = v
+                m, g, q, o = v
                 st = stats[v]
                 rays = st["samples"] + st["shadow_rays"]
                 med, mn = statistics.median(times[v]), min(times[v])
                 same = bool(np.array_equal(pix[v], base))
-                print(json.dumps({"config": cname, "mode": m, "gate": g, "persist": q, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                print(json.dumps({"config": cname, "mode": m, "gate": g, "persist": q, "heavy_first": o, "ms_median": round(med, 4), "ms_min": round(mn, 4),
                                   "Gray_s": round(rays / med / 1e6, 2), "same_as_first": same,
                                   "psnr_vs_first": None if same else round(host.psnr(pix[v], base), 2),
                                   "tests_per_sample": round(st["sphere_tests"] / st["samples"], 2),

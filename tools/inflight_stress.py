@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """F contexts in flight on their own streams (bench.py's pattern), every frame checked."""
 import os, sys
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,8 +14,8 @@ ctxs, want = [], []
 for k in range(F):
     sph, orig, target = scn[k % 2]
     cam = host.compute_camera(orig, target, w, h)
-    c = api.RtContext(w, h); c.set_scene(sph); c.set_camera(cam); ctxs.append(c)
-    with api.RtContext(w, h) as ref:
+    c = api.RtContext(w, h, diag=True); c.set_scene(sph); c.set_camera(cam); ctxs.append(c)
+    with api.RtContext(w, h, diag=True) as ref:
         ref.set_scene(sph); ref.set_camera(cam); want.append(ref.render_pass(spp))
 bad = 0
 progressive = len(sys.argv) > 3 and sys.argv[3] == "progressive"
@@ -35,7 +34,7 @@ for r in range(rounds):
     for c in ctxs:
         if len(sys.argv) > 3 and sys.argv[3] in ("copykernel", "memcpy"):    # the earlier reset: seeds restored by a copy, read back by the launch
             import ctypes as C
-            lib = api.load_library()
+            lib = api.load_library(diag=True)
             lib.rt_debug_reset_by_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
             lib.rt_debug_reset_by_copy(c._h, C.c_void_p(c.stream), 1 if sys.argv[3] == "memcpy" else 0)
         else:

@@ -16,12 +16,12 @@ for name, maker in (("demo", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DE
             cases.append((name, sph, o, target, w, h))
 for name, sph, o, t, w, h in cases:
     cam = host.compute_camera(o, t, w, h)
-    with api.RtContext(w, h) as ctx:
+    with api.RtContext(w, h, diag=True) as ctx:
         ctx.set_scene(sph); ctx.set_camera(cam); ctx.set_mode(105)
         ctx.render_pass(8, copy=False)
         st = ctx.stats()
         buf = (C.c_ulonglong * 24)()
-        api.load_library().rt_debug_counters(ctx._h, buf)
+        api.load_library(diag=True).rt_debug_counters(ctx._h, buf)
         v = list(buf)
         print("CENSUS " + json.dumps({"name": name, "w": w, "h": h, "n": len(sph), "execs": [c >> 32 for c in v[:10]],
                                       "lanes": [c & 0xFFFFFFFF for c in v[:10]], "roots_c": v[10], "roots_s": v[11],

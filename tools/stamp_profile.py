@@ -16,14 +16,14 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
     maker, w, h, spp = CONFIGS[cname]
     sph, orig, target = maker()
     cam = host.compute_camera(orig, target, w, h)
-    with api.RtContext(w, h) as ctx:
+    with api.RtContext(w, h, diag=True) as ctx:
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         ctx.set_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 101)
         ctx.render_pass(spp, copy=False)
         st = ctx.stats()
         buf = (C.c_ulonglong * 24)()
-        api.load_library().rt_debug_counters(ctx._h, buf)
+        api.load_library(diag=True).rt_debug_counters(ctx._h, buf)
         v = list(buf)[:12]
         print(f"{cname}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
               f"active lanes per execution, executions per sample-wave")

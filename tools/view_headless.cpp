@@ -15,9 +15,9 @@
 #include "rt_api.h"
 
 static unsigned long long fnv(const uint32_t* p, size_t n) {
-    unsigned long long hsh = 1469598103934665603ull;
+    unsigned long long hsh = 0xcbf29ce484222325ull;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < 4 * n; ++i) hsh = (hsh ^ b[i]) * 1099511628211ull;
+    for (size_t i = 0; i < 4 * n; ++i) hsh = (hsh ^ b[i]) * 0x100000001b3ull;
     return hsh;
 }
 
