@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 # further streams share them; two frames on one queue do not overlap at all.  Results never depend on it
 # (tools/gather_stress.py runs the N > 1 frame loop clean without it; DESIGN.md section 3 has the story of the
 # round-1 failure this variable used to paper over).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 W, H, SPP = 1920, 1080, 64            # the headline workload (BASELINE.json configs[1]); --workload changes them
 TILE_ROWS = 8

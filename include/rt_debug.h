@@ -35,6 +35,7 @@ RT_API int rt_debug_set_mat_lds_limit(rt_ctx *ctx, int bytes);
 RT_API int rt_debug_set_persist(rt_ctx *ctx, int on);
 RT_API int rt_debug_set_ncus(rt_ctx *ctx, int n);
 RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
+RT_API int rt_debug_set_wg_waves(rt_ctx *ctx, int waves);          /* 0 = automatic, 1 or 4 wavefronts per workgroup */
 RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order                */
 RT_API int rt_debug_read_tile_order(rt_ctx *ctx, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid);
 

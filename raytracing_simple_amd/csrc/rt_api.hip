@@ -41,24 +41,23 @@ using rt::fail;
 
 // rt_reset_async zeroes the work counters with a kernel on the caller's stream and restores NO seeds:
 // the next launch reads the pristine default stream directly (LaunchParams::seeds_in).
-// (Every store of the kernels in this file is a write-through store, rt_device.h st_wt.)
 __global__ void rt_zero_counters_kernel(unsigned long long *counters, unsigned long long *stats) {
-    for (int i = threadIdx.x; i < 32; i += blockDim.x) rt::st_wt(counters + i, 0ull);
-    for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) rt::st_wt(stats + i, 0ull);
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) counters[i] = 0ull;
+    for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) stats[i] = 0ull;
 }
 
 // rt_create / rt_reset: seeds = the pristine default stream, colour plane, pixels and counters zero
-// (OpenCLConfig.cpp:613-682), as ONE kernel with write-through stores instead of runtime copies and fills.
+// (OpenCLConfig.cpp:613-682), as ONE kernel instead of a runtime copy and four fills.
 __global__ void __launch_bounds__(256) rt_restore_kernel(unsigned long long *seeds, const unsigned long long *seeds0, size_t n_pairs,
                                                          uint32_t *colors, size_t n_colors, uint32_t *pixels, size_t n_pixels,
                                                          unsigned long long *counters, unsigned long long *stats) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t i = first; i < n_pairs; i += stride) rt::st_wt(seeds + i, seeds0[i]);
-    for (size_t i = first; i < n_colors; i += stride) rt::st_wt(colors + i, 0u);
-    for (size_t i = first; i < n_pixels; i += stride) rt::st_wt(pixels + i, 0u);
+    for (size_t i = first; i < n_pairs; i += stride) seeds[i] = seeds0[i];
+    for (size_t i = first; i < n_colors; i += stride) colors[i] = 0u;
+    for (size_t i = first; i < n_pixels; i += stride) pixels[i] = 0u;
     if (blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < 32; i += blockDim.x) rt::st_wt(counters + i, 0ull);
-        for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) rt::st_wt(stats + i, 0ull);
+        for (int i = threadIdx.x; i < 32; i += blockDim.x) counters[i] = 0ull;
+        for (int i = threadIdx.x; i < rt::kStatReplicas * 8; i += blockDim.x) stats[i] = 0ull;
     }
 }
 
@@ -83,9 +82,9 @@ __global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *s
         if (i < n) {
             const float *r = reinterpret_cast<const float *>(sph + i);      // 11 dwords: rad, p, e, c, refl
             rad = r[0]; px = r[1]; py = r[2]; pz = r[3]; ex = r[4]; ey = r[5]; ez = r[6];
-            rt::st_wt(geom + i, make_float4(px, py, pz, rad * rad));
-            rt::st_wt(emis + i, make_float4(ex, ey, ez, r[10]));              // refl keeps its bits
-            rt::st_wt(colr + i, make_float4(r[7], r[8], r[9], rad));
+            geom[i] = make_float4(px, py, pz, rad * rad);
+            emis[i] = make_float4(ex, ey, ez, r[10]);                        // refl keeps its bits
+            colr[i] = make_float4(r[7], r[8], r[9], rad);
             light = !((ex == 0.f) && (ez == 0.f));
         }
         const unsigned long long m = __builtin_amdgcn_ballot_w64(light);
@@ -95,14 +94,14 @@ __global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *s
         uint32_t off = s_base;
         for (int k = 0; k < wave; ++k) off += s_wave_count[k];
         if (light) {
-            rt::st_wt(la + off + before, make_float4(px, py, pz, rad));
-            rt::st_wt(lb + off + before, make_float4(ex, ey, ez, 4.f * 3.14159265358979323846f * rad * rad));
+            la[off + before] = make_float4(px, py, pz, rad);
+            lb[off + before] = make_float4(ex, ey, ez, 4.f * 3.14159265358979323846f * rad * rad);
         }
         __syncthreads();
         if (tid == 0) s_base += s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
         __syncthreads();
     }
-    if (tid == 0) rt::st_wt(n_lights_out, (uint32_t)s_base);
+    if (tid == 0) *n_lights_out = s_base;
 }
 
 // Heavy-first order of the 32x8 tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a
@@ -111,15 +110,22 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
     __shared__ unsigned s_max;
     __shared__ unsigned s_hist[1024];
     const unsigned tid = threadIdx.x;
+    constexpr unsigned kCap = 0x1FFFFFu;            // 21 ms of ticks: cost * 1023 stays inside 32 bits
     if (tid == 0) s_max = 1u;
     s_hist[tid] = 0u;
     __syncthreads();
     unsigned m = 0;
-    for (uint32_t i = tid; i < n; i += 1024) m = cost[i] > m ? cost[i] : m;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
+        m = c_ > m ? c_ : m;
+    }
     atomicMax(&s_max, m);
     __syncthreads();
-    const unsigned long long top = s_max;
-    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[1023u - (unsigned)((unsigned long long)cost[i] * 1023ull / top)], 1u);
+    const unsigned top = s_max;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
+        atomicAdd(&s_hist[1023u - c_ * 1023u / top], 1u);
+    }
     __syncthreads();
     if (tid == 0) {                     // exclusive prefix over the classes, most expensive class first
         unsigned run = 0;
@@ -131,25 +137,26 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
     }
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 1024) {
-        const unsigned pos = atomicAdd(&s_hist[1023u - (unsigned)((unsigned long long)cost[i] * 1023ull / top)], 1u);
-        rt::st_wt(order + pos, (uint32_t)i);
+        const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
+        const unsigned pos = atomicAdd(&s_hist[1023u - c_ * 1023u / top], 1u);
+        order[pos] = i;
     }
 }
 
 // rt_deinterleave_rows: full[y] = row (t/n)*tile_rows + y%tile_rows of rank t%n's block, t = y/tile_rows.
-// One thread per 8 bytes where the row length allows it (w % 2 == 0 keeps every row 8-byte aligned).
+// One thread per 16 bytes where the row length allows it (w % 4 == 0 keeps every row 16-byte aligned).
 __global__ void __launch_bounds__(256) rt_deinterleave_kernel(uint32_t *__restrict__ full, const uint32_t *__restrict__ gathered, int w,
                                                               int h, int nranks, int tile_rows, int pad_rows, int vec) {
-    const int per_row = vec ? w / 2 : w;
+    const int per_row = vec ? w / 4 : w;
     const size_t total = (size_t)per_row * (size_t)h;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(i / (size_t)per_row), xq = (int)(i - (size_t)y * (size_t)per_row);
         const int t = y / tile_rows, r = t % nranks, lrow = (t / nranks) * tile_rows + (y - t * tile_rows);
         const size_t src = ((size_t)r * (size_t)pad_rows + (size_t)lrow) * (size_t)w, dst = (size_t)y * (size_t)w;
         if (vec)
-            rt::st_wt(reinterpret_cast<unsigned long long *>(full + dst) + xq, reinterpret_cast<const unsigned long long *>(gathered + src)[xq]);
+            reinterpret_cast<uint4 *>(full + dst)[xq] = reinterpret_cast<const uint4 *>(gathered + src)[xq];
         else
-            rt::st_wt(full + dst + xq, gathered[src + xq]);
+            full[dst + xq] = gathered[src + xq];
     }
 }
 
@@ -167,7 +174,7 @@ __global__ void rt_debug_copy_seeds_kernel(uint32_t *seeds, const uint32_t *seed
     if (tl && threadIdx.x == 0 && blockIdx.x == 0) { tl[2] = 2ull; tl[3] = tag; }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         if (flags & 8) __hip_atomic_exchange(seeds + i, seeds0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // memory-side read-modify-write
-        else if (flags & 4) rt::st_wt(seeds + i, seeds0[i]);                // write-through (global_store ... sc1)
+        else if (flags & 4) __hip_atomic_store(seeds + i, seeds0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (global_store ... sc1)
         else seeds[i] = seeds0[i];
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -305,23 +312,48 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     p.mat_in_lds = lds_all <= (size_t)c->mat_lds_limit;
     const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
 
-    dim3 grid((unsigned)((c->w + rt::kTileW - 1) / rt::kTileW),
-              (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
-    hipError_t e;
+    // which instance: arithmetic mode x any-hit form x workgroup shape.  Single-wavefront workgroups (8x8 tiles)
+    // keep the wave slots of a CU full (a 4-wavefront workgroup waits for four free slots at once) and give the
+    // heavy-first order a finer granule; each stages its own copy of the tables, so only while 24 copies fit a CU.
     const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+    const bool fast = c->mode == RT_MODE_FAST;
+    const bool w1 = c->wg_waves == 1 || (c->wg_waves == 0 && lds + (coop ? 1536u : 256u) <= 6 * 1024);   // + the instance's static LDS
+    int variant = fast ? (coop ? (w1 ? rt::kFastCoopW1Variant : rt::kFastCoopVariant) : (w1 ? rt::kFastW1Variant : 0))
+                       : (coop ? (w1 ? rt::kParityCoopW1Variant : rt::kParityCoopVariant) : (w1 ? rt::kParityW1Variant : 0));
+    bool use_fast_table = fast;
+    bool persist = false;
+#if RT_DIAGNOSTICS
+    persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
+    if (persist) variant = fast ? (coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant)
+                                : (coop ? rt::kParityPersistCoopVariant : rt::kParityPersistVariant);
+    else if (c->mode >= 200) { variant = c->mode - 200; use_fast_table = true; }
+    else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
+#endif
+    const int waves = use_fast_table ? rt::fast_variant_waves(variant) : rt::parity_variant_waves(variant);
+    const int tile_w = 8 * waves;
+    dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
+    hipError_t e;
     // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
-    // same scene and camera walks the tiles in descending order of cost (sorted on the device, once)
-    if (c->use_order && c->d_tile_cost && (size_t)grid.x * grid.y == c->n_tiles) {
+    // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)
+    const uint32_t n_tiles = grid.x * grid.y;
+    bool instance_logs_cost = !persist;
+#if RT_DIAGNOSTICS
+    // A/B instances that predate the order (parity_r0) or have their own scheduling (stage-scheduled ones) neither
+    // read an order nor leave costs
+    if (!use_fast_table && (variant == 2 || variant == 3 || variant == 8)) instance_logs_cost = false;
+    if (use_fast_table && variant == 2) instance_logs_cost = false;
+#endif
+    if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
+        if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
         if (c->cost_valid && !c->order_valid && n_samples >= 8) {
-            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, c->n_tiles);
+            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
         }
         if (c->order_valid) p.order = c->d_order;
     }
 #if RT_DIAGNOSTICS
-    const bool persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
     if (persist) {
         // just enough workgroups to fill the machine; the tile queue (counters[30]) does the rest
         size_t per_cu = lds > 0 ? (160 * 1024) / (lds + 6 * 1024) : 6;
@@ -339,22 +371,17 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
         p.tl_tag = c->timelog_tag;
         p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
     }
-    if (persist && c->mode == RT_MODE_FAST)
-        e = rt::launch_fast(coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant, p, grid, lds, stream);
-    else if (persist)
-        e = rt::launch_parity(coop ? rt::kParityPersistCoopVariant : rt::kParityPersistVariant, p, grid, lds, stream);
-    else if (c->mode >= 200) e = rt::launch_fast(c->mode - 200, p, grid, lds, stream);
-    else if (c->mode >= 100) e = rt::launch_parity(c->mode - 100, p, grid, lds, stream);
-    else
 #endif
-    if (c->mode == RT_MODE_FAST) e = rt::launch_fast(coop ? rt::kFastCoopVariant : 0, p, grid, lds, stream);
-    else e = rt::launch_parity(coop ? rt::kParityCoopVariant : 0, p, grid, lds, stream);
+    e = use_fast_table ? rt::launch_fast(variant, p, grid, lds, stream) : rt::launch_parity(variant, p, grid, lds, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
                     hipGetErrorString(e), grid.x, grid.y, lds);
     c->current_sample += n_samples;
     c->launches += 1;
-    if (p.tile_cost && n_samples >= 4) c->cost_valid = true;
+    if (p.tile_cost && n_samples >= 4) {
+        c->cost_valid = true;
+        c->cost_tiles = n_tiles;
+    }
     c->seeds_default = false;           // this launch has written every seed pair the context renders
     c->pixels_current = c->pixel_write != 0;
     return RT_OK;
@@ -502,7 +529,7 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
         HIP_TRY(hipMalloc(&c->d_pixels, ((size_t)rows * w + 4) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc(&c->d_stats, rt::kStatReplicas * 8 * sizeof(unsigned long long)));
-        c->n_tiles = (uint32_t)(((w + rt::kTileW - 1) / rt::kTileW) * ((rows + rt::kTileH - 1) / rt::kTileH));
+        c->n_tiles = (uint32_t)(((w + 7) / 8) * ((rows + rt::kTileH - 1) / rt::kTileH));      // the finest tile shape (8x8)
         if (c->n_tiles) {
             HIP_TRY(hipMalloc(&c->d_tile_cost, (size_t)c->n_tiles * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&c->d_order, (size_t)c->n_tiles * sizeof(uint32_t)));
@@ -830,8 +857,8 @@ RT_API int rt_deinterleave_rows(uint32_t *full, const uint32_t *gathered, int w,
     if (pad_rows < need && pad_rows < ((n_tiles - 1) / nranks) * tile_rows + (h - (n_tiles - 1) * tile_rows))
         return fail(RT_ERR_ARG, "pad_rows %d is less than a rank's row count", pad_rows);
     HIP_TRY(hipSetDevice(device));
-    const int vec = (w % 2 == 0) && ((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(gathered)) % 8 == 0);
-    const size_t total = (size_t)(vec ? w / 2 : w) * (size_t)h;
+    const int vec = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(gathered)) % 16 == 0);
+    const size_t total = (size_t)(vec ? w / 4 : w) * (size_t)h;
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(rt_deinterleave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, full, gathered, w, h, nranks,
@@ -959,6 +986,7 @@ static int dbg_set_matlds(rt_ctx *c, int v) { c->mat_lds_limit = v; return RT_OK
 static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT_OK; }
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
+static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
 static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
 static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }
 
@@ -978,6 +1006,10 @@ RT_API int rt_debug_set_persist(rt_ctx *c, int on) {
 RT_API int rt_debug_set_ncus(rt_ctx *c, int n) {      // shrink the persistent grid (tests of the tile queue)
     if (!c || n < 1) return fail(RT_ERR_ARG, "n %d", n);
     return dbg_apply(c, dbg_set_ncus, n);
+}
+RT_API int rt_debug_set_wg_waves(rt_ctx *c, int waves) {    // 0 = automatic, 1 = single-wavefront workgroups, 4 = four wavefronts
+    if (!c || (waves != 0 && waves != 1 && waves != 4)) return fail(RT_ERR_ARG, "waves %d", waves);
+    return dbg_apply(c, dbg_set_wg, waves);
 }
 RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour)
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
@@ -1079,6 +1111,18 @@ RT_API int rt_debug_timelog_enable(rt_ctx *c, uint32_t entries, uint32_t wave_en
     if (entries) {
         HIP_TRY(hipMalloc(&c->d_blocklog, (size_t)entries * 1024 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(c->d_blocklog, 0, (size_t)entries * 1024 * sizeof(unsigned long long)));
+        if (wave_entries == 0xC0FFEEu) {
+            // provenance experiment (tools/gather_stress.py RT_LOG_PATTERN=1): the zeros above were written by the
+            // runtime's fill KERNEL (shader stores through some XCD's L2); now the same bytes are overwritten with a
+            // pattern by a host-to-device copy that does not go through any L2.  A workgroup log entry that is later
+            // found lost then tells by its value what happened: the pattern = the write never arrived; zero = a stale
+            // line from the fill kernel was written back over it afterwards.
+            HIP_TRY(hipDeviceSynchronize());
+            std::vector<unsigned long long> pat((size_t)entries * 1024, 0x5555555555555550ull);
+            HIP_TRY(hipMemcpy(c->d_blocklog, pat.data(), pat.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            HIP_TRY(hipDeviceSynchronize());
+            wave_entries = 0;
+        }
         HIP_TRY(hipMalloc(&c->d_stalelog, (size_t)entries * 64 * sizeof(uint32_t)));
         HIP_TRY(hipMemset(c->d_stalelog, 0, (size_t)entries * 64 * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_timelog, (size_t)entries * 8 * sizeof(unsigned long long)));

@@ -84,6 +84,10 @@ constexpr int kFastCoopVariant = 3;
 constexpr int kParityPersistVariant = 6, kParityPersistCoopVariant = 7;
 constexpr int kFastPersistVariant = 4, kFastPersistCoopVariant = 5;
 constexpr int kParityTimelogVariant = 9;
+constexpr int kParityW1Variant = 10, kParityCoopW1Variant = 11;   // single-wavefront workgroups (8x8 tiles)
+constexpr int kFastW1Variant = 6, kFastCoopW1Variant = 7;
+int parity_variant_waves(int variant);   // wavefronts per workgroup of an instance: 4 (32x8 tile) or 1 (8x8 tile)
+int fast_variant_waves(int variant);
 int parity_variant_count();
 int fast_variant_count();
 hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream, int which = 0);
@@ -91,25 +95,5 @@ hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream);
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);
 hipError_t prepare_parity();    // raise the dynamic-LDS limit (called once per context)
 hipError_t prepare_fast();
-
-#if defined(__HIPCC__)
-// Write-through stores (global_store ... sc1; 8 bytes at most per store).  Every byte a kernel of this
-// library leaves for a later consumer -- seeds, colour plane, pixels, scene tables, assembled frames -- is
-// stored this way: it goes to memory at once and leaves NO dirty line in the XCD's L2.  Reason (DESIGN.md
-// section 3, profiles/r02_stale_seed_*): when a compute queue is descheduled in the middle of a kernel (four
-// processes time-sliced on one GPU), plain stores of the workgroups of one XCD that had already finished were
-// lost -- the dirty lines never reached memory, although every AQL packet carried the barrier bit and
-// agent-scope release/acquire.  Atomics and write-through stores are not held in that L2 and survived.
-__device__ __forceinline__ void st_wt(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_wt(unsigned long long *p, unsigned long long v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_wt(float4 *p, float4 v) {          // two 8-byte stores (p is 16-byte aligned)
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
-    st_wt(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32));
-    st_wt(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32));
-}
-#endif
 
 }  // namespace rt

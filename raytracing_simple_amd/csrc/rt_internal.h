@@ -34,7 +34,9 @@ struct rt_ctx {
     std::vector<rt_sphere> h_spheres;      // host mirror of the records (an identical rt_set_scene uploads nothing)
     // heavy-first tile order (rt_trace.inc.h): per-tile cost of the last launch, and the order derived from it
     uint32_t *d_tile_cost = nullptr, *d_order = nullptr;
-    uint32_t n_tiles = 0;
+    uint32_t n_tiles = 0;               // capacity of the two arrays (8x8 tiles)
+    uint32_t cost_tiles = 0;            // tile count of the launch the costs come from
+    int wg_waves = 0;                   // diagnostics knob: 0 = automatic, 1 / 4 = force the workgroup shape
     bool cost_valid = false, order_valid = false;
     int use_order = 1;
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads

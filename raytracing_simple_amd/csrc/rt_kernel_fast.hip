@@ -35,6 +35,19 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_w1
+#define RT_KERNEL_NAME rt_trace_fast_w1
+#define RT_OPT_WG_WAVES 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fast_coop_w1
+#define RT_KERNEL_NAME rt_trace_fast_coop_w1
+#define RT_OPT_WG_WAVES 1
+#define RT_OPT_COOP 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS fast_persist
 #define RT_KERNEL_NAME rt_trace_fast_persist
@@ -65,15 +78,20 @@ static KernelFn const kFastKernels[] = {
 #if RT_DIAGNOSTICS
     fast_persist::rt_trace_fast_persist,             // 4 = kFastPersistVariant
     fast_persist_coop::rt_trace_fast_persist_coop,   // 5 = kFastPersistCoopVariant
+#else
+    nullptr, nullptr,
 #endif
+    fast_w1::rt_trace_fast_w1,                       // 6 = kFastW1Variant
+    fast_coop_w1::rt_trace_fast_coop_w1,             // 7 = kFastCoopW1Variant
 };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 
 int fast_variant_count() { return kFastCount; }
+int fast_variant_waves(int variant) { return (variant == kFastW1Variant || variant == kFastCoopW1Variant) ? 1 : 4; }
 
 hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
     if (variant < 0 || variant >= kFastCount || !kFastKernels[variant]) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kFastKernels[variant], grid, dim3(kBlockThreads), lds, stream, p);
+    hipLaunchKernelGGL(kFastKernels[variant], grid, dim3(64 * fast_variant_waves(variant)), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -35,6 +35,23 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_w1              /* single-wavefront workgroups (8x8 tiles): scenes with small tables */
+#define RT_KERNEL_NAME rt_trace_parity_w1
+#define RT_OPT_WG_WAVES 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_coop_w1
+#define RT_KERNEL_NAME rt_trace_parity_coop_w1
+#define RT_OPT_WG_WAVES 1
+#define RT_OPT_COOP 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS parity_coopv           /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coopv
@@ -103,15 +120,20 @@ static KernelFn const kParityKernels[] = {
     parity_persist_coop::rt_trace_parity_persist_coop,  // 7 = kParityPersistCoopVariant
     parity_r0::rt_trace_parity_r0,                      // 8
     parity_tl::rt_trace_parity_tl,                      // 9 = kParityTimelogVariant
+#else
+    nullptr, nullptr, nullptr, nullptr, nullptr,
 #endif
+    parity_w1::rt_trace_parity_w1,                      // 10 = kParityW1Variant
+    parity_coop_w1::rt_trace_parity_coop_w1,            // 11 = kParityCoopW1Variant
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
 int parity_variant_count() { return kParityCount; }
+int parity_variant_waves(int variant) { return (variant == kParityW1Variant || variant == kParityCoopW1Variant) ? 1 : 4; }
 
 hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {
     if (variant < 0 || variant >= kParityCount || !kParityKernels[variant]) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kParityKernels[variant], grid, dim3(kBlockThreads), lds, stream, p);
+    hipLaunchKernelGGL(kParityKernels[variant], grid, dim3(64 * parity_variant_waves(variant)), lds, stream, p);
     return hipGetLastError();
 }
 

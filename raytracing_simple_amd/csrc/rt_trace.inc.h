@@ -57,6 +57,14 @@
 // descending order of that cost (P.order), so that the launch ends on cheap tiles (sky) instead of on a
 // few wavefronts of the most expensive ones (glass: up to 8 bounces x 64 samples, 1.7 ms against a mean of
 // 0.5 ms) that happened to start late.  Scheduling only: pixels do not depend on who renders them when.
+// RT_OPT_WG_WAVES: wavefronts per workgroup, 4 (a 32x8 tile) or 1 (an 8x8 tile).  A workgroup of four wavefronts
+// holds its wave slots until the dispatcher finds room for four more at once (measured: 95-96 % of the slots
+// filled on the plateau of a launch); single-wavefront workgroups refill slot by slot and give the heavy-first
+// order an 8x8 granule.  Each workgroup stages its own copy of the tables, so this is for scenes whose tables are
+// small (the host picks: rt_api.hip launch()).
+#ifndef RT_OPT_WG_WAVES
+#define RT_OPT_WG_WAVES 4
+#endif
 // RT_OPT_AB_OLD: the `parity_r0` A/B instance = the shipped shape minus its newest change (tools/ab_bench.py)
 #ifndef RT_OPT_AB_OLD
 #define RT_OPT_AB_OLD 0
@@ -577,7 +585,10 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 #ifndef RT_OPT_MINWAVES
 #define RT_OPT_MINWAVES 1
 #endif
-extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
+extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
+    constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;      // (shadow the 4-wavefront constants of rt_device.h)
+    constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
+    (void)kTileW;
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
@@ -647,7 +658,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 #else
     const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;           // (wave-uniform: a scalar load)
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
-    __shared__ unsigned long long s_wave_t0[4];
+    __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
     if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
 #endif
 #if RT_OPT_WAVE_TILE_W == 8
@@ -699,7 +710,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     unsigned long long st_roots_c = 0, st_roots_s = 0;   // wave-uniform; dead unless RT_OPT_STAMPS
     (void)st_roots_s;
 #if RT_OPT_COOP
-    __shared__ __attribute__((aligned(16))) float s_coop[4 * kCoopWaveFloats];
+    __shared__ __attribute__((aligned(16))) float s_coop[RT_OPT_WG_WAVES * kCoopWaveFloats];
 #endif
 #if RT_OPT_STAMPS
     __shared__ unsigned long long s_census[12];
@@ -737,13 +748,14 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
 #endif
             if (F != 0ull) {
                 if (take && has_pixel) {                                   // .cl:580-599 of the finished pixel
-                    st_wt(P.colors + 3 * ci, acc.x);
-                    st_wt(P.colors + 3 * ci + 1, acc.y);
-                    st_wt(P.colors + 3 * ci + 2, acc.z);
+                    P.colors[3 * ci] = acc.x;
+                    P.colors[3 * ci + 1] = acc.y;
+                    P.colors[3 * ci + 2] = acc.z;
                     if (!P.skip_pixels)
-                        st_wt(P.pixels + (size_t)lrow * (size_t)P.w + (size_t)x,
-                              (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16)));
-                    st_wt(reinterpret_cast<unsigned long long *>(P.seeds + 2 * gid), (unsigned long long)s0 | ((unsigned long long)s1 << 32));
+                        P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =
+                            (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+                    P.seeds[2 * gid] = s0;
+                    P.seeds[2 * gid + 1] = s1;
                     c_samples += (uint32_t)P.n_samples;
                     has_pixel = false;
 #if RT_OPT_PERSIST == 2
@@ -1065,9 +1077,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
         asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;           // .cl:560-563
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;   // .cl:579
-        // write-through stores (rt_device.h st_wt: nothing of a frame stays behind as a dirty L2 line)
         float *colors = Q.colors;
-#if RT_OPT_AB_OLD
         colors[3 * ci] = acc.x;
         colors[3 * ci + 1] = acc.y;
         colors[3 * ci + 2] = acc.z;
@@ -1075,15 +1085,6 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
             Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =               // .cl:594-596
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);   // .cl:598-599
-#else
-        st_wt(colors + 3 * ci, acc.x);
-        st_wt(colors + 3 * ci + 1, acc.y);
-        st_wt(colors + 3 * ci + 2, acc.z);
-        if (!Q.skip_pixels)                                                // (wave-uniform)
-            st_wt(Q.pixels + (size_t)le * (size_t)Q.w + (size_t)xe,         // .cl:594-596
-                  (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16)));
-        st_wt(reinterpret_cast<unsigned long long *>(Q.seeds + 2 * gid), (unsigned long long)s0 | ((unsigned long long)s1 << 32));   // .cl:598-599
-#endif
     }
 
 #endif
@@ -1115,7 +1116,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES) RT_
     }
     __syncthreads();
 #if !RT_OPT_PERSIST && !RT_OPT_AB_OLD
-    if (tid == 5 && Q.tile_cost) st_wt(Q.tile_cost + tile_id, s_tile_cost);
+    if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
 #endif
     if (tid < 5) {
 #if RT_OPT_PERSIST
@@ -1160,7 +1161,7 @@ extern "C" __global__ void RT_PACK_KERNEL_NAME(const LaunchParams P) {
     if (x >= P.w || lrow >= P.local_rows || y >= P.h) return;
     const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;
     const float r = P.colors[3 * ci], g = P.colors[3 * ci + 1], b = P.colors[3 * ci + 2];
-    st_wt(P.pixels + (size_t)lrow * (size_t)P.w + (size_t)x, (uint32_t)(to_int(r) | (to_int(g) << 8) | (to_int(b) << 16)));
+    P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] = (uint32_t)(to_int(r) | (to_int(g) << 8) | (to_int(b) << 16));
 }
 #endif
 

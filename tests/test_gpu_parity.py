@@ -273,7 +273,7 @@ def test_every_kernel_instance_in_the_libraries_has_parity():
     cooperative any-hit shapes run (coop_min = 12 spheres)."""
     lib = api.load_library(diag=True)
     n_par, n_fast = lib.rt_debug_variant_count(0), lib.rt_debug_variant_count(1)
-    assert n_par >= 10 and n_fast >= 6
+    assert n_par >= 12 and n_fast >= 8
     for maker, w, h, spp in ((lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 96, 64, 6),
                              (lambda: scenes.mirror_box(64), 64, 48, 4)):
         sph, orig, target = maker()
@@ -282,6 +282,16 @@ def test_every_kernel_instance_in_the_libraries_has_parity():
         _assert_same(_gpu(sph, cam, w, h, spp), want)                       # the product library's instance
         for k in range(n_par):
             _assert_same(_gpu(sph, cam, w, h, spp, mode=100 + k), want)
+        # both workgroup shapes of the product selection (forced), with and without the heavy-first order
+        for waves in (1, 4):
+            with api.RtContext(w, h, diag=True) as ctx:
+                lib.rt_debug_set_wg_waves(ctx._h, waves)
+                ctx.set_scene(sph)
+                ctx.set_camera(cam)
+                for _ in range(3):
+                    ctx.reset()
+                    got = {"pixels": ctx.render_pass(8), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+                _assert_same(got, O.render(sph, cam, w, h, 8))
         # persistent-wavefront instances (tile queue), also with a grid much smaller than the tile count
         for persist_cus in (256, 3):
             with api.RtContext(w, h, diag=True) as ctx:

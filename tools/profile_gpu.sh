@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --mode $MODE --steps 4 --warmup 2 --no-cpu --no-extras"
+BENCH="python3 $R/bench.py --mode $MODE --steps 10 --warmup 3 --no-cpu --no-extras"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {
   name=$1; shift

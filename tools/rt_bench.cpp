@@ -3,7 +3,10 @@
 //
 //   rt_bench <framework ID> <CPU/GPU (0/1)> <mem (0/1/2)> [scene.scn]
 //            [--w W] [--h H] [--spp N] [--passes-per-launch K] [--pin] [--readback-ms T] [--mode parity|fast]
-//            [--no-doubling] [--out frame.ppm]
+//            [--no-doubling] [--out frame.ppm] [--oneshot K] [--gpus N]
+//   --oneshot K   render through the headline call rt_render(scene, cam, out, w, h, spp) K times instead of a
+//                 context (prints the wall time of every call: the first builds the device state, the rest reuse it)
+//   --gpus N      a multi-device context (rt_create_multi: N GPUs of this process, one RCCL gather per frame)
 //
 // The four positional arguments are the reference's; only framework ID 2 (the slot
 // Config.cpp:63-65 leaves empty) is served, GPU = 1, memory type 0 (Buffer).
@@ -41,7 +44,7 @@ static bool write_ppm(const std::string& path, const std::vector<uint32_t>& px, 
 }
 
 int main(int argc, char** argv) {
-    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY;
+    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY, oneshot = 0, gpus = 1;
     bool pin = false;
     double readback_ms = 0.0;   // > 0: copy the frame out only when the last copy is this old (the adapter's display cadence)   // SetupGL.cpp:32-33
     bool doubling = true;
@@ -58,6 +61,8 @@ int main(int argc, char** argv) {
         else if (a == "--readback-ms") readback_ms = atof(next());
         else if (a == "--mode") mode = strcmp(next(), "fast") == 0 ? RT_MODE_FAST : RT_MODE_PARITY;
         else if (a == "--no-doubling") doubling = false;
+        else if (a == "--oneshot") oneshot = atoi(next());
+        else if (a == "--gpus") gpus = atoi(next());
         else if (a == "--out") out = next();
         else pos.push_back(argv[i]);
     }
@@ -85,8 +90,23 @@ int main(int argc, char** argv) {
     }
     rt_compute_camera(&cam, w, h);
 
+    if (oneshot > 0) {                               // the one call north_star names, as a host would use it per frame
+        std::vector<uint32_t> px1(static_cast<size_t>(w) * h);
+        const rt_scene scene{ spheres.data(), n };
+        printf("{\"rt_render_wall_ms\": [");
+        for (int k = 0; k < oneshot; ++k) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (rt_render(&scene, &cam, px1.data(), w, h, spp) != RT_OK) return die("rt_render");
+            printf("%s%.3f", k ? ", " : "", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        printf("], \"w\": %d, \"h\": %d, \"spp\": %d, \"spheres\": %u}\n", w, h, spp, n);
+        if (!out.empty() && !write_ppm(out, px1, w, h)) fprintf(stderr, "cannot write %s\n", out.c_str());
+        rt_release_cache();
+        return 0;
+    }
+
     rt_ctx* ctx = nullptr;
-    if (rt_create(&ctx, w, h) != RT_OK) return die("rt_create");
+    if ((gpus > 1 ? rt_create_multi(&ctx, w, h, gpus) : rt_create(&ctx, w, h)) != RT_OK) return die("rt_create");
     if (rt_set_scene(ctx, spheres.data(), n) != RT_OK) return die("rt_set_scene");
     if (rt_set_camera(ctx, &cam) != RT_OK) return die("rt_set_camera");
     if (rt_set_mode(ctx, mode) != RT_OK) return die("rt_set_mode");

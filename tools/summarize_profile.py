@@ -19,7 +19,7 @@ def main():
     tag, mode, out_name = sys.argv[1], sys.argv[2], sys.argv[3]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "gpurun_out", tag)
-    kern = "rt_trace_" + mode
+    kern = sys.argv[4] if len(sys.argv) > 4 else "rt_trace_" + mode + "_w1"      # the C2 instance: single-wavefront workgroups
     summary = {"mode": mode, "kernel": kern, "source": f"gpurun_out/{tag} (tools/profile_gpu.sh)"}
     stats = find(os.path.join(src, "trace"), "*kernel_stats.csv")
     lines = []
