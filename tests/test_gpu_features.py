@@ -305,3 +305,32 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
             parts.append(px)
     from raytracing_simple_amd import dist as rdist
     assert np.array_equal(rdist.assemble_numpy(parts, h, w, 3, 8), want["pixels"])
+
+
+# ---- convergence tooling -----------------------------------------------------------------------
+def test_convergence_tool_checkpoints_are_the_oracles_frames_and_converge(tmp_path):
+    """tools/convergence.py: progressive checkpoints at every power of two, PPM per checkpoint, PSNR / RMSE
+    against a long render.  The PPMs must be the oracle's frames of those pass counts, and the error must fall."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    w, h = 96, 64
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "convergence.py"), "--scene", "demo", "--w", str(w), "--h", str(h),
+                          "--max-spp", "16", "--ref-spp", "256", "--out", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert [r["spp"] for r in rows] == [1, 2, 4, 8, 16]
+    assert rows[-1]["psnr_parity_vs_ref_db"] > rows[0]["psnr_parity_vs_ref_db"] + 6.0          # 16x the samples: ~12 dB
+    assert rows[-1]["rmse_colour_parity"] < rows[0]["rmse_colour_parity"] / 2
+    assert all(r["psnr_fast_vs_parity_same_spp_db"] >= 45.0 for r in rows)
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    for spp in (1, 4, 16):
+        raw = (tmp_path / ("demo_parity_%dspp.ppm" % spp)).read_bytes()
+        head = b"P6\n%d %d\n255\n" % (w, h)
+        assert raw.startswith(head)
+        rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)[::-1]
+        want = O.render(sph, cam, w, h, spp)["pixels"].view(np.uint8).reshape(h, w, 4)[:, :, :3]
+        assert np.array_equal(rgb, want), spp

@@ -20,6 +20,7 @@ else
     raytracing_simple_amd/rt_bench 2 1 0 --w 1920 --h 1080 --spp 64 --oneshot 8 | tee $O/rt_bench_oneshot.json
     raytracing_simple_amd/rt_bench 2 1 0 raytracing_simple_amd/scenes_scn/c16_demo_plus_10.scn --no-doubling --w 1920 --h 1080 --spp 64 | tee $O/rt_bench_c16.json
     raytracing_simple_amd/rt_inflight 1 20 | tee $O/rt_inflight.jsonl; raytracing_simple_amd/rt_inflight 2 20 | tee -a $O/rt_inflight.jsonl
+    python tools/ab_bench.py --configs c2,c16 --modes 0 --gates 8,10,12,14 --orders 1 --rounds 9 > $O/ab_gates.jsonl 2>&1; cut -c1-200 $O/ab_gates.jsonl
     RT_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_n2_rehearsal.json 2> $O/bench_n2.err; tail -c 400 $O/bench_n2_rehearsal.json
 fi
 echo "part $PART done"
