@@ -642,14 +642,14 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
-    c->cost_valid = c->order_valid = false;
+    c->order_valid = false;             // the last frame's costs still predict this one (moving spheres): sort them again
     return upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
 }
 
 RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
     if (c->multi) return rt::multi_set_camera(c, cam);
-    if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) c->cost_valid = c->order_valid = false;
+    if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) c->order_valid = false;   // a moved camera: the last frame's costs, sorted again
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;
     return RT_OK;

@@ -279,18 +279,24 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         capped = np.minimum(cost, 0x1FFFFF).astype(np.uint64)
         cls = 1023 - (capped * 1023 // int(capped.max())).astype(np.int64)                    # the kernel's cost classes
         assert np.all(np.diff(cls[order]) >= 0)                                # most expensive class first
-        # short launches neither sort nor need an order; a changed camera drops it
+        # short launches neither sort nor need an order
         ctx.reset(); ctx.render_pass(2); ctx.render_pass(6)
         _assert_same(_state(ctx, ctx.read_pixels()), want)
+        # a moved camera keeps the last frame's costs (they still predict the next frame) and sorts them again
         cam2 = host.compute_camera((30.0, 90.0, 110.0), target, w, h)
         ctx.set_camera(cam2)
         ctx.reset()
         _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))
-        assert not order_state(ctx)[2]
+        assert order_state(ctx)[2]
         ctx.set_scene(sph)                                                     # the identical scene: nothing changes
         ctx.reset()
         _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))
         assert order_state(ctx)[2]
+        ctx.set_scene(scenes.demo_plus(12)[0])                                 # another scene: costs and order dropped
+        ctx.reset(); ctx.render_pass(spp)
+        assert not order_state(ctx)[2]
+        ctx.set_scene(sph)
+        ctx.reset(); ctx.render_pass(spp)
         lib.rt_debug_set_tile_order(ctx._h, 0)                                 # knob: natural order again
         ctx.reset()
         _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))

@@ -35,7 +35,7 @@ for r in range(rounds):
         if len(sys.argv) > 3 and sys.argv[3] in ("copykernel", "memcpy"):    # the earlier reset: seeds restored by a copy, read back by the launch
             import ctypes as C
             lib = api.load_library(diag=True)
-            lib.rt_debug_reset_by_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            
             lib.rt_debug_reset_by_copy(c._h, C.c_void_p(c.stream), 1 if sys.argv[3] == "memcpy" else 0)
         else:
             c.reset_async(c.stream)
