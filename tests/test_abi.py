@@ -80,6 +80,19 @@ def test_argument_validation_needs_no_device():
     assert lib.rt_render(None, None, None, 4, 4, 1) == -1
     assert lib.rt_set_scene(None, None, 0) == -1
     assert lib.rt_local_rows(None) == -1
+    # the round-2 entry points: argument checks come before any device call
+    assert lib.rt_create_multi(C.byref(h), 16, 16, 0) == -1 and b"ngpus" in lib.rt_last_error()
+    assert lib.rt_create_multi(C.byref(h), 16, 16, 65) == -1
+    assert lib.rt_create_multi_on(C.byref(h), 0, 16, (C.c_int * 1)(0), 1, 8) == -1
+    assert lib.rt_create_multi_on(C.byref(h), 16, 16, None, 1, 8) == -1
+    assert lib.rt_shard_count(None) == -1
+    assert lib.rt_update_spheres_async(None, 0, 0, None, None) == -1
+    assert lib.rt_read_pixels(None, None) == -1
+    assert lib.rt_deinterleave_rows(None, None, 16, 16, 1, 8, 16, 0, None) == -1
+    buf = (C.c_uint32 * 4)()
+    assert lib.rt_deinterleave_rows(buf, buf, 0, 16, 1, 8, 16, 0, None) == -1
+    assert lib.rt_deinterleave_rows(buf, buf, 16, 16, 2, 8, 4, 0, None) == -1 and b"pad_rows" in lib.rt_last_error()
+    lib.rt_release_cache()                                            # nothing cached: a no-op, no device needed
 
 
 def test_default_seeds_equal_oracle_and_pins(golden_dir):
@@ -189,3 +202,14 @@ def test_committed_scn_files_equal_the_generators():
         doubled, _, _ = host.read_scene(os.path.join(d, name), reference_doubling=True)     # what the reference's loader hands over
         assert len(doubled) == 2 * len(sph) and not doubled[: len(sph)].view(np.uint8).any()
         assert np.array_equal(doubled[len(sph):].view(np.uint8), got.view(np.uint8))
+
+
+@pytest.mark.skipif(_gpu_present(), reason="checks the no-device paths of bench.py")
+def test_bench_refuses_to_measure_without_the_gpus_it_was_asked_for():
+    """`python bench.py --gpus N` without a launcher starts its ranks itself -- but never on fewer devices than asked
+    for, and never on a CPU fallback."""
+    import sys
+    for argv, text in ((["--gpus", "2"], "nothing is measured on fewer"), ([], "no HIP device visible")):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300,
+                             env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert res.returncode != 0 and text in (res.stderr + res.stdout), (argv, res.stderr[-500:])
