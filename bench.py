@@ -172,6 +172,11 @@ def main():
         return inproc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
+    # ONE line on stdout: whatever the libraries underneath print there (RCCL's version banner at communicator
+    # creation, for one) goes to stderr instead; the JSON line is written to the real stdout at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch                       # plumbing: streams, events, torch.distributed (RCCL)
@@ -477,6 +482,10 @@ def main():
                    "every_gathered_frame_equals_unsharded": None if frames_ok is None else frames_ok["wrong_pixels"] == 0,
                    "gathered_frames_checked": None if frames_ok is None else frames_ok["frames_checked"],
                    "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
+                   "strong_scaling_bound": None if world == 1 else
+                   "one frame cannot take less than its slowest wavefront: a pixel's 64 samples consume ONE random stream in order "
+                   "(.cl:143-169), 8 bounces x 64 samples over glass = 1.2-1.7 ms, so one frame gains at most ~2.3x from any number of "
+                   "GPUs (DESIGN.md section 6); frames_in_flight is the throughput of the same frames",
                    "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
                    "Mray_s_all_rays": round((closest + shadow) * args.steps / el1_max / 1e6, 1),
                    "Msample_s": round(samples * args.steps / el1_max / 1e6, 1)},
@@ -513,7 +522,8 @@ def main():
         line["cpu_baseline"] = base
         if args.mode == "parity":
             line["config"]["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(last_pixels, cpu_out["pixels"]))
-    print(json.dumps(line), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
     return 0
 
 

@@ -7,6 +7,7 @@
 //   --oneshot K   render through the headline call rt_render(scene, cam, out, w, h, spp) K times instead of a
 //                 context (prints the wall time of every call: the first builds the device state, the rest reuse it)
 //   --gpus N      a multi-device context (rt_create_multi: N GPUs of this process, one RCCL gather per frame)
+//   --rehearse N  the same with all N shards on device 0 (rt_create_multi_on: the one-GPU rehearsal of that path)
 //
 // The four positional arguments are the reference's; only framework ID 2 (the slot
 // Config.cpp:63-65 leaves empty) is served, GPU = 1, memory type 0 (Buffer).
@@ -44,7 +45,7 @@ static bool write_ppm(const std::string& path, const std::vector<uint32_t>& px, 
 }
 
 int main(int argc, char** argv) {
-    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY, oneshot = 0, gpus = 1;
+    int w = 800, h = 600, spp = 1, per_launch = 0, mode = RT_MODE_PARITY, oneshot = 0, gpus = 1, rehearse = 0;
     bool pin = false;
     double readback_ms = 0.0;   // > 0: copy the frame out only when the last copy is this old (the adapter's display cadence)   // SetupGL.cpp:32-33
     bool doubling = true;
@@ -63,6 +64,7 @@ int main(int argc, char** argv) {
         else if (a == "--no-doubling") doubling = false;
         else if (a == "--oneshot") oneshot = atoi(next());
         else if (a == "--gpus") gpus = atoi(next());
+        else if (a == "--rehearse") rehearse = atoi(next());
         else if (a == "--out") out = next();
         else pos.push_back(argv[i]);
     }
@@ -106,7 +108,12 @@ int main(int argc, char** argv) {
     }
 
     rt_ctx* ctx = nullptr;
-    if ((gpus > 1 ? rt_create_multi(&ctx, w, h, gpus) : rt_create(&ctx, w, h)) != RT_OK) return die("rt_create");
+    if (rehearse > 0) {
+        std::vector<int> dev(static_cast<size_t>(rehearse), 0);
+        if (rt_create_multi_on(&ctx, w, h, dev.data(), rehearse, 8) != RT_OK) return die("rt_create_multi_on");
+    } else if ((gpus > 1 ? rt_create_multi(&ctx, w, h, gpus) : rt_create(&ctx, w, h)) != RT_OK) {
+        return die("rt_create");
+    }
     if (rt_set_scene(ctx, spheres.data(), n) != RT_OK) return die("rt_set_scene");
     if (rt_set_camera(ctx, &cam) != RT_OK) return die("rt_set_camera");
     if (rt_set_mode(ctx, mode) != RT_OK) return die("rt_set_mode");
