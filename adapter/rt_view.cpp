@@ -23,27 +23,27 @@
 #include "rt_api.h"
 
 static ProgressiveRenderer* renderer;
-static int glWidth = 800, glHeight = 600;                    // SetupGL.cpp:32-33
-static char captionBuffer[256];
+static const int kWinW = 800, kWinH = 600;               // the reference's window size (glWidth, glHeight: SetupGL.cpp:32-33)
+static char caption_text[256];
 
-static void PrintString(void* font, const char* str) {       // SetupGL.cpp:42-47
-    for (size_t i = 0, len = strlen(str); i < len; ++i) glutBitmapCharacter(font, str[i]);
+static void draw_text(void* font, const char* text) {     // what SetupGL.cpp:42-47 (PrintString) does
+    while (*text) glutBitmapCharacter(font, *text++);
 }
 
-static void idleFunc(void) { glutPostRedisplay(); }          // SetupGL.cpp:52-57
+static void on_idle(void) { glutPostRedisplay(); }        // idleFunc, SetupGL.cpp:52-57
 
-static void displayFunc(void) {                              // SetupGL.cpp:59-76
+static void on_display(void) {                           // displayFunc, SetupGL.cpp:59-76
     const uint32_t* frame = renderer->frames().acquire();    // the latest whole frame; never one being copied into
-    renderer->copy_caption(captionBuffer, sizeof captionBuffer);
+    renderer->copy_caption(caption_text, sizeof caption_text);
     glClear(GL_COLOR_BUFFER_BIT);
     glRasterPos2i(0, 0);
-    glDrawPixels(glWidth, glHeight, GL_RGBA, GL_UNSIGNED_BYTE, frame);   // row 0 = bottom of the image, byte 0 = R (.cl:594-596)
+    glDrawPixels(kWinW, kWinH, GL_RGBA, GL_UNSIGNED_BYTE, frame);   // row 0 = bottom of the image, byte 0 = R (.cl:594-596)
     glColor3f(1.f, 1.f, 1.f);
-    glRasterPos2i(4, glHeight - 16);
-    PrintString(GLUT_BITMAP_HELVETICA_18, "Ray Tracing Experiment");
+    glRasterPos2i(4, kWinH - 16);
+    draw_text(GLUT_BITMAP_HELVETICA_18, "Ray Tracing Experiment");
     glColor3f(1.f, 1.f, 1.f);
     glRasterPos2i(4, 10);
-    PrintString(GLUT_BITMAP_HELVETICA_18, captionBuffer);
+    draw_text(GLUT_BITMAP_HELVETICA_18, caption_text);
     glutSwapBuffers();
 }
 
@@ -70,30 +70,30 @@ int main(int argc, char* argv[]) {
         cam.orig = rt_vec3{ 20.f, 100.f, 120.f };
         cam.target = rt_vec3{ 0.f, 25.f, 0.f };
     }
-    rt_compute_camera(&cam, glWidth, glHeight);               // updateCamera, OpenCLConfig.cpp:386-392
+    rt_compute_camera(&cam, kWinW, kWinH);               // updateCamera, OpenCLConfig.cpp:386-392
 
     rt_ctx* ctx = nullptr;
-    if (rt_create(&ctx, glWidth, glHeight) != RT_OK || rt_set_scene(ctx, spheres.data(), count) != RT_OK ||
+    if (rt_create(&ctx, kWinW, kWinH) != RT_OK || rt_set_scene(ctx, spheres.data(), count) != RT_OK ||
         rt_set_camera(ctx, &cam) != RT_OK) {
         fprintf(stderr, "Failed to set up the HIP render context: %s\n", rt_last_error());
         exit(-1);
     }
     const char* ms = getenv("RT_READBACK_MS");
-    ProgressiveRenderer progressive(ctx, glWidth, glHeight, ms ? atof(ms) : 8.0, 0);
+    ProgressiveRenderer progressive(ctx, kWinW, kWinH, ms ? atof(ms) : 8.0, 0);
     renderer = &progressive;
     progressive.start();                                      // the compute thread, Main.cpp:96-102
 
     char title[] = "SimpleRT (HIP / MI355X)";                 // InitGlut, SetupGL.cpp:80-100
-    glutInitWindowSize(glWidth, glHeight);
+    glutInitWindowSize(kWinW, kWinH);
     glutInitWindowPosition(0, 0);
     glutInitDisplayMode(GLUT_RGB | GLUT_DOUBLE);
     glutInit(&argc, argv);
     glutCreateWindow(title);
-    glutDisplayFunc(displayFunc);
-    glutIdleFunc(idleFunc);
-    glViewport(0, 0, glWidth, glHeight);
+    glutDisplayFunc(on_display);
+    glutIdleFunc(on_idle);
+    glViewport(0, 0, kWinW, kWinH);
     glLoadIdentity();
-    glOrtho(0.f, glWidth - 1.f, 0.f, glHeight - 1.f, -1.f, 1.f);
+    glOrtho(0.f, kWinW - 1.f, 0.f, kWinH - 1.f, -1.f, 1.f);
     glutMainLoop();                                           // Main.cpp:106 (does not return)
     progressive.stop();
     rt_destroy(ctx);
