@@ -350,6 +350,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
             hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
+            c->order_age = 0;
         }
         if (c->order_valid) p.order = c->d_order;
     }
@@ -642,14 +643,18 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
-    c->order_valid = false;             // the last frame's costs still predict this one (moving spheres): sort them again
+    // the last frames' costs still predict this one (moving spheres): the order stays, and is sorted again from
+    // fresh costs after a few changes
+    if (++c->order_age >= 8) c->order_valid = false;
     return upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
 }
 
 RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
     if (c->multi) return rt::multi_set_camera(c, cam);
-    if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) c->order_valid = false;   // a moved camera: the last frame's costs, sorted again
+    if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) {
+        if (++c->order_age >= 8) c->order_valid = false;        // a moved camera: the order stays for a few frames, then is sorted again
+    }
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;
     return RT_OK;
