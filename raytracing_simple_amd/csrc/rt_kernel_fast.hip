@@ -1,8 +1,8 @@
 // rt_kernel_fast.hip -- fused-arithmetic instances of the path-trace kernel
 // (-ffp-contract=fast, hardware rcp/rsq/sqrt/sin/cos/exp2/log2).  Gated by PSNR >= 50 dB
 // against the parity instance at equal spp (tests/test_gpu_parity.py).
-//   [0] rt_trace_fast, [3] rt_trace_fast_coop: shipped; the others are A/B shapes (mode 200+k) of the
-//   diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1).
+//   [0] rt_trace_fast, [3] rt_trace_fast_coop, [6] rt_trace_fast_w1, [7] rt_trace_fast_coop_w1: shipped; the
+//   others are A/B shapes (mode 200+k) of the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1).
 #define RT_FAST 1
 #ifndef RT_DIAGNOSTICS
 #define RT_DIAGNOSTICS 0

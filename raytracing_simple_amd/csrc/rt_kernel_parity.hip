@@ -1,7 +1,8 @@
 // rt_kernel_parity.hip -- strict-arithmetic instances of the path-trace kernel.
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
-//   [0] rt_trace_parity        shipped: small scenes
-//   [4] rt_trace_parity_coop   shipped: scenes with >= 12 spheres (cooperative any-hit)
+//   [0] rt_trace_parity, [10] rt_trace_parity_w1            shipped: small scenes (4-wave / single-wave workgroups)
+//   [4] rt_trace_parity_coop, [11] rt_trace_parity_coop_w1  shipped: scenes with >= 12 spheres (cooperative any-hit)
+//   (rt_api.hip launch() takes the single-wavefront shape while the scene tables leave LDS room for 6 waves per SIMD)
 // Everything else exists only in the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1):
 // A/B and verification shapes of the same arithmetic (mode 100+k, tools/ab_bench.py) and the
 // exhaustive device-side checks of the lean square root / reciprocal.
