@@ -10,6 +10,8 @@
 // null stream or a device-wide synchronisation.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -140,6 +142,184 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
         const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
         const unsigned pos = atomicAdd(&s_hist[1023u - c_ * 1023u / top], 1u);
         order[pos] = i;
+    }
+}
+
+// The hierarchy of rt_device.h BvhTables from the raw records, ONE workgroup of 1024 threads:
+//   1. a sphere stays outside the tree ("always" list, scene order kept) unless its radius and centre are finite and
+//      |rad| <= r_cut (the host derives r_cut from the median radius: ground planes, walls and lights the size of
+//      the scene would blow up every box above them);
+//   2. the tree's spheres are sorted along a 30-bit Morton curve through the box of their centres (bitonic sort of
+//      key << 32 | scene index in LDS);
+//   3. leaves take kBvhLeaf consecutive spheres; the tree over the leaves splits every range in the middle and is
+//      laid out depth-first, so a node's first child is the next node and `skip` = node + size of its subtree;
+//   4. boxes are rounded outwards; every node also carries the lowest scene index below it.
+// Host and device agree on the counts because they apply the same test to the same bits (bvh_outside).
+__host__ __device__ inline bool bvh_outside(float rad, float px, float py, float pz, float r_cut) {
+    const float big = 3.0e38f;
+    const bool finite = (fabsf(rad) <= big) && (fabsf(px) <= big) && (fabsf(py) <= big) && (fabsf(pz) <= big);   // false for NaN
+    return !(finite && fabsf(rad) <= r_cut);
+}
+__device__ inline unsigned bvh_ordered(float f) {          // unsigned order = float order
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float bvh_unordered(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__device__ inline unsigned bvh_spread(unsigned v) {        // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ inline float bvh_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
+__device__ inline float bvh_up(float v) { return v + (fabsf(v) * 0x1p-22f + 1e-30f); }
+
+__global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, uint32_t n, float r_cut, uint32_t n_always,
+                                                            uint32_t n_tree, uint32_t n_pad, float4 *blob) {
+    extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, later 2 float4 per leaf
+    __shared__ unsigned s_lo[3], s_hi[3], s_rmin, s_rmax;
+    __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad;
+    const unsigned tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    const uint32_t n_nodes = n_leaves ? 2 * n_leaves - 1 : 0;
+    const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
+    float4 *hdr = blob, *nodes = blob + 2, *slots = nodes + 2 * (size_t)n_nodes;
+    uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
+    if (tid < 3) { s_lo[tid] = 0xffffffffu; s_hi[tid] = 0u; }
+    if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; }
+    for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
+    __syncthreads();
+    // ---- 1. box of the tree's centres, radius range ----
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const float *r = reinterpret_cast<const float *>(sph + i);
+        if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
+            atomicMin(&s_lo[0], bvh_ordered(r[1])); atomicMax(&s_hi[0], bvh_ordered(r[1]));
+            atomicMin(&s_lo[1], bvh_ordered(r[2])); atomicMax(&s_hi[1], bvh_ordered(r[2]));
+            atomicMin(&s_lo[2], bvh_ordered(r[3])); atomicMax(&s_hi[2], bvh_ordered(r[3]));
+            atomicMin(&s_rmin, __float_as_uint(fabsf(r[0]))); atomicMax(&s_rmax, __float_as_uint(fabsf(r[0])));
+        }
+    }
+    __syncthreads();
+    const float lox = bvh_unordered(s_lo[0]), loy = bvh_unordered(s_lo[1]), loz = bvh_unordered(s_lo[2]);
+    const float kx = 1023.f / fmaxf(bvh_unordered(s_hi[0]) - lox, 1e-30f), ky = 1023.f / fmaxf(bvh_unordered(s_hi[1]) - loy, 1e-30f),
+                kz = 1023.f / fmaxf(bvh_unordered(s_hi[2]) - loz, 1e-30f);
+    // ---- 2. the always list in scene order, the tree's keys in any order (ballot prefix per 1024 records) ----
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        bool out = false, in = false;
+        float rad = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+        if (i < n) {
+            const float *r = reinterpret_cast<const float *>(sph + i);
+            rad = r[0]; px = r[1]; py = r[2]; pz = r[3];
+            out = bvh_outside(rad, px, py, pz, r_cut);
+            in = !out;
+        }
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(out), mt = __builtin_amdgcn_ballot_w64(in);
+        const uint32_t before_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+        const uint32_t before_t = __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
+        if ((tid & 63) == 0) { s_wave_a[wave] = (uint32_t)__popcll(ma); s_wave_t[wave] = (uint32_t)__popcll(mt); }
+        __syncthreads();
+        uint32_t off_a = s_base_a, off_t = s_base_t;
+        for (unsigned k = 0; k < wave; ++k) { off_a += s_wave_a[k]; off_t += s_wave_t[k]; }
+        if (out) {
+            const uint32_t j = off_a + before_a;
+            if (j < n_always) { slots[j] = make_float4(px, py, pz, rad * rad); index[j] = i; }
+            else atomicAdd(&s_bad, 1u);
+        }
+        if (in) {
+            const uint32_t j = off_t + before_t;
+            const unsigned qx = (unsigned)fminf(fmaxf((px - lox) * kx, 0.f), 1023.f), qy = (unsigned)fminf(fmaxf((py - loy) * ky, 0.f), 1023.f),
+                           qz = (unsigned)fminf(fmaxf((pz - loz) * kz, 0.f), 1023.f);
+            const unsigned code = (bvh_spread(qx) << 2) | (bvh_spread(qy) << 1) | bvh_spread(qz);
+            if (j < n_tree) s_keys[j] = ((unsigned long long)code << 32) | i;
+            else atomicAdd(&s_bad, 1u);
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < 16; ++k) { s_base_a += s_wave_a[k]; s_base_t += s_wave_t[k]; }
+        __syncthreads();
+    }
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {             // bitonic sort, ascending
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n_pad; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[l];
+                    if ((a > b) == ((i & k) == 0)) { s_keys[i] = b; s_keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 3. records in leaf order; padding records never hit (NaN centre: every comparison of the test is false) ----
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (uint32_t j = tid; j < rt::kBvhLeaf * n_leaves; j += 1024) {
+        const uint32_t ix = j < n_tree ? (uint32_t)s_keys[j] : 0xffffffffu;
+        if (ix != 0xffffffffu) {
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            slots[n_always + j] = make_float4(r[1], r[2], r[3], r[0] * r[0]);
+        } else {
+            slots[n_always + j] = make_float4(qnan, qnan, qnan, qnan);
+        }
+        index[n_always + j] = ix;
+    }
+    __threadfence_block();                                  // the index written above is read back below by other threads
+    __syncthreads();                                        // the keys are dead: the same LDS now holds the leaf boxes
+    float4 *s_leaf = reinterpret_cast<float4 *>(s_keys);
+    for (uint32_t leaf = tid; leaf < n_leaves; leaf += 1024) {
+        float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        uint32_t low = 0xffffffffu;
+        for (int k = 0; k < rt::kBvhLeaf; ++k) {
+            const uint32_t ix = index[n_always + rt::kBvhLeaf * leaf + k];
+            if (ix == 0xffffffffu) continue;
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            const float ar = fabsf(r[0]);
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], bvh_down(r[1 + a] - ar));
+                hi[a] = fmaxf(hi[a], bvh_up(r[1 + a] + ar));
+            }
+            low = ix < low ? ix : low;
+        }
+        s_leaf[2 * leaf] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        s_leaf[2 * leaf + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+    }
+    __syncthreads();
+    // ---- 4. one thread per node: leaves by number, inner nodes by the place where they split their range ----
+    for (uint32_t w = tid; w < n_nodes; w += 1024) {
+        const bool is_leaf = w < n_leaves;
+        const uint32_t want = is_leaf ? w : w - n_leaves + 1;       // leaf number, or split point in [1, n_leaves)
+        uint32_t a = 0, b = n_leaves, at = 0;
+        while (b - a > 1) {                                          // (a leaf's walk ends on a range of one)
+            const uint32_t mid = (a + b) / 2;
+            if (!is_leaf && mid == want) break;
+            if (want < mid) { at += 1; b = mid; }
+            else { at += 2 * (mid - a); a = mid; }
+        }
+        float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        uint32_t low = 0xffffffffu;
+        for (uint32_t l = a; l < b; ++l) {
+            const float4 A = s_leaf[2 * l], B = s_leaf[2 * l + 1];
+            lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
+            hi[0] = fmaxf(hi[0], B.x); hi[1] = fmaxf(hi[1], B.y); hi[2] = fmaxf(hi[2], B.z);
+            const uint32_t q = __float_as_uint(B.w);
+            low = q < low ? q : low;
+        }
+        const uint32_t skip = at + 2 * (b - a) - 1;
+        const uint32_t link = skip | (is_leaf ? (a + 1) << 16 : 0u);
+        nodes[2 * (size_t)at] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(link));
+        nodes[2 * (size_t)at + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+        if (at == 0) {
+            const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+            const float ex = hi[0] - cx, ey = hi[1] - cy, ez = hi[2] - cz;
+            hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
+            const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
+            hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float(s_bad));
+        }
+    }
+    if (n_nodes == 0 && tid == 0) {
+        hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(s_bad));
     }
 }
 
@@ -295,7 +475,16 @@ rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
     return p;
 }
 
-int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
+// the scene has a hierarchy and the instance that walks it fits
+bool bvh_usable(const rt_ctx *c, int n_samples) {
+    if (!c->bvh_ok || c->wg_waves == 1 || c->persist != 0) return false;
+    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
+    const bool mat = lds_all <= (size_t)c->mat_lds_limit;
+    return rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_nodes, c->bvh.n_slots, false) <= (size_t)c->bvh_lds_limit;
+}
+
+// `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one that fits), 2 = the plain sweep
+int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     if (!c->have_scene || !c->have_cam)
         return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
     if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
@@ -322,12 +511,38 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
                        : (coop ? (w1 ? rt::kParityCoopW1Variant : rt::kParityCoopVariant) : (w1 ? rt::kParityW1Variant : 0));
     bool use_fast_table = fast;
     bool persist = false;
+    // large scenes: the instance that walks the hierarchy, while its tables leave room for two workgroups per CU
+    size_t lds_use = lds;
+    const size_t lds_bvh = c->bvh_ok ? rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples,
+                                                        c->bvh.n_nodes, c->bvh.n_slots, false) : 0;
+    if (form != 2 && bvh_usable(c, n_samples)) {
+        const bool per_call = c->walk_form == 1;
+        variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant) : (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant);
+        p.bvh = c->bvh;
+        lds_use = lds_bvh;
+        if (!per_call && c->regen_gate <= 0) p.regen_gate = c->walk_gate;
+    }
+    p.walk_steps = c->walk_steps;
 #if RT_DIAGNOSTICS
     persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
     if (persist) variant = fast ? (coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant)
                                 : (coop ? rt::kParityPersistCoopVariant : rt::kParityPersistVariant);
     else if (c->mode >= 200) { variant = c->mode - 200; use_fast_table = true; }
     else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
+    if (c->mode >= 100) {
+        const bool wants_bvh = use_fast_table ? (variant == rt::kFastBvhVariant || variant == rt::kFastWalkVariant)
+                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityWalkVariant);
+        p.bvh = rt::BvhTables{};
+        lds_use = lds;
+        if (wants_bvh) {
+            if (!c->bvh_ok) return fail(RT_ERR_STATE, "mode %d needs a scene with a hierarchy (rt_debug_set_bvh)", c->mode);
+            const bool full = !use_fast_table && variant == rt::kParityBvhCheckVariant;
+            p.bvh = c->bvh;
+            lds_use = rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
+                                        c->bvh.n_slots, full);
+            if (lds_use > 152 * 1024) return fail(RT_ERR_ARG, "mode %d needs %zu B of LDS", c->mode, lds_use);
+        }
+    }
 #endif
     const int waves = use_fast_table ? rt::fast_variant_waves(variant) : rt::parity_variant_waves(variant);
     const int tile_w = 8 * waves;
@@ -373,10 +588,10 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
         p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
     }
 #endif
-    e = use_fast_table ? rt::launch_fast(variant, p, grid, lds, stream) : rt::launch_parity(variant, p, grid, lds, stream);
+    e = use_fast_table ? rt::launch_fast(variant, p, grid, lds_use, stream) : rt::launch_parity(variant, p, grid, lds_use, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
-                    hipGetErrorString(e), grid.x, grid.y, lds);
+                    hipGetErrorString(e), grid.x, grid.y, lds_use);
     c->current_sample += n_samples;
     c->launches += 1;
     if (p.tile_cost && n_samples >= 4) {
@@ -388,6 +603,61 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream) {
     return RT_OK;
 }
 
+// Hierarchy or plain sweep for this scene?  The walk wins by 3x on a thousand spheres scattered over a plane and
+// loses on a box packed with overlapping glass -- so it is measured: the first launch of a new scene walks the
+// hierarchy, the second sweeps, each between two events; when both have finished (asked without blocking), the
+// form that took less time per pass renders the rest.  A blocking call with enough passes splits off one pass for
+// each probe and waits for the verdict before it queues the rest (progressive passes equal one launch bit for bit).
+void probe_poll(rt_ctx *c, bool wait) {
+    if (c->bvh_pick != 0 || c->probe_state < 2) return;
+    if (wait) {
+        if (hipEventSynchronize(c->probe_ev[3]) != hipSuccess) return;
+    } else if (hipEventQuery(c->probe_ev[3]) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, c->probe_ev[0], c->probe_ev[1]) != hipSuccess || hipEventElapsedTime(&b, c->probe_ev[2], c->probe_ev[3]) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    const double ta = (double)a / c->probe_samples[0], tb = (double)b / c->probe_samples[1];
+    c->bvh_pick = ta <= 1.1 * tb ? 1 : 2;       // (the second probe may already run heavy tiles first)
+}
+
+int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
+    const int k = c->probe_state;               // 0: hierarchy, 1: plain sweep
+    int rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(c->probe_ev[2 * k], stream));
+    rc = launch_form(c, n_samples, stream, k == 0 ? 1 : 2);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(c->probe_ev[2 * k + 1], stream));
+    c->probe_samples[k] = n_samples;
+    c->probe_state = k + 1;
+    return RT_OK;
+}
+
+int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false) {
+    const bool measured = c->walk_form == 0 && c->mode < 100;
+    if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c, n_samples))
+        return launch_form(c, n_samples, stream, measured ? 2 : 0);
+    probe_poll(c, false);
+    if (c->bvh_pick != 0) return launch_form(c, n_samples, stream, c->bvh_pick);
+    if (c->probe_state == 2) return launch_form(c, n_samples, stream, 1);    // both probes in flight: the usual winner meanwhile
+    if (may_block && n_samples >= 16) {
+        int done = 0;
+        while (c->probe_state < 2) {
+            const int rc = launch_probe(c, 1, stream);
+            if (rc != RT_OK) return rc;
+            done += 1;
+        }
+        probe_poll(c, true);
+        return launch_form(c, n_samples - done, stream, c->bvh_pick ? c->bvh_pick : 1);
+    }
+    return launch_probe(c, n_samples, stream);
+}
+
 // ---- scene storage -------------------------------------------------------------------------
 
 bool light_test(const rt_sphere &s) { return !((s.e.x == 0.f) && (s.e.z == 0.f)); }   // .cl:135-138,266
@@ -395,8 +665,11 @@ bool light_test(const rt_sphere &s) { return !((s.e.x == 0.f) && (s.e.z == 0.f))
 void free_scene(rt_ctx *c) {
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_tables);
+    (void)hipFree(c->d_bvh);
     c->d_spheres = nullptr;
     c->d_tables = nullptr;
+    c->d_bvh = nullptr;
+    c->bvh_ok = false;
     c->scene_cap = 0;
 }
 
@@ -409,14 +682,19 @@ int ensure_scene_capacity(rt_ctx *c, uint32_t count) {
     rt_sphere *ns = nullptr;
     float4 *nt = nullptr;
     HIP_TRY(hipMalloc(&ns, (size_t)cap * sizeof(rt_sphere)));
+    float4 *nb = nullptr;
     hipError_t e = hipMalloc(&nt, ((size_t)cap * 5 + 1) * sizeof(float4));
+    // blob: 2 + 2 * nodes + slots + index, nodes < cap / 2 + 2, slots < cap + 4
+    if (e == hipSuccess) e = hipMalloc(&nb, ((size_t)cap * 5 / 2 + 32) * sizeof(float4));
     if (e != hipSuccess) {
         (void)hipFree(ns);
+        (void)hipFree(nt);
         return fail(RT_ERR_ALLOC, "scene tables for %u spheres: %s", cap, hipGetErrorString(e));
     }
     free_scene(c);
     c->d_spheres = ns;
     c->d_tables = nt;
+    c->d_bvh = nb;
     c->scene_cap = cap;
     return RT_OK;
 }
@@ -435,6 +713,40 @@ int ensure_stage_capacity(rt_ctx *c, uint32_t count) {
     c->stage_cap = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_stage), (size_t)cap * 4 * sizeof(rt_sphere), hipHostMallocDefault));
     c->stage_cap = cap;
+    return RT_OK;
+}
+
+// The hierarchy of a large scene (rt_bvh_build_kernel), on `stream` behind the records.  Which spheres stay outside
+// the tree is decided here, from the host mirror, with the test the device applies to the same bits: 16 times the
+// median |radius| is the cut (ground, walls, big lights), non-finite records stay outside as well.
+int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
+    c->bvh_ok = false;
+    c->bvh = rt::BvhTables{};
+    if (c->bvh_min <= 0 || n_total < (uint32_t)c->bvh_min || !c->d_bvh) return RT_OK;
+    std::vector<float> radii;
+    radii.reserve(n_total);
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const float r = fabsf(c->h_spheres[i].rad);
+        if (r <= 3.0e38f) radii.push_back(r);
+    }
+    if (radii.empty()) return RT_OK;
+    std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+    const float r_cut = 16.f * radii[radii.size() / 2];
+    uint32_t n_tree = 0;
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const rt_sphere &s = c->h_spheres[i];
+        n_tree += bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut) ? 0u : 1u;
+    }
+    if (n_tree < (uint32_t)c->bvh_min) return RT_OK;
+    const uint32_t n_always = n_total - n_tree;
+    uint32_t n_pad = 2;
+    while (n_pad < n_tree) n_pad *= 2;
+    const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    const size_t lds = std::max((size_t)n_pad * 8, (size_t)n_leaves * 32);
+    hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
+    HIP_TRY(hipGetLastError());
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, 2 * n_leaves - 1, n_always + rt::kBvhLeaf * n_leaves };
+    c->bvh_ok = true;
     return RT_OK;
 }
 
@@ -466,7 +778,7 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
         HIP_TRY(hipGetLastError());
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, n_total, nl };
-    return RT_OK;
+    return build_bvh(c, n_total, stream);
 }
 
 }  // namespace
@@ -522,6 +834,7 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
         c->last_stream = c->stream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
+        for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreate(&c->probe_ev[k]));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
         for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
         HIP_TRY(hipMalloc(&c->d_seeds, 2 * px * sizeof(uint32_t)));
@@ -543,6 +856,8 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
             if (device >= 64 || !prepared[device]) {
                 HIP_TRY(rt::prepare_parity());
                 HIP_TRY(rt::prepare_fast());
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rt_bvh_build_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 if (device < 64) prepared[device] = true;
             }
         }
@@ -587,6 +902,8 @@ RT_API void rt_destroy(rt_ctx *c) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
+        for (int k = 0; k < 4; ++k)
+            if (c->probe_ev[k]) (void)hipEventDestroy(c->probe_ev[k]);
         if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
         for (int k = 0; k < 4; ++k)
             if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
@@ -618,6 +935,8 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     c->is_light.assign(c->scene_cap, 0);
     c->h_spheres.assign(spheres, spheres + count);
     c->cost_valid = c->order_valid = false;
+    c->bvh_pick = 0;                    // a new scene: hierarchy or plain sweep is measured again
+    c->probe_state = 0;
     rc = upload_spheres(c, 0, count, spheres, count, c->stream);
     if (rc != RT_OK) {
         c->have_scene = false;          // the tables are in an unknown state
@@ -720,7 +1039,7 @@ RT_API int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
     rc = chain(c, c->stream);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    rc = launch(c, n_samples, c->stream);
+    rc = launch(c, n_samples, c->stream, true);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (out_host && c->local_rows > 0)
@@ -1032,6 +1351,59 @@ RT_API int rt_debug_read_tile_order(rt_ctx *c, uint32_t *order_out, uint32_t *co
     if (cost_out && n) HIP_TRY(hipMemcpy(cost_out, c->d_tile_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (n_tiles) *n_tiles = c->n_tiles;
     if (valid) *valid = c->order_valid ? 1 : 0;
+    return RT_OK;
+}
+// the hierarchy of large scenes: min_spheres = smallest tree that is built and used (0 = never), lds_limit = largest
+// LDS footprint it is used at (0 = keep).  Takes effect at once: the current scene's tables are rebuilt.
+static int dbg_set_bvh_lds(rt_ctx *c, int v) { if (v > 0) c->bvh_lds_limit = v; return RT_OK; }
+static int dbg_set_bvh_min(rt_ctx *c, int v) {
+    c->bvh_min = v;
+    c->bvh_pick = 0;
+    c->probe_state = 0;
+    if (!c->have_scene) return RT_OK;
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = chain(c, c->stream);
+    return rc != RT_OK ? rc : build_bvh(c, c->scene.n_spheres, c->stream);
+}
+static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
+static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
+static int dbg_set_walk_form(rt_ctx *c, int v) { c->walk_form = v; c->bvh_pick = 0; c->probe_state = 0; return RT_OK; }
+// rt_walk.inc.h: node tests per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
+// form: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = always the walk-per-call form,
+// 2 = always the walk
+RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int per_call) {
+    if (!c || steps < 0 || gate < 0 || gate > 64 || per_call < 0 || per_call > 2) return fail(RT_ERR_ARG, "steps %d, gate %d, form %d", steps, gate, per_call);
+    int rc = dbg_apply(c, dbg_set_walk_steps, steps);
+    if (rc == RT_OK) rc = dbg_apply(c, dbg_set_walk_gate, gate);
+    return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_form, per_call);
+}
+RT_API int rt_debug_bvh_pick(rt_ctx *c) {
+    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
+    if (select_device(c) == RT_OK) probe_poll(c, false);
+    return c->bvh_pick;
+}
+RT_API int rt_debug_set_bvh(rt_ctx *c, int min_spheres, int lds_limit) {
+    if (!c || min_spheres < 0 || lds_limit < 0 || lds_limit > 152 * 1024) return fail(RT_ERR_ARG, "min_spheres %d, lds_limit %d", min_spheres, lds_limit);
+    int rc = dbg_apply(c, dbg_set_bvh_lds, lds_limit);
+    return rc != RT_OK ? rc : dbg_apply(c, dbg_set_bvh_min, min_spheres);
+}
+// the blob of rt_device.h BvhTables as it lies in HBM (float4 units), and its four counts {always, leaves, nodes, slots};
+// counts of 0 = the scene has no hierarchy
+RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, uint32_t *counts4) {
+    if (!c || c->multi || !counts4) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
+    if (!c->bvh_ok) return RT_OK;
+    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.n_nodes; counts4[3] = c->bvh.n_slots;
+    const size_t need = rt::bvh_blob_float4s(c->bvh.n_nodes, c->bvh.n_slots);
+    if (blob_out) {
+        if (cap_float4 < need) return fail(RT_ERR_ARG, "blob needs %zu float4", need);
+        HIP_TRY(hipMemcpy(blob_out, c->d_bvh, need * sizeof(float4), hipMemcpyDeviceToHost));
+    }
     return RT_OK;
 }
 RT_API int rt_debug_set_coop_min(rt_ctx *c, int min_spheres) {

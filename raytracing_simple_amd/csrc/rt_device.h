@@ -34,8 +34,27 @@ struct SceneTables {
     uint32_t n_lights;
 };
 
+// Bounding-volume hierarchy over the small spheres of a large scene (rt_bvh_build_kernel in rt_api.hip;
+// traversal in rt_trace.inc.h, RT_OPT_BVH).  It only decides WHICH spheres a ray is tested against: every test
+// that is made is the reference's arithmetic, and the selection rule (smallest distance, lowest scene index among
+// equals; lowest blocking index for shadow rays) is the reference's loop order restated, so frames and counters do
+// not change.  One blob in HBM, staged into LDS by every workgroup:
+//   hdr[0] = { root box centre, half diagonal }   hdr[1] = { min |rad|, max |rad|, 1 / (2 min |rad|), - }
+//   nodes[2k], nodes[2k+1] = { lo.xyz, bits(skip | (leaf+1) << 16) }, { hi.xyz, bits(lowest scene index below) }
+//            in depth-first order: the first child of k is k+1, `skip` is the node after k's subtree
+//   slots[j] = { p, rad*rad } for j < n_always: the spheres that stay outside the tree (large or non-finite), in
+//            scene order, swept by every ray as before; then 4 per leaf, in leaf order (padded with NaN records)
+//   index[j] = scene index of slot j
+constexpr int kBvhLeaf = 8;
+struct BvhTables {
+    const float4 *blob;     // hdr | nodes | slots | index
+    uint32_t n_always, n_leaves, n_nodes, n_slots;
+};
+inline size_t bvh_blob_float4s(uint32_t n_nodes, uint32_t n_slots) { return 2 + 2 * (size_t)n_nodes + n_slots + (n_slots + 3) / 4; }
+
 struct LaunchParams {
     SceneTables scene;
+    BvhTables bvh;          // instances with RT_OPT_BVH only
     rt_camera cam;
     uint32_t *seeds;        // [2*w*h], pair per pixel at gid = y*w + x        (.cl:570-571); written at the end of a launch
     const uint32_t *seeds_in;   // read at the start of a launch: `seeds`, or the pristine default stream for the
@@ -50,6 +69,7 @@ struct LaunchParams {
     int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
     int n_tiles, tiles_x;   // persistent instances: 8x8 pixel tiles of this rank's rows, and tiles per row
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
+    int walk_steps;         // rt_walk.inc.h: node tests a lane may take per loop trip
     float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
     const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order
@@ -65,6 +85,16 @@ struct LaunchParams {
 // LDS bytes the kernels need for a scene
 inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples = 0) {
     size_t b = (size_t)n_spheres * 16 + (size_t)n_lights * 32;
+    if (mat_in_lds) b += (size_t)n_spheres * 32;
+    if (n_samples <= kMaxK2Table) b += (size_t)(n_samples > 0 ? n_samples : 0) * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+// the same for the instances that walk the hierarchy (no full geometry table; the check instance carries both)
+inline size_t lds_bytes_bvh(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples, uint32_t n_nodes,
+                            uint32_t n_slots, bool with_full_table) {
+    size_t b = bvh_blob_float4s(n_nodes, n_slots) * 16 + (size_t)n_lights * 32;
+    if (with_full_table) b += (size_t)n_spheres * 16;
     if (mat_in_lds) b += (size_t)n_spheres * 32;
     if (n_samples <= kMaxK2Table) b += (size_t)(n_samples > 0 ? n_samples : 0) * 4;
     return (b + 15) & ~(size_t)15;
@@ -86,6 +116,9 @@ constexpr int kFastPersistVariant = 4, kFastPersistCoopVariant = 5;
 constexpr int kParityTimelogVariant = 9;
 constexpr int kParityW1Variant = 10, kParityCoopW1Variant = 11;   // single-wavefront workgroups (8x8 tiles)
 constexpr int kFastW1Variant = 6, kFastCoopW1Variant = 7;
+constexpr int kParityBvhVariant = 12, kParityBvhCheckVariant = 13;  // hierarchy over the small spheres (large scenes)
+constexpr int kFastBvhVariant = 8;
+constexpr int kParityWalkVariant = 15, kFastWalkVariant = 9;       // ... with the walk as lane state (rt_walk.inc.h)
 int parity_variant_waves(int variant);   // wavefronts per workgroup of an instance: 4 (32x8 tile) or 1 (8x8 tile)
 int fast_variant_waves(int variant);
 int parity_variant_count();

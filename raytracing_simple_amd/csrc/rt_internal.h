@@ -30,6 +30,20 @@ struct rt_ctx {
     rt_sphere *d_spheres = nullptr;
     float4 *d_tables = nullptr;         // geom | emis | colr | lightA | lightB, each `scene_cap` entries
     uint32_t scene_cap = 0;
+    // hierarchy over the small spheres of a large scene (rt_device.h BvhTables), rebuilt with the tables
+    float4 *d_bvh = nullptr;            // blob, sized for scene_cap
+    rt::BvhTables bvh{};
+    bool bvh_ok = false;                // the blob describes the current scene
+    int bvh_min = 64;                   // scenes with at least this many spheres inside the tree use it (0 = never)
+    int bvh_lds_limit = 64 * 1024;      // ... while the instance's LDS stays below this
+    int walk_steps = 64, walk_gate = 16;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
+    int walk_form = 0;                  // 0 = measured choice (below); diagnostics: 1 = the walk-per-call form, 2 = the walk, unmeasured
+    // hierarchy or plain sweep?  Decided per scene by measurement: the first launch of a new scene walks the
+    // hierarchy, the second sweeps, both between events; whichever took less time per pass renders the rest
+    int bvh_pick = 0;                   // 0 = not decided yet, 1 = hierarchy, 2 = plain sweep
+    int probe_state = 0;                // probes issued (0..2)
+    int probe_samples[2] = { 0, 0 };
+    hipEvent_t probe_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     std::vector<unsigned char> is_light;   // host mirror of the light test per sphere (sizes the light list)
     std::vector<rt_sphere> h_spheres;      // host mirror of the records (an identical rt_set_scene uploads nothing)
     // heavy-first tile order (rt_trace.inc.h): per-tile cost of the last launch, and the order derived from it

@@ -1,7 +1,7 @@
 // rt_kernel_fast.hip -- fused-arithmetic instances of the path-trace kernel
 // (-ffp-contract=fast, hardware rcp/rsq/sqrt/sin/cos/exp2/log2).  Gated by PSNR >= 50 dB
 // against the parity instance at equal spp (tests/test_gpu_parity.py).
-//   [0] rt_trace_fast, [3] rt_trace_fast_coop, [6] rt_trace_fast_w1, [7] rt_trace_fast_coop_w1: shipped; the
+//   [0] rt_trace_fast, [3] rt_trace_fast_coop, [6] rt_trace_fast_w1, [7] rt_trace_fast_coop_w1, [8] rt_trace_fast_bvh: shipped; the
 //   others are A/B shapes (mode 200+k) of the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1).
 #define RT_FAST 1
 #ifndef RT_DIAGNOSTICS
@@ -48,6 +48,18 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_bvh
+#define RT_KERNEL_NAME rt_trace_fast_bvh
+#define RT_OPT_BVH 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fast_walk
+#define RT_KERNEL_NAME rt_trace_fast_walk
+#define RT_OPT_BVH 4
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS fast_persist
 #define RT_KERNEL_NAME rt_trace_fast_persist
@@ -83,6 +95,8 @@ static KernelFn const kFastKernels[] = {
 #endif
     fast_w1::rt_trace_fast_w1,                       // 6 = kFastW1Variant
     fast_coop_w1::rt_trace_fast_coop_w1,             // 7 = kFastCoopW1Variant
+    fast_bvh::rt_trace_fast_bvh,                     // 8 = kFastBvhVariant
+    fast_walk::rt_trace_fast_walk,                   // 9 = kFastWalkVariant
 };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 

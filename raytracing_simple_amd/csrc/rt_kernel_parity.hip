@@ -2,6 +2,7 @@
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
 //   [0] rt_trace_parity, [10] rt_trace_parity_w1            shipped: small scenes (4-wave / single-wave workgroups)
 //   [4] rt_trace_parity_coop, [11] rt_trace_parity_coop_w1  shipped: scenes with >= 12 spheres (cooperative any-hit)
+//   [12] rt_trace_parity_bvh                                shipped: scenes with many small spheres (hierarchy)
 //   (rt_api.hip launch() takes the single-wavefront shape while the scene tables leave LDS room for 6 waves per SIMD)
 // Everything else exists only in the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1):
 // A/B and verification shapes of the same arithmetic (mode 100+k, tools/ab_bench.py) and the
@@ -53,7 +54,37 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_bvh             /* large scenes: the small spheres in a hierarchy, walked per lane */
+#define RT_KERNEL_NAME rt_trace_parity_bvh
+#define RT_OPT_BVH 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 4
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_walk            /* ... with the walk as lane state that survives loop trips (rt_walk.inc.h) */
+#define RT_KERNEL_NAME rt_trace_parity_walk
+#define RT_OPT_BVH 4
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
+#define RT_NS parity_bvhv            /* the walk + the plain sweep beside it (verification) */
+#define RT_KERNEL_NAME rt_trace_parity_bvhv
+#define RT_OPT_BVH 2
+#define RT_OPT_LEAN_SQRT 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_bvhs            /* the walk with a census of its steps (counters[20..27]) */
+#define RT_KERNEL_NAME rt_trace_parity_bvhs
+#define RT_OPT_BVH 3
+#define RT_OPT_LEAN_SQRT 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_coopv           /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coopv
 #define RT_OPT_COOP 2
@@ -126,6 +157,14 @@ static KernelFn const kParityKernels[] = {
 #endif
     parity_w1::rt_trace_parity_w1,                      // 10 = kParityW1Variant
     parity_coop_w1::rt_trace_parity_coop_w1,            // 11 = kParityCoopW1Variant
+    parity_bvh::rt_trace_parity_bvh,                    // 12 = kParityBvhVariant
+#if RT_DIAGNOSTICS
+    parity_bvhv::rt_trace_parity_bvhv,                  // 13 = kParityBvhCheckVariant
+    parity_bvhs::rt_trace_parity_bvhs,                  // 14   census of the walk
+#else
+    nullptr, nullptr,
+#endif
+    parity_walk::rt_trace_parity_walk,                  // 15 = kParityWalkVariant
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 

@@ -21,3 +21,4 @@
 #undef RT_OPT_AB_OLD
 #undef RT_PACK_KERNEL_NAME
 #undef RT_OPT_WG_WAVES
+#undef RT_OPT_BVH

@@ -76,6 +76,15 @@
 #ifndef RT_OPT_COOP
 #define RT_OPT_COOP 0
 #endif
+// RT_OPT_BVH: large scenes.  The small spheres hang in a bounding-volume hierarchy (rt_device.h BvhTables) that
+// each lane walks for its own ray; the few large ones are swept by every ray as before.  The hierarchy only
+// selects candidates -- every candidate goes through the reference's test, and the winner is chosen by the
+// reference's rule -- so frames and counters equal the plain sweep's.  2 = check instance: the plain sweep runs
+// beside the walk and disagreements are counted (counters[20..26]); 3 = census of the walk's steps; 4 = the shipped
+// form, in which a ray's walk is lane state that survives loop trips (rt_walk.inc.h).
+#ifndef RT_OPT_BVH
+#define RT_OPT_BVH 0
+#endif
 // RT_OPT_PERSIST: persistent wavefronts.  The grid only fills the machine; each wavefront pulls
 // 8x8 pixel tiles from a global queue and hands their pixels to its lanes one by one as lanes
 // finish (wave ballot + prefix count), so no lane idles at the end of its pixel while the others
@@ -565,6 +574,165 @@ RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d
 }
 #endif
 
+#if RT_OPT_BVH
+// ---- walking the hierarchy ---------------------------------------------------------------------------
+// A sphere can only matter to a ray if the reference's test (hit_pre / hit_roots above, binary32, rounded after
+// every operation) returns a distance t for it, EPSILON < t <= t_max.  Where is X = o + t d then?  With op = fl(p - o),
+// OP = |op|, B = op.d exactly, b = B + db the computed dot product (|db| <= 3u OP, u = 2^-24), det = b^2 - OP^2 + r^2 + e
+// the computed discriminant (|e| <= 8u M^2, M^2 = OP^2 + r^2: one rounded square, a rounded three-term dot product,
+// the rounded r*r, two rounded sums), sq = sqrt(det)(1 + th), |th| <= u, and tau = b -+ sq before its own rounding:
+//     |X - p|^2 = tau^2 dd - 2 tau B + OP^2 = (sq^2 - b^2 + OP^2) + tau^2 (dd - 1) + 2 tau db
+//               = r^2 + e + 2 th det + tau^2 (dd - 1) + 2 tau db,      |tau| <= OP + |r|, tau^2 <= 2 M^2,
+// so |X - p|^2 <= r^2 + (19u + 2 |dd - 1|) M^2 <= r^2 + eps with eps := (64u + 4 |dd - 1|) M^2: X lies within
+// |r| + min(sqrt(eps), eps / 2|r|) of the centre -- inside the sphere's box grown by that `pad` -- at a ray parameter
+// in (0, t_max].  (The rounding of t itself, of p - o and of the shifted origin below move X by a few u (OP + |o|),
+// which the linear term of the pad covers eight times over.)  The walk therefore tests each node's box, grown by
+// `pad`, against the stretch [-pad, t_max + pad] of the ray, with OP bounded by the distance to the far side of the
+// root box and |r| by the largest radius in the tree; the slab arithmetic itself is made one-sided by widening its
+// results by 2^-20 relative (16 ulps against the four roundings of a slab distance and the 1-ulp v_rcp_f32).  A
+// lane whose direction is not a unit vector to within 10^-3, or not finite, gets an infinite pad: it visits
+// everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
+#if RT_OPT_BVH == 3
+struct BvhCount {                // census instance: [0] node steps of the wavefront, [1] node tests of this lane, [2]/[3] the same for leaves
+    uint32_t v[4];
+};
+#define RT_BVH_COUNT(C, k)                                                                        \
+    do {                                                                                         \
+        const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)act_) - 1)) (C).v[k] += 1u;      \
+        (C).v[(k) + 1] += 1u;                                                                    \
+    } while (0)
+#else
+struct BvhCount {};
+#define RT_BVH_COUNT(C, k)
+#endif
+struct BvhRay {
+    V3 olo, ohi, inv;      // origin shifted by +-pad; 1 / direction
+    float tback;           // how far behind the origin / beyond the current best a box still counts
+};
+RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
+    const float4 h0 = s_hdr[0], h1 = s_hdr[1];
+    const float u = 0x1p-24f, inf = __builtin_inff();
+    const float dd = d.x * d.x + d.y * d.y + d.z * d.z;
+    const V3 oc = sub(mk(h0.x, h0.y, h0.z), o);
+    const float far = (__builtin_amdgcn_sqrtf(dot(oc, oc)) + h0.w) * 1.01f;     // >= |p - o| of every sphere in the tree
+    const float skew = fabsf(dd - 1.f);
+    const float eps = (64.f * u + 4.f * skew) * (far * far + h1.y * h1.y);
+    float pad = fminf(__builtin_amdgcn_sqrtf(eps), eps * h1.z);                 // sqrt(r^2 + eps) - r, from above
+    pad = pad * 1.01f + 32.f * u * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far + h1.y);
+    float tback = pad + 1e-6f * far;
+    const bool sane = skew < 1e-3f;                                             // false for NaN
+    pad = sane ? pad : inf;
+    tback = sane ? tback : inf;
+    BvhRay R;
+    R.olo = mk(o.x + pad, o.y + pad, o.z + pad);
+    R.ohi = mk(o.x - pad, o.y - pad, o.z - pad);
+    R.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    R.tback = tback;
+    return R;
+}
+// true when the ray stretch [-tback, t_far + tback] misses the grown box for certain
+RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
+    const float x0 = (A.x - R.olo.x) * R.inv.x, x1 = (B.x - R.ohi.x) * R.inv.x;
+    const float y0 = (A.y - R.olo.y) * R.inv.y, y1 = (B.y - R.ohi.y) * R.inv.y;
+    const float z0 = (A.z - R.olo.z) * R.inv.z, z1 = (B.z - R.ohi.z) * R.inv.z;
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -R.tback));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
+    tn = __builtin_fmaf(-fabsf(tn), 0x1p-20f, tn);
+    tf = __builtin_fmaf(fabsf(tf), 0x1p-20f, tf);
+    return tn > tf;
+}
+
+// closest hit among the spheres of the tree, .cl:215-232 restated: (t, idx) only ever moves to a smaller distance
+// or, at the same distance, to a lower scene index -- what the reference's `d < t` in index order ends with.
+RT_DEV void bvh_closest(const float4 *s_nodes, const float4 *s_slots, const uint32_t *s_index, uint32_t n_nodes,
+                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, float &t, uint32_t &slot, uint32_t &idx, BvhCount &cnt) {
+    uint32_t node = 0;
+    uint32_t guard = 2u * n_nodes + 8u;             // (a well-formed tree needs at most n_nodes trips)
+    while (node < n_nodes && guard != 0u) {
+        uint32_t leaf = 0xffffffffu;
+        bool more;
+        do {                                        // branch-free per step: one LDS round trip, selects
+            guard -= 1u;
+            RT_BVH_COUNT(cnt, 0);
+            const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
+            const uint32_t link = __float_as_uint(A.w);
+            const uint32_t next = max(link & 0xffffu, node + 1u);
+            const bool miss = bvh_misses(R, A, B, t);
+            const bool is_leaf = (link >> 16) != 0u;
+            const bool take = !miss & is_leaf;
+            leaf = take ? (link >> 16) - 1u : leaf;
+            node = (miss | is_leaf) ? next : node + 1u;
+            more = !take & (node < n_nodes) & (guard != 0u);
+        } while (more);
+        if (leaf != 0xffffffffu) {
+            RT_BVH_COUNT(cnt, 2);
+            const uint32_t s = n_always + (uint32_t)kBvhLeaf * leaf;
+            HitPre p[kBvhLeaf];
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[s + k], o, d);
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) {
+                if (p[k].det >= 0.f) {
+                    const HitRoots h = hit_roots(p[k]);
+                    if (h.hit && h.t <= t) {
+                        const uint32_t ix = s_index[s + k];
+                        if (h.t < t || ix < idx) {
+                            t = h.t;
+                            slot = s + (uint32_t)k;
+                            idx = ix;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// lowest scene index of a sphere of the tree that blocks the shadow ray (.cl:234-247 stops at the first blocker in
+// scene order), given the lowest one found so far (`first`, n = none): subtrees that only hold higher indices are skipped
+RT_DEV uint32_t bvh_any(const float4 *s_nodes, const float4 *s_slots, const uint32_t *s_index, uint32_t n_nodes,
+                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, float max_t, uint32_t first, BvhCount &cnt) {
+    uint32_t node = 0;
+    uint32_t guard = 2u * n_nodes + 8u;
+    while (node < n_nodes && guard != 0u) {
+        uint32_t leaf = 0xffffffffu;
+        bool more;
+        do {
+            guard -= 1u;
+            RT_BVH_COUNT(cnt, 0);
+            const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
+            const uint32_t link = __float_as_uint(A.w);
+            const uint32_t next = max(link & 0xffffu, node + 1u);
+            const bool miss = (__float_as_uint(B.w) > first) | bvh_misses(R, A, B, max_t);
+            const bool is_leaf = (link >> 16) != 0u;
+            const bool take = !miss & is_leaf;
+            leaf = take ? (link >> 16) - 1u : leaf;
+            node = (miss | is_leaf) ? next : node + 1u;
+            more = !take & (node < n_nodes) & (guard != 0u);
+        } while (more);
+        if (leaf != 0xffffffffu) {
+            RT_BVH_COUNT(cnt, 2);
+            const uint32_t s = n_always + (uint32_t)kBvhLeaf * leaf;
+            HitPre p[kBvhLeaf];
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[s + k], o, d);
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) {
+                if (p[k].det >= 0.f) {
+                    const HitRoots h = hit_roots(p[k]);
+                    if (h.hit && h.t < max_t) {
+                        const uint32_t ix = s_index[s + k];
+                        first = ix < first ? ix : first;
+                    }
+                }
+            }
+        }
+    }
+    return first;
+}
+#endif  // RT_OPT_BVH
+
 // .cl:34
 RT_DEV int to_int(float v) {
     float c = fminf(fmaxf(v, 0.f), 1.f);
@@ -585,6 +753,9 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 #ifndef RT_OPT_MINWAVES
 #define RT_OPT_MINWAVES 1
 #endif
+#if RT_OPT_BVH == 4
+#include "rt_walk.inc.h"       // large scenes: the walk as lane state (its own kernel body)
+#else
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;      // (shadow the 4-wavefront constants of rt_device.h)
     constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
@@ -592,8 +763,27 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
+#if RT_OPT_BVH
+#if RT_OPT_COOP || RT_OPT_PERSIST
+#error "the hierarchy instances are plain (no cooperative any-hit, no persistent wavefronts)"
+#endif
+    // the blob of rt_device.h BvhTables, copied as it lies: hdr | nodes | slots | index
+    const uint32_t n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
+    float4 *s_hdr = lds;
+    float4 *s_nodes = s_hdr + 2;
+    float4 *s_slots = s_nodes + 2 * n_nodes;
+    uint32_t *s_index = reinterpret_cast<uint32_t *>(s_slots + n_slots);
+    const uint32_t blob_n = 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
+#if RT_OPT_BVH == 2
+    float4 *s_geom = lds + blob_n;           // check instance: the full table beside it
+    float4 *s_lightA = s_geom + n;
+#else
+    float4 *s_lightA = lds + blob_n;
+#endif
+#else
     float4 *s_geom = lds;
     float4 *s_lightA = s_geom + n;           // {centre, radius}
+#endif
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;             // {colour, radius}
@@ -608,7 +798,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     (void)s_tile_cost;
     if (tid < 5) s_stat[tid] = 0;
     if (tid == 5) s_tile_cost = 0u;
+#if RT_OPT_BVH
+    for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
+#endif
+#if RT_OPT_BVH == 0 || RT_OPT_BVH == 2
     for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
+#endif
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
         s_lightA[i] = P.scene.lightA[i];
         s_lightB[i] = P.scene.lightB[i];
@@ -707,6 +902,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     bool after_specular = true;
     bool need_ray = true;
 
+#if RT_OPT_BVH
+    BvhCount cnt_c{}, cnt_s{};                           // census instance only
+    (void)cnt_c;
+    (void)cnt_s;
+#endif
     unsigned long long st_roots_c = 0, st_roots_s = 0;   // wave-uniform; dead unless RT_OPT_STAMPS
     (void)st_roots_s;
 #if RT_OPT_COOP
@@ -843,7 +1043,33 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         uint32_t id = 0;
         RT_STAMP(1);
         st_roots_c = 0;
+#if RT_OPT_BVH
+        // the large spheres as before, then the tree; `slot` is where the winner's record lies, `id` its scene index
+        uint32_t slot = 0;
+        sweep_closest(s_slots, n_always, o, d, t, slot, st_roots_c);
+        id = (t < 1e20f) ? s_index[slot] : 0xffffffffu;
+        {
+            const BvhRay R = bvh_ray(s_hdr, o, d);
+            bvh_closest(s_nodes, s_slots, s_index, n_nodes, n_always, o, d, R, t, slot, id, cnt_c);
+        }
+#if RT_OPT_BVH == 2
+        {
+            float t_ref = 1e20f;
+            uint32_t id_ref = 0;
+            unsigned long long dummy = 0;
+            sweep_closest(s_geom, n, o, d, t_ref, id_ref, dummy);
+            atomicAdd(&P.counters[20], 1ull);
+            const bool hit_ref = t_ref < 1e20f, hit_bvh = t < 1e20f;
+            if (hit_ref != hit_bvh || (hit_ref && (__float_as_uint(t_ref) != __float_as_uint(t) || id_ref != id))) {
+                atomicAdd(&P.counters[21], 1ull);
+                P.counters[22] = ((unsigned long long)id << 32) | id_ref;
+                P.counters[23] = ((unsigned long long)__float_as_uint(t) << 32) | __float_as_uint(t_ref);
+            }
+        }
+#endif
+#else
         sweep_closest(s_geom, n, o, d, t, id, st_roots_c);
+#endif
         RT_STAMP_ROOTS(10, st_roots_c);
         c_closest += 1;
 
@@ -857,7 +1083,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             path_done = true;                                              // miss, .cl:327-330
         } else {
             RT_STAMP(2);
+#if RT_OPT_BVH
+            const float4 ge = s_slots[slot];
+#else
             const float4 ge = s_geom[id];
+#endif
             float4 em4, co4;
             if (P.mat_in_lds) {                 // wave-uniform: ds_read / global_load, not flat_load
                 em4 = s_emis[id];
@@ -952,7 +1182,27 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 c_shadow += 1;
                 RT_STAMP(4);
                 st_roots_s = 0;
+#if RT_OPT_BVH
+                const uint32_t first_large = sweep_any(s_slots, n_always, hp, sd, len - RT_EPS, st_roots_s);
+                uint32_t first = first_large < n_always ? s_index[first_large] : n;
+                {
+                    const BvhRay R = bvh_ray(s_hdr, hp, sd);
+                    first = bvh_any(s_nodes, s_slots, s_index, n_nodes, n_always, hp, sd, R, len - RT_EPS, first, cnt_s);
+                }
+#if RT_OPT_BVH == 2
+                {
+                    unsigned long long dummy = 0;
+                    const uint32_t first_ref = sweep_any(s_geom, n, hp, sd, len - RT_EPS, dummy);
+                    atomicAdd(&P.counters[24], 1ull);
+                    if (first_ref != first) {
+                        atomicAdd(&P.counters[25], 1ull);
+                        P.counters[26] = ((unsigned long long)first << 32) | first_ref;
+                    }
+                }
+#endif
+#else
                 const uint32_t first = sweep_any(s_geom, n, hp, sd, len - RT_EPS, st_roots_s);
+#endif
                 RT_STAMP_ROOTS(11, st_roots_s);
                 const bool blocked = first < n;
                 c_tests += blocked ? first + 1 : n;
@@ -1132,6 +1382,15 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     __syncthreads();
     if (tid < 12) atomicAdd(&P.counters[8 + tid], s_census[tid]);
 #endif
+#if RT_OPT_BVH == 3
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t a = wave_sum(cnt_c.v[k]), b = wave_sum(cnt_s.v[k]);
+        if (lane == 0) {
+            atomicAdd(&P.counters[20 + k], (unsigned long long)a);
+            atomicAdd(&P.counters[24 + k], (unsigned long long)b);
+        }
+    }
+#endif
 #if RT_OPT_TIMELOG
     {
         const unsigned long long tl_end = __builtin_amdgcn_s_memrealtime();
@@ -1148,6 +1407,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 #endif
 }
+#endif   // RT_OPT_BVH != 4
 
 #if !defined(RT_VARIANT_KERNEL)
 // The packed frame from the colour plane (.cl:34,594-596) with this mode's toInt, for frames whose

@@ -1,0 +1,383 @@
+// rt_walk.inc.h -- the path-trace kernel for large scenes (RT_OPT_BVH == 4), included by rt_trace.inc.h in
+// place of its own kernel body; everything above it there (vector helpers, RNG, the sphere test, the sweeps,
+// sample_light, the hierarchy walk's ray set-up and slab test) is shared.
+//
+// Same mapping (one lane = one pixel, the spp loop and the path state in registers), same arithmetic, same
+// order of random draws per pixel -- but the lanes of a wavefront are decoupled once more.  A census of the
+// walk-per-call form (RT_OPT_BVH 1: every lane walks the hierarchy to the end inside its closest-hit / shadow
+// call) showed 13 of 64 lanes busy per node step on closest-hit rays and 6 of 64 on shadow rays: a ray takes 28 /
+// 38 node tests on average (1024 spheres), the slowest of a wavefront's rays five times that, and everybody
+// waits for it.  Here a ray's walk is lane state (node, bound, best so far) that survives loop trips:
+//
+//   T  every lane with a walk in flight takes up to P.walk_steps node tests (closest-hit and shadow rays run the
+//      same loop; they differ in how a candidate updates the state);
+//   S  lanes whose walk has ended (or that have no ray) do what comes next for them -- process the hit, sample
+//      the next light and start its shadow ray, add the light's contribution, bounce, finish the sample, start
+//      a camera ray -- once P.regen_gate of them are waiting or nobody is walking, and then join T again.
+//
+// So the walk runs with nearly all lanes busy, at the price of running the shading sections for the part of
+// the wavefront that is ready.  Nothing here depends on which trip a lane does what: per pixel the sequence of
+// operations and random draws is the reference's.
+
+extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
+    constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
+    constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
+    extern __shared__ float4 lds[];
+    const uint32_t n = P.scene.n_spheres;
+    const uint32_t n_lights = P.scene.n_lights;
+    // the blob of rt_device.h BvhTables, copied as it lies: hdr | nodes | slots | index
+    const uint32_t n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
+    float4 *s_hdr = lds;
+    float4 *s_nodes = s_hdr + 2;
+    float4 *s_slots = s_nodes + 2 * n_nodes;
+    uint32_t *s_index = reinterpret_cast<uint32_t *>(s_slots + n_slots);
+    const uint32_t blob_n = 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
+    float4 *s_lightA = lds + blob_n;              // {centre, radius}
+    float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
+    float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
+    float4 *s_colr = s_emis + n;                  // {colour, radius}
+    float *s_k2 = reinterpret_cast<float *>(P.mat_in_lds ? s_colr + n : s_emis);
+    const bool k2_in_lds = P.n_samples <= kMaxK2Table;
+
+    const int tid = threadIdx.x;
+    __shared__ unsigned long long s_stat[5];
+    __shared__ unsigned s_tile_cost;
+    if (tid < 5) s_stat[tid] = 0;
+    if (tid == 5) s_tile_cost = 0u;
+    for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
+    for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
+        s_lightA[i] = P.scene.lightA[i];
+        s_lightB[i] = P.scene.lightB[i];
+    }
+    if (P.mat_in_lds) {
+        for (uint32_t i = tid; i < n; i += kBlockThreads) {
+            s_emis[i] = P.scene.emis[i];
+            s_colr[i] = P.scene.colr[i];
+        }
+    }
+    if (k2_in_lds)
+        for (int i = tid; i < P.n_samples; i += kBlockThreads) s_k2[i] = rt_rcp((float)(P.first_sample + i) + 1.f);
+    __syncthreads();
+
+    // ---- pixel of this lane (as in rt_trace.inc.h) ------------------------------------------
+    const int wave = tid >> 6, lane = tid & 63;
+    const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;
+    const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
+    __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
+    if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
+    const int x = tile_bx * kTileW + wave * 8 + (lane & 7);
+    const int lrow = tile_by * kTileH + (lane >> 3);
+    const int rtile = lrow / P.tile_rows;
+    const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
+    const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
+
+    uint32_t s0 = 0, s1 = 0;
+    V3 acc = mk(0.f, 0.f, 0.f);
+    int s = P.first_sample;
+    const int s_end = valid ? P.first_sample + P.n_samples : P.first_sample;
+    if (valid) {
+        const size_t gid = (size_t)y * (size_t)P.w + (size_t)x;             // .cl:560-563
+        const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;  // .cl:579
+        const uint2 sd = *reinterpret_cast<const uint2 *>(P.seeds_in + 2 * gid);
+        s0 = sd.x;
+        s1 = sd.y;
+        if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
+    }
+    const float inv_w = P.inv_w, inv_h = P.inv_h;
+    const V3 cam_o = mk(P.cam.orig.x, P.cam.orig.y, P.cam.orig.z);
+    const V3 cam_d = mk(P.cam.dir.x, P.cam.dir.y, P.cam.dir.z);
+    const V3 cam_x = mk(P.cam.x.x, P.cam.x.y, P.cam.x.z);
+    const V3 cam_y = mk(P.cam.y.x, P.cam.y.y, P.cam.y.z);
+
+    uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
+    unsigned long long c_tests = 0;
+
+    // ---- lane state ---------------------------------------------------------------------------
+    enum { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3 };
+    int st = kNew;
+    V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);     // the ray in flight: the path's, or the shadow ray (o = hit point)
+    V3 thr = mk(1.f, 1.f, 1.f), rad = mk(0.f, 0.f, 0.f);
+    int depth = 0;
+    bool after_specular = true;
+    // the walk: next node, distance bound, best sphere so far (scene index and slot)
+    uint32_t node = n_nodes, w_idx = 0xffffffffu, w_slot = 0;
+    float w_far = 0.f;
+    BvhRay R = bvh_ray(s_hdr, o, d);
+    // a diffuse hit being lit: its normal, the light sum, the light in flight and what it adds if unblocked
+    V3 nl = mk(0.f, 0.f, 1.f), ld = mk(0.f, 0.f, 0.f);
+    uint32_t lj = 0;
+    float l_k = 0.f;
+    unsigned long long unused_roots = 0;
+
+    for (;;) {
+        if (st == kNew && s >= s_end) break;
+
+        // ---- T: walk ----
+        if (node < n_nodes) {
+            int budget = P.walk_steps;
+            const bool shadow = st == kShadow;
+            while (node < n_nodes && budget > 0) {
+                // node tests until a leaf's box is hit (branch-free per step: one LDS round trip, selects)
+                uint32_t leaf = 0xffffffffu;
+                bool more;
+                do {
+                    budget -= 1;
+                    const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
+                    const uint32_t link = __float_as_uint(A.w);
+                    const uint32_t next = max(link & 0xffffu, node + 1u);          // (forward, whatever the table says)
+                    const bool prune = shadow & (__float_as_uint(B.w) > w_idx);     // only higher scene indices below
+                    const bool miss = prune | bvh_misses(R, A, B, w_far);
+                    const bool is_leaf = (link >> 16) != 0u;
+                    const bool take = !miss & is_leaf;
+                    leaf = take ? (link >> 16) - 1u : leaf;
+                    node = (miss | is_leaf) ? next : node + 1u;
+                    more = !take & (node < n_nodes) & (budget > 0);
+                } while (more);
+                if (leaf != 0xffffffffu) {
+                    const uint32_t sl = n_always + (uint32_t)kBvhLeaf * leaf;
+                    HitPre p[kBvhLeaf];
+#pragma unroll
+                    for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
+#pragma unroll
+                    for (int k = 0; k < kBvhLeaf; ++k) {
+                        if (p[k].det >= 0.f) {
+                            const HitRoots hr = hit_roots(p[k]);
+                            // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
+                            // shadow ray (.cl:234-247): the lowest scene index that blocks
+                            if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
+                                const uint32_t ix = s_index[sl + k];
+                                if (shadow) {
+                                    w_idx = ix < w_idx ? ix : w_idx;
+                                } else if (hr.t < w_far || ix < w_idx) {
+                                    w_far = hr.t;
+                                    w_slot = sl + (uint32_t)k;
+                                    w_idx = ix;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- S: lanes whose walk has ended, once enough of them wait ----
+        const bool ready = node >= n_nodes;
+        const unsigned long long br = __builtin_amdgcn_ballot_w64(ready);
+        const unsigned long long bw = __builtin_amdgcn_ballot_w64(!ready);
+        const bool go = (__popcll(br) >= P.regen_gate) || (bw == 0ull);
+        if (ready && go) {
+            bool path_done = false;
+            bool start_closest = false;
+            if (st == kShadow) {
+                // ---- the shadow ray of light lj - 1 has its answer, .cl:297-301 ----
+                const bool blocked = w_idx < n;
+                c_tests += blocked ? w_idx + 1u : n;
+                if (!blocked) {
+                    const float4 lb = s_lightB[lj - 1u];
+                    ld = add(ld, scale(mk(lb.x, lb.y, lb.z), l_k));
+                }
+                st = kLights;
+            } else if (st == kClosest) {
+                c_closest += 1;
+                if (!(w_far < 1e20f)) {
+                    path_done = true;                                              // miss, .cl:327-330
+                } else {
+                    const float4 ge = s_slots[w_slot];
+                    const uint32_t id = w_idx;
+                    float4 em4, co4;
+                    if (P.mat_in_lds) {
+                        em4 = s_emis[id];
+                        co4 = s_colr[id];
+                        asm volatile("; materials from LDS" : "+v"(em4.x));
+                    } else {
+                        em4 = P.scene.emis[id];
+                        co4 = P.scene.colr[id];
+                    }
+                    const V3 em = mk(em4.x, em4.y, em4.z);
+                    const V3 col = mk(co4.x, co4.y, co4.z);
+                    const int refl = __float_as_int(em4.w);
+                    const V3 hp = add(o, scale(d, w_far));                         // .cl:338-340
+                    const V3 nrm = unit(sub(hp, mk(ge.x, ge.y, ge.z)));            // .cl:345-347
+                    const float dp = dot(nrm, d);
+                    nl = scale(nrm, -1.f * cl_sign(dp));                           // .cl:354-355
+                    if (!((em.x == 0.f) && (em.z == 0.f))) {                       // .cl:358-368
+                        if (after_specular) rad = add(rad, mul(thr, scale(em, fabsf(dp))));
+                        path_done = true;
+                    } else if (refl == RT_DIFF) {                                  // .cl:370-373
+                        after_specular = false;
+                        thr = mul(thr, col);
+                        o = hp;
+                        ld = mk(0.f, 0.f, 0.f);
+                        lj = 0;
+                        st = kLights;
+                    } else {
+                        // mirror / glass, .cl:413-489 (as in rt_trace.inc.h)
+                        const V3 rfl = sub(d, scale(nrm, 2.f * dp));
+                        after_specular = true;
+                        if (refl == RT_SPEC) {
+                            thr = mul(thr, col);
+                            d = rfl;
+                        } else {
+                            const bool into = dp < 0.f;
+                            const float ddn = -fabsf(dp);
+                            const float nc = 1.f, nt = 1.52f;
+                            float nnt = into ? nc / nt : nt / nc;
+                            float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
+                            if (cos2t < 0.f) {
+                                thr = mul(thr, col);
+                                d = rfl;
+                            } else {
+                                float kk = (into ? 1.f : -1.f) * (ddn * nnt + rt_sqrt(cos2t));
+                                V3 td = unit(sub(scale(d, nnt), scale(nrm, kk)));
+                                const float fa = nt - nc, fb = nt + nc;
+                                const float R0 = fa * fa / (fb * fb);
+                                float c = 1 - (into ? -ddn : dot(td, nrm));
+                                float Re = R0 + (1 - R0) * c * c * c * c * c;
+                                float Tr = 1.f - Re;
+                                float Pr = .25f + .5f * Re;
+                                float pick = next_random(s0, s1);
+                                c_draws += 1;
+                                const bool take_rfl = pick < Pr;
+                                const float wgt = rt_div(take_rfl ? Re : Tr, take_rfl ? Pr : 1.f - Pr);
+                                thr = mul(scale(thr, wgt), col);
+                                d = take_rfl ? rfl : td;
+                            }
+                        }
+                        o = hp;
+                        depth += 1;
+                        if (depth >= kMaxDepth) path_done = true;                  // .cl:320
+                        else start_closest = true;
+                    }
+                }
+            }
+            // ---- next-event estimation, .cl:249-303: the lights one by one, each with its two draws ----
+            while (st == kLights) {
+                if (lj == n_lights) {
+                    rad = add(rad, mul(thr, ld));                                  // .cl:377-378
+                    // cosine-weighted bounce, .cl:383-411
+                    float u = next_random(s0, s1);
+                    float r2 = next_random(s0, s1);
+                    c_draws += 2;
+                    float r2s = rt_sqrt_unit(r2);
+                    V3 w = nl;
+                    V3 a = (fabsf(w.x) > .1f) ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
+                    V3 uu = unit(cross(a, w));
+                    V3 vv = cross(w, uu);
+                    float s1v, c1v;
+#if RT_FAST
+                    fm_sincos_turns(u, s1v, c1v);
+#else
+                    dm_sincosf_pos((2.f * RT_PI) * u, s1v, c1v);
+#endif
+                    V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
+                    nd = add(nd, scale(w, rt_sqrt_unit(1 - r2)));
+                    d = nd;
+                    depth += 1;
+                    st = kNew;                                                     // (leaves the light loop)
+                    if (depth >= kMaxDepth) path_done = true;
+                    else start_closest = true;
+                    break;
+                }
+                const float4 lb = s_lightB[lj];
+                V3 sd;
+                float len, numer;
+                const bool want = sample_light(s_lightA[lj], lb, s0, s1, c_draws, o, nl, sd, len, numer);
+                lj += 1u;
+                if (want) {
+                    // ---- shadow ray, any hit, .cl:234-247: the large spheres now, the tree in the trips to come ----
+                    c_shadow += 1;
+                    l_k = rt_div(numer, len * len);                                // .cl:297 (used only if nothing blocks)
+                    d = sd;
+                    w_far = len - RT_EPS;
+                    const uint32_t first_large = sweep_any(s_slots, n_always, o, d, w_far, unused_roots);
+                    w_idx = first_large < n_always ? s_index[first_large] : n;
+                    R = bvh_ray(s_hdr, o, d);
+                    node = 0;
+                    st = kShadow;
+                }
+            }
+            if (path_done) {
+                // ---- running average, .cl:580-589 ----
+                if (s == 0) {
+                    acc = rad;
+                } else {
+                    float k1 = (float)s;
+                    float k2 = k2_in_lds ? s_k2[s - P.first_sample] : rt_rcp((float)s + 1.f);
+                    acc = mk((acc.x * k1 + rad.x) * k2, (acc.y * k1 + rad.y) * k2, (acc.z * k1 + rad.z) * k2);
+                }
+                s += 1;
+                st = kNew;
+                start_closest = false;
+            }
+            if (st == kNew && !start_closest && s < s_end) {
+                // ---- camera ray, .cl:494-549 ----
+                float j1 = next_random_centred(s0, s1);
+                float j2 = next_random_centred(s0, s1);
+                c_draws += 2;
+                float kcx = ((float)x + j1) * inv_w - 0.5f;
+                float kcy = ((float)y + j2) * inv_h - 0.5f;
+                V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
+                           cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
+                o = add(scale(rd, 0.1f), cam_o);
+                d = unit(rd);
+                thr = mk(1.f, 1.f, 1.f);
+                rad = mk(0.f, 0.f, 0.f);
+                depth = 0;
+                after_specular = true;
+                start_closest = true;
+            }
+            if (start_closest) {
+                // ---- closest hit, .cl:215-232: the large spheres now, the tree in the trips to come ----
+                float t = 1e20f;
+                uint32_t slot = 0;
+                sweep_closest(s_slots, n_always, o, d, t, slot, unused_roots);
+                w_far = t;
+                w_slot = slot;
+                w_idx = (t < 1e20f) ? s_index[slot] : 0xffffffffu;
+                R = bvh_ray(s_hdr, o, d);
+                node = 0;
+                st = kClosest;
+            }
+        }
+    }
+
+    // ---- epilogue: as in rt_trace.inc.h ----
+    const __attribute__((address_space(4))) LaunchParams *qp =
+        (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; epilogue arguments re-read" : "+s"(qp));
+    const __attribute__((address_space(4))) LaunchParams &Q = *qp;
+    if (valid && Q.n_samples > 0) {
+        int xe = x, ye = y, le = lrow;
+        asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
+        const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;
+        const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;
+        float *colors = Q.colors;
+        colors[3 * ci] = acc.x;
+        colors[3 * ci + 1] = acc.y;
+        colors[3 * ci + 2] = acc.z;
+        if (!Q.skip_pixels)
+            Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =
+                (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+        *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);
+    }
+    uint32_t n_done = valid ? (uint32_t)Q.n_samples : 0u;
+    uint32_t t_samples = wave_sum(n_done);
+    uint32_t t_closest = wave_sum(c_closest);
+    uint32_t t_shadow = wave_sum(c_shadow);
+    uint32_t t_draws = wave_sum(c_draws);
+    unsigned long long tests64 = c_tests + (unsigned long long)c_closest * n;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
+    if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wave_t0[wave]));
+    if (lane == 0) {
+        atomicAdd(&s_stat[0], (unsigned long long)t_samples);
+        atomicAdd(&s_stat[1], (unsigned long long)t_closest);
+        atomicAdd(&s_stat[2], (unsigned long long)t_shadow);
+        atomicAdd(&s_stat[3], tests64);
+        atomicAdd(&s_stat[4], (unsigned long long)t_draws);
+    }
+    __syncthreads();
+    if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
+    if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
+}

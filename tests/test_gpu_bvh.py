@@ -1,0 +1,173 @@
+"""Large scenes: the hierarchy over the small spheres (csrc/rt_device.h BvhTables, rt_walk.inc.h).  It only selects
+which spheres a ray is tested against, so everything must stay BIT-EXACT: frames, colour plane, seeds and the work
+counters against the oracle, with the hierarchy forced on small and adversarial scenes too."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from raytracing_simple_amd import api, host, scenes
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import bvh_check  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(sph, cam, w, h, spp, bvh_min=1, form=2, mode=api.RT_MODE_PARITY, passes=None):
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_mode(mode)
+        px = None
+        for n in (passes or [spp]):
+            px = ctx.render_pass(n)
+        return {"pixels": px, "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats(),
+                "pick": ctx._lib.rt_debug_bvh_pick(ctx._h)}
+
+
+def _same(got, want):
+    assert np.array_equal(got["pixels"], want["pixels"])
+    assert np.array_equal(got["colors"].view(np.uint32), want["colors"].view(np.uint32))
+    assert np.array_equal(got["seeds"], want["seeds"])
+    g, o = got["stats"], want["stats"]
+    assert (g["samples"], g["closest_rays"], g["shadow_rays"], g["sphere_tests"], g["rng_draws"]) == \
+           (o["samples"], o["closest_calls"], o["shadow_calls"], o["sphere_tests"], o["rng_draws"])
+
+
+@pytest.mark.parametrize("maker", [lambda: scenes.random_spheres(1024), lambda: scenes.random_spheres(97),
+                                   lambda: scenes.mirror_box(64), lambda: scenes.demo_plus(16),
+                                   lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET)])
+def test_device_built_tables_are_a_valid_hierarchy(maker):
+    sph, _, _ = maker()
+    sph = api.as_spheres(sph)
+    with api.RtContext(64, 64, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+        ctx.set_scene(sph)
+        b = bvh_check.read_bvh(ctx)
+    assert b is not None
+    assert bvh_check.check_structure(sph, b) == []
+    assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(sph)
+
+
+@pytest.mark.parametrize("maker,w,h,spp", [
+    (lambda: scenes.random_spheres(1024), 96, 64, 3),
+    (lambda: scenes.random_spheres(300), 80, 60, 4),
+    (lambda: scenes.mirror_box(64), 64, 64, 4),
+    (lambda: scenes.mirror_box(200), 48, 48, 3),
+    (lambda: scenes.demo_plus(16), 96, 64, 4),
+])
+def test_both_forms_of_the_walk_equal_the_oracle(maker, w, h, spp):
+    sph, orig, target = maker()
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    for form in (1, 2):
+        _same(_render(sph, cam, w, h, spp, form=form), want)
+
+
+def test_walk_and_plain_sweep_agree_ray_by_ray():
+    """The check instance runs the plain sweep beside the walk for every ray and counts disagreements
+    (closest hit: distance bits and sphere index; shadow rays: first blocking index)."""
+    for maker, (w, h, spp) in ((lambda: scenes.random_spheres(1024), (128, 72, 3)), (lambda: scenes.mirror_box(96), (96, 64, 4))):
+        sph, orig, target = maker()
+        r = bvh_check.agreement(sph, host.compute_camera(orig, target, w, h), w, h, spp)
+        assert r is not None and r["closest_rays"] > 0 and r["shadow_rays"] > 0
+        assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
+
+
+def _adversarial(seed):
+    """Duplicated spheres (the reference's loader doubles them: exact ties), zero and negative radii, concentric and
+    heavily overlapping spheres, a camera inside a glass sphere, non-finite records, a far-away cluster."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([40, 70, 130]))
+    sph = np.zeros(n, api.SPHERE_DT)
+    sph["rad"] = rng.uniform(0.5, 6.0, n).astype(np.float32)
+    sph["p"] = rng.uniform(-30, 30, (n, 3)).astype(np.float32)
+    sph["c"] = rng.uniform(0.1, 0.95, (n, 3)).astype(np.float32)
+    sph["refl"] = rng.integers(0, 3, n)
+    sph["rad"][0], sph["p"][0], sph["refl"][0] = 1000.0, (0, -1030, 0), 0          # ground
+    sph["rad"][1], sph["p"][1], sph["e"][1] = 8.0, (0, 45, 0), (10, 10, 10)         # light
+    half = n // 2
+    dup = rng.integers(2, half, 8)
+    sph[half:half + 8] = sph[dup]                                                   # exact duplicates, higher index
+    sph["rad"][half + 8] = 0.0
+    sph["rad"][half + 9] = -3.0                                                      # rad*rad is what the test uses
+    sph["p"][half + 10] = sph["p"][half + 11]                                        # concentric
+    sph["rad"][half + 12] = np.float32("nan")
+    sph["p"][half + 13, 1] = np.float32("inf")
+    sph["p"][half + 14] = (4000.0, 10.0, -3000.0)                                    # far-away member of the tree
+    orig = (float(sph["p"][3, 0]), float(sph["p"][3, 1]), float(sph["p"][3, 2]) + 0.5) if seed % 2 else (10.0, 30.0, 70.0)
+    if seed % 2:
+        sph["refl"][3], sph["rad"][3] = 2, 5.0                                       # the camera sits inside glass
+    return sph, orig, (0.0, 5.0, 0.0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
+    sph, orig, target = _adversarial(seed)
+    w, h, spp = 72, 48, 3
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    _same(_render(sph, cam, w, h, spp, form=2), want)
+    r = bvh_check.agreement(sph, cam, w, h, spp)
+    assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
+
+
+def test_measured_choice_changes_no_bit_and_probes_split_a_blocking_call():
+    """form 0 = the library's behaviour: the first pass of a new scene walks the hierarchy, the second sweeps, the
+    faster form renders the rest.  Whatever it picks, and however the passes are split, the frame is the oracle's."""
+    sph, orig, target = scenes.random_spheres(200)
+    w, h, spp = 96, 64, 20
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    one = _render(sph, cam, w, h, spp, bvh_min=64, form=0)
+    _same(one, want)
+    assert one["pick"] in (1, 2)                     # a blocking call of >= 16 passes waits for the verdict
+    assert one["stats"]["launches"] == 3             # probe, probe, the rest
+    many = _render(sph, cam, w, h, spp, bvh_min=64, form=0, passes=[1, 1, 5, 13])
+    _same(many, want)
+    small = _render(*((lambda s: (s[0], host.compute_camera(s[1], s[2], w, h)))(scenes.demo_plus(16))), w, h, 4, bvh_min=64, form=0)
+    assert small["pick"] == 0 and small["stats"]["launches"] == 1      # no hierarchy below bvh_min: nothing to measure
+
+
+def test_moving_spheres_rebuild_the_hierarchy_on_the_stream():
+    sph, orig, target = scenes.random_spheres(160)
+    sph = api.as_spheres(sph).copy()
+    w, h, spp = 80, 48, 3
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 2))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        for step in range(3):
+            sph["p"][10:40, 0] += np.float32(1.5)
+            sph["p"][10:40, 1] += np.float32(0.25 * step)
+            ctx.update_spheres(10, sph[10:40])
+            ctx.reset()
+            got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            _same(got, O.render(sph, cam, w, h, spp))
+            b = bvh_check.read_bvh(ctx)
+            assert bvh_check.check_structure(sph, b) == []
+
+
+def test_fast_mode_with_the_hierarchy_is_as_close_as_fast_mode_without():
+    """Fused arithmetic changes single bounces, and on a scene with mirrors and glass a changed bounce changes a path:
+    fast mode's distance from parity mode is a property of the scene (the 50 dB gate is quoted on the Demo scene).
+    With the hierarchy it must be what it is with the plain sweep."""
+    sph, orig, target = scenes.random_spheres(400)
+    w, h, spp = 160, 96, 16
+    cam = host.compute_camera(orig, target, w, h)
+    par = _render(sph, cam, w, h, spp, form=2)
+    plain = _render(sph, cam, w, h, spp, bvh_min=0, mode=api.RT_MODE_FAST)
+    base = host.psnr(plain["pixels"], par["pixels"])
+    assert base >= 30.0
+    for form in (1, 2):
+        fast = _render(sph, cam, w, h, spp, form=form, mode=api.RT_MODE_FAST)
+        assert fast["stats"]["samples"] == par["stats"]["samples"]
+        assert host.psnr(fast["pixels"], par["pixels"]) >= min(50.0, base - 3.0)

@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""The hierarchy of large scenes (csrc/rt_device.h BvhTables), checked three ways on the GPU:
+
+  structure   the tables the device built, read back and walked on the host: every node's skip link
+              points forward, the leaves hold every tree sphere exactly once, every sphere lies inside
+              the boxes of its leaf and of all its ancestors, every node knows the lowest scene index
+              below it, the always list keeps scene order
+  agreement   the check instance (mode 113) renders with the walk AND the plain sweep per ray and counts
+              the rays on which they differ (closest hit: distance bits and sphere; shadow: first blocker)
+  parity      the shipped instance against the oracle, and timing with the hierarchy on / off
+
+    python tools/bvh_check.py [--quick]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from raytracing_simple_amd import api, host, scenes  # noqa: E402
+
+
+def read_bvh(ctx):
+    counts = (C.c_uint32 * 4)()
+    ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, None, 0, counts))
+    n_always, n_leaves, n_nodes, n_slots = list(counts)
+    if n_nodes == 0:
+        return None
+    n4 = 2 + 2 * n_nodes + n_slots + (n_slots + 3) // 4
+    blob = np.zeros(4 * n4, np.float32)
+    ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, blob.ctypes.data_as(C.c_void_p), n4, counts))
+    b4 = blob.reshape(n4, 4)
+    nodes = b4[2:2 + 2 * n_nodes]
+    slots = b4[2 + 2 * n_nodes:2 + 2 * n_nodes + n_slots]
+    index = blob[4 * (2 + 2 * n_nodes + n_slots):].view(np.uint32)[:n_slots]
+    return {"hdr": b4[:2], "lo": nodes[0::2, :3], "hi": nodes[1::2, :3], "link": nodes[0::2, 3].view(np.uint32),
+            "low": nodes[1::2, 3].view(np.uint32), "slots": slots, "index": index, "n_always": n_always,
+            "n_leaves": n_leaves, "n_nodes": n_nodes, "n_slots": n_slots}
+
+
+def check_structure(sph, b):
+    """Host-side walk of the device-built tables; returns a list of complaints (empty = fine)."""
+    bad = []
+    n = len(sph)
+    na, nn, nl = b["n_always"], b["n_nodes"], b["n_leaves"]
+    leaf_size = (b["n_slots"] - na) // max(nl, 1)
+    idx = b["index"]
+    # always list: scene order, records equal
+    al = idx[:na]
+    if not np.all(np.diff(al.astype(np.int64)) > 0):
+        bad.append("always list not in scene order")
+    tree_idx = idx[na:]
+    real = tree_idx[tree_idx != 0xffffffff]
+    if sorted(list(al) + list(real)) != list(range(n)):
+        bad.append("slots do not hold every sphere exactly once")
+    rad = sph["rad"].astype(np.float32)
+    p = np.ascontiguousarray(sph["p"]).astype(np.float32)
+    for j in range(b["n_slots"]):
+        ix = idx[j]
+        if ix == 0xffffffff:
+            if not np.all(np.isnan(b["slots"][j])):
+                bad.append(f"padding slot {j} is not NaN")
+            continue
+        want = np.array([p[ix, 0], p[ix, 1], p[ix, 2], np.float32(rad[ix]) * np.float32(rad[ix])], np.float32)
+        if not np.array_equal(want.view(np.uint32), b["slots"][j].view(np.uint32)):
+            bad.append(f"slot {j} != record {ix}")
+    skip = b["link"] & 0xffff
+    leaf = (b["link"] >> 16).astype(np.int64) - 1
+    if not np.all(skip > np.arange(nn)):
+        bad.append("a skip link does not point forward")
+    if np.any(skip > nn):
+        bad.append("a skip link points past the end")
+    if sorted(leaf[leaf >= 0]) != list(range(nl)):
+        bad.append("leaf numbers are not 0..n_leaves-1, each once")
+    # subtree of node k = [k, skip[k]); every sphere below it inside its box, lowest index right
+    leaf_of_node = leaf
+    node_leaves = [[] for _ in range(nn)]
+    stack = []
+    for k in range(nn):
+        while stack and skip[stack[-1]] <= k:
+            stack.pop()
+        stack.append(k)
+        if leaf_of_node[k] >= 0:
+            for a in stack:
+                node_leaves[a].append(int(leaf_of_node[k]))
+    for k in range(nn):
+        members = []
+        for lf in node_leaves[k]:
+            members += [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size] if i != 0xffffffff]
+        if not members:
+            bad.append(f"node {k} has no sphere below it")
+            continue
+        m = np.array(members)
+        ar = np.abs(rad[m]).astype(np.float64)
+        lo = (p[m].astype(np.float64) - ar[:, None]).min(0)
+        hi = (p[m].astype(np.float64) + ar[:, None]).max(0)
+        if np.any(b["lo"][k] > lo) or np.any(b["hi"][k] < hi):
+            bad.append(f"node {k}: box does not hold its spheres")
+        if b["low"][k] != m.min():
+            bad.append(f"node {k}: lowest index {b['low'][k]} != {m.min()}")
+    if leaf_of_node[0] < 0 and nn > 1 and len(node_leaves[0]) != nl:
+        bad.append("the root does not reach every leaf")
+    return bad
+
+
+def counters_raw(ctx):
+    out = (C.c_ulonglong * 32)()
+    ctx._check(ctx._lib.rt_debug_counters_raw(ctx._h, out))
+    return list(out)
+
+
+def agreement(sph, cam, w, h, spp, bvh_min=1):
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        b = read_bvh(ctx)
+        if b is None:
+            return None
+        ctx.set_mode(113)
+        ctx.render_pass(spp)
+        c = counters_raw(ctx)
+        return {"closest_rays": c[20], "closest_differ": c[21], "shadow_rays": c[24], "shadow_differ": c[25],
+                "last_closest": [hex(c[22]), hex(c[23])], "last_shadow": hex(c[26]), "tree": [b["n_always"], b["n_leaves"], b["n_nodes"]]}
+
+
+def census(sph, cam, w, h, spp):
+    """mode 114: steps of the walk per wavefront and per lane (closest-hit and shadow rays)"""
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_mode(114)
+        ctx.render_pass(spp)
+        c = counters_raw(ctx)
+        st = ctx.stats()
+    out = {}
+    for name, base, rays in (("closest", 20, st["closest_rays"]), ("shadow", 24, st["shadow_rays"])):
+        wn, ln, wl, ll = c[base:base + 4]
+        out[name] = {"rays": rays, "node_tests_per_ray": round(ln / max(rays, 1), 1), "leaf_visits_per_ray": round(ll / max(rays, 1), 2),
+                     "wave_node_steps": wn, "lanes_per_node_step": round(ln / max(wn, 1), 1),
+                     "wave_leaf_steps": wl, "lanes_per_leaf_step": round(ll / max(wl, 1), 1)}
+    return out
+
+
+def timed(sph, cam, w, h, spp, bvh_min, reps=3, mode=api.RT_MODE_PARITY, walk=(0, 0, 0)):
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 0))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, *walk))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_mode(mode)
+        best = None
+        px = None
+        for _ in range(reps):
+            ctx.reset()
+            px = ctx.render_pass(spp)
+            ms = ctx.stats()["last_kernel_ms"]
+            best = ms if best is None else min(best, ms)
+        st = ctx.stats()
+        st["pick"] = ctx._lib.rt_debug_bvh_pick(ctx._h)
+        return best, px, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--boxes", action="store_true", help="timing on enclosed all-specular scenes instead of the open ones")
+    ap.add_argument("--timing-only", action="store_true")
+    ap.add_argument("--census", action="store_true", help="only the step census of the walk (c3 and c5 at quarter size)")
+    args = ap.parse_args()
+    report = {}
+    if args.census:
+        for name, mk, (w, h, spp) in [("c3", lambda: scenes.random_spheres(1024), (480, 270, 16)),
+                                      ("c5", lambda: scenes.mirror_box(64), (480, 270, 16)),
+                                      ("mirror_box_256", lambda: scenes.mirror_box(256), (480, 270, 16)),
+                                      ("mirror_box_1024", lambda: scenes.mirror_box(1024), (480, 270, 16)),
+                                      ("c256", lambda: scenes.random_spheres(256), (480, 270, 16))]:
+            sph, orig, target = mk()
+            print("census", name, json.dumps(census(sph, host.compute_camera(orig, target, w, h), w, h, spp)), flush=True)
+        return 0
+    if args.timing_only:
+        return timing(args, report)
+    # --- structure ---
+    makers = {"random_1024": lambda: scenes.random_spheres(1024), "random_96": lambda: scenes.random_spheres(96),
+              "mirror_box_64": lambda: scenes.mirror_box(64), "demo_plus_16": lambda: scenes.demo_plus(16),
+              "random_37": lambda: scenes.random_spheres(37)}
+    for name, mk in makers.items():
+        sph, orig, target = mk()
+        sph = api.as_spheres(sph)
+        with api.RtContext(64, 64, diag=True) as ctx:
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+            ctx.set_scene(sph)
+            b = read_bvh(ctx)
+            bad = check_structure(sph, b) if b else ["no hierarchy"]
+            report["structure_" + name] = {"always": b["n_always"], "leaves": b["n_leaves"], "nodes": b["n_nodes"], "complaints": bad[:5],
+                                           "hdr": [float(v) for v in b["hdr"].ravel()[:7]]}
+            print("structure", name, report["structure_" + name], flush=True)
+            if bad:
+                print(json.dumps(report))
+                return 1
+    # --- agreement ---
+    for name, mk, (w, h, spp) in [("random_1024", lambda: scenes.random_spheres(1024), (192, 108, 4)),
+                                  ("mirror_box_64", lambda: scenes.mirror_box(64), (128, 96, 8)),
+                                  ("demo_plus_16", lambda: scenes.demo_plus(16), (128, 96, 8)),
+                                  ("random_96", lambda: scenes.random_spheres(96), (128, 96, 8))]:
+        sph, orig, target = mk()
+        cam = host.compute_camera(orig, target, w, h)
+        r = agreement(sph, cam, w, h, spp)
+        report["agreement_" + name] = r
+        print("agreement", name, r, flush=True)
+        if r is None or r["closest_differ"] or r["shadow_differ"]:
+            print(json.dumps(report))
+            return 1
+    # --- parity against the oracle (small) and timing on / off ---
+    import _oracle as O
+    for name, mk, (w, h, spp) in [("random_1024", lambda: scenes.random_spheres(1024), (96, 64, 2)),
+                                  ("mirror_box_64", lambda: scenes.mirror_box(64), (64, 64, 4))]:
+        sph, orig, target = mk()
+        cam = host.compute_camera(orig, target, w, h)
+        want = O.render(sph, cam, w, h, spp)
+        with api.RtContext(w, h, diag=True) as ctx:
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 2))
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            px = ctx.render_pass(spp)
+            st = ctx.stats()
+            same = bool(np.array_equal(px, want["pixels"]) and np.array_equal(ctx.read_colors().view(np.uint32), want["colors"].view(np.uint32))
+                        and np.array_equal(ctx.read_seeds(), want["seeds"]))
+            cnt = (st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"], st["rng_draws"]) == \
+                  (want["stats"]["samples"], want["stats"]["closest_calls"], want["stats"]["shadow_calls"], want["stats"]["sphere_tests"], want["stats"]["rng_draws"])
+        report["oracle_" + name] = {"frame_equal": same, "counters_equal": cnt}
+        print("oracle", name, report["oracle_" + name], flush=True)
+    return timing(args, report)
+
+
+def timing(args, report):
+    full = [("c3_random_1024", lambda: scenes.random_spheres(1024), (1920, 1080, 16)),
+            ("random_512", lambda: scenes.random_spheres(512), (1920, 1080, 16)),
+            ("random_256", lambda: scenes.random_spheres(256), (1920, 1080, 16)),
+            ("random_128", lambda: scenes.random_spheres(128), (1920, 1080, 16)),
+            ("mirror_box_256", lambda: scenes.mirror_box(256), (1920, 1080, 16)),
+            ("c5_mirror_box_64", lambda: scenes.mirror_box(64), (1920, 1080, 16))]
+    if args.boxes:
+        full = [("mirror_box_512", lambda: scenes.mirror_box(512), (960, 540, 16)), ("mirror_box_1024", lambda: scenes.mirror_box(1024), (960, 540, 16)),
+                ("mirror_box_2048", lambda: scenes.mirror_box(2048), (960, 540, 16)), ("random_2048", lambda: scenes.random_spheres(2048), (960, 540, 16))]
+    if args.quick:
+        full = [(n, m, (w // 4, h // 4, s)) for n, m, (w, h, s) in full]
+    for name, mk, (w, h, spp) in full:
+        sph, orig, target = mk()
+        cam = host.compute_camera(orig, target, w, h)
+        t_off, px_off, st_off = timed(sph, cam, w, h, spp, 0)
+        t_on, px_on, st_on = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 2))
+        t_call, px_call, st_call = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 1))
+        t_auto, px_auto, st_auto = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 0))
+        sweep = {}
+        for steps in (64,):
+            for gate in (16,):
+                tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 2))
+                sweep[f"{steps}/{gate}"] = round(tt, 2) if np.array_equal(pp, px_off) else "FRAME DIFFERS"
+        rays = st_on["samples"] + st_on["shadow_rays"]
+        report["timing_" + name] = {"plain_ms": round(t_off, 3), "hierarchy_ms": round(t_on, 3), "per_call_ms": round(t_call, 3), "measured_choice_ms": round(t_auto, 3), "measured_choice": st_auto.get("pick"),
+                                    "frames_equal": bool(np.array_equal(px_off, px_on) and np.array_equal(px_off, px_call) and np.array_equal(px_off, px_auto)), "steps/gate_ms": sweep,
+                                    "counters_equal": st_off["sphere_tests"] == st_on["sphere_tests"],
+                                    "Mray_s_hierarchy": round(rays / t_on / 1e3, 1), "Mray_s_plain": round(rays / t_off / 1e3, 1)}
+        print("timing", name, report["timing_" + name], flush=True)
+    print(json.dumps(report))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
