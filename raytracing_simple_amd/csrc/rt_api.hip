@@ -480,7 +480,7 @@ bool bvh_usable(const rt_ctx *c, int n_samples) {
     if (!c->bvh_ok || c->wg_waves == 1 || c->persist != 0) return false;
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     const bool mat = lds_all <= (size_t)c->mat_lds_limit;
-    return rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_nodes, c->bvh.n_slots, false) <= (size_t)c->bvh_lds_limit;
+    return rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_nodes, c->bvh.n_slots, false, c->walk_form == 1) <= (size_t)c->bvh_lds_limit;
 }
 
 // `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one that fits), 2 = the plain sweep
@@ -514,7 +514,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     // large scenes: the instance that walks the hierarchy, while its tables leave room for two workgroups per CU
     size_t lds_use = lds;
     const size_t lds_bvh = c->bvh_ok ? rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples,
-                                                        c->bvh.n_nodes, c->bvh.n_slots, false) : 0;
+                                                        c->bvh.n_nodes, c->bvh.n_slots, false, c->walk_form == 1) : 0;
     if (form != 2 && bvh_usable(c, n_samples)) {
         const bool per_call = c->walk_form == 1;
         variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant) : (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant);
@@ -531,15 +531,16 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
     if (c->mode >= 100) {
         const bool wants_bvh = use_fast_table ? (variant == rt::kFastBvhVariant || variant == rt::kFastWalkVariant)
-                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityWalkVariant);
+                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityWalkVariant + 1);
         p.bvh = rt::BvhTables{};
         lds_use = lds;
         if (wants_bvh) {
             if (!c->bvh_ok) return fail(RT_ERR_STATE, "mode %d needs a scene with a hierarchy (rt_debug_set_bvh)", c->mode);
             const bool full = !use_fast_table && variant == rt::kParityBvhCheckVariant;
             p.bvh = c->bvh;
+            const bool walk = use_fast_table ? variant == rt::kFastWalkVariant : variant >= rt::kParityWalkVariant;
             lds_use = rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
-                                        c->bvh.n_slots, full);
+                                        c->bvh.n_slots, full, !walk);
             if (lds_use > 152 * 1024) return fail(RT_ERR_ARG, "mode %d needs %zu B of LDS", c->mode, lds_use);
         }
     }
@@ -1368,6 +1369,7 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
 }
 static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
+
 static int dbg_set_walk_form(rt_ctx *c, int v) { c->walk_form = v; c->bvh_pick = 0; c->probe_state = 0; return RT_OK; }
 // rt_walk.inc.h: node tests per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
 // form: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = always the walk-per-call form,

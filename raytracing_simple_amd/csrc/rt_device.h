@@ -92,8 +92,8 @@ inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, 
 
 // the same for the instances that walk the hierarchy (no full geometry table; the check instance carries both)
 inline size_t lds_bytes_bvh(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples, uint32_t n_nodes,
-                            uint32_t n_slots, bool with_full_table) {
-    size_t b = bvh_blob_float4s(n_nodes, n_slots) * 16 + (size_t)n_lights * 32;
+                            uint32_t n_slots, bool with_full_table, bool with_index = true) {
+    size_t b = (bvh_blob_float4s(n_nodes, n_slots) - (with_index ? 0 : (n_slots + 3) / 4)) * 16 + (size_t)n_lights * 32;
     if (with_full_table) b += (size_t)n_spheres * 16;
     if (mat_in_lds) b += (size_t)n_spheres * 32;
     if (n_samples <= kMaxK2Table) b += (size_t)(n_samples > 0 ? n_samples : 0) * 4;

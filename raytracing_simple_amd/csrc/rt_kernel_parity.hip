@@ -66,7 +66,7 @@
 #define RT_KERNEL_NAME rt_trace_parity_walk
 #define RT_OPT_BVH 4
 #define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_MINWAVES 5
+#define RT_OPT_MINWAVES 6
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
@@ -81,6 +81,13 @@
 #define RT_NS parity_bvhs            /* the walk with a census of its steps (counters[20..27]) */
 #define RT_KERNEL_NAME rt_trace_parity_bvhs
 #define RT_OPT_BVH 3
+#define RT_OPT_LEAN_SQRT 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_walks           /* rt_walk.inc.h with a census of its two phases (counters[20..28]) */
+#define RT_KERNEL_NAME rt_trace_parity_walks
+#define RT_OPT_BVH 5
 #define RT_OPT_LEAN_SQRT 1
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
@@ -165,6 +172,9 @@ static KernelFn const kParityKernels[] = {
     nullptr, nullptr,
 #endif
     parity_walk::rt_trace_parity_walk,                  // 15 = kParityWalkVariant
+#if RT_DIAGNOSTICS
+    parity_walks::rt_trace_parity_walks,                // 16   its census
+#endif
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 

@@ -753,7 +753,7 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 #ifndef RT_OPT_MINWAVES
 #define RT_OPT_MINWAVES 1
 #endif
-#if RT_OPT_BVH == 4
+#if RT_OPT_BVH >= 4
 #include "rt_walk.inc.h"       // large scenes: the walk as lane state (its own kernel body)
 #else
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
@@ -1407,7 +1407,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 #endif
 }
-#endif   // RT_OPT_BVH != 4
+#endif   // RT_OPT_BVH < 4
 
 #if !defined(RT_VARIANT_KERNEL)
 // The packed frame from the colour plane (.cl:34,594-596) with this mode's toInt, for frames whose

@@ -30,8 +30,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     float4 *s_hdr = lds;
     float4 *s_nodes = s_hdr + 2;
     float4 *s_slots = s_nodes + 2 * n_nodes;
-    uint32_t *s_index = reinterpret_cast<uint32_t *>(s_slots + n_slots);
-    const uint32_t blob_n = 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
+    // (the scene index of a slot is only read for a candidate that passes the test: from HBM / L2, not staged)
+    const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + 2u + 2u * n_nodes + n_slots);
+    const uint32_t blob_n = 2u + 2u * n_nodes + n_slots;
     float4 *s_lightA = lds + blob_n;              // {centre, radius}
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
@@ -109,9 +110,32 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     uint32_t lj = 0;
     float l_k = 0.f;
     unsigned long long unused_roots = 0;
+#if RT_OPT_BVH == 5
+    // census instance: wave-level trips and lane participation of the two phases, and where the clock goes
+    unsigned long long cen[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define RT_WALK_COUNT(k)                                                                         \
+    do {                                                                                         \
+        const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
+        if (lane == __ffsll((long long)act_) - 1) cen[k] += 1ull;                                \
+        cen[(k) + 1] += 1ull;                                                                    \
+    } while (0)
+#define RT_WALK_CLOCK(k, t0)                                                                     \
+    do {                                                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
+        const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
+        if (lane == __ffsll((long long)act_) - 1) cen[k] += now_ - (t0);                         \
+    } while (0)
+#else
+#define RT_WALK_COUNT(k)
+#define RT_WALK_CLOCK(k, t0)
+#endif
 
     for (;;) {
         if (st == kNew && s >= s_end) break;
+#if RT_OPT_BVH == 5
+        cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
+        const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
+#endif
 
         // ---- T: walk ----
         if (node < n_nodes) {
@@ -123,6 +147,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 bool more;
                 do {
                     budget -= 1;
+                    RT_WALK_COUNT(0);
                     const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
                     const uint32_t link = __float_as_uint(A.w);
                     const uint32_t next = max(link & 0xffffu, node + 1u);          // (forward, whatever the table says)
@@ -135,6 +160,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     more = !take & (node < n_nodes) & (budget > 0);
                 } while (more);
                 if (leaf != 0xffffffffu) {
+                    RT_WALK_COUNT(2);
                     const uint32_t sl = n_always + (uint32_t)kBvhLeaf * leaf;
                     HitPre p[kBvhLeaf];
 #pragma unroll
@@ -161,12 +187,17 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             }
         }
 
+#if RT_OPT_BVH == 5
+        RT_WALK_CLOCK(6, t_trip);
+        const unsigned long long t_s = __builtin_amdgcn_s_memtime();
+#endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
         const bool ready = node >= n_nodes;
         const unsigned long long br = __builtin_amdgcn_ballot_w64(ready);
         const unsigned long long bw = __builtin_amdgcn_ballot_w64(!ready);
         const bool go = (__popcll(br) >= P.regen_gate) || (bw == 0ull);
         if (ready && go) {
+            RT_WALK_COUNT(4);
             bool path_done = false;
             bool start_closest = false;
             if (st == kShadow) {
@@ -340,7 +371,18 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 st = kClosest;
             }
         }
+#if RT_OPT_BVH == 5
+        RT_WALK_CLOCK(7, t_s);
+#endif
     }
+#if RT_OPT_BVH == 5
+    for (int k = 0; k < 9; ++k) {
+        unsigned long long v = cen[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) atomicAdd(&P.counters[20 + k], v);
+    }
+#endif
 
     // ---- epilogue: as in rt_trace.inc.h ----
     const __attribute__((address_space(4))) LaunchParams *qp =

@@ -150,10 +150,29 @@ def census(sph, cam, w, h, spp):
     return out
 
 
-def timed(sph, cam, w, h, spp, bvh_min, reps=3, mode=api.RT_MODE_PARITY, walk=(0, 0, 0)):
+def census_walk(sph, cam, w, h, spp, steps=0, gate=0):
+    """mode 116: the two phases of rt_walk.inc.h -- wave-level trips, lanes taking part, clock ticks"""
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, steps, gate, 2))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.set_mode(116)
+        ctx.render_pass(spp)
+        c = counters_raw(ctx)[20:29]
+        st = ctx.stats()
+    rays = st["closest_rays"] + st["shadow_rays"]
+    return {"rays": rays, "node_tests_per_ray": round(c[1] / rays, 1), "lanes_per_node_step": round(c[1] / max(c[0], 1), 1),
+            "leaf_visits_per_ray": round(c[3] / rays, 2), "lanes_per_leaf_step": round(c[3] / max(c[2], 1), 1),
+            "shade_phases": c[4], "lanes_per_shade_phase": round(c[5] / max(c[4], 1), 1), "loop_trips": c[8],
+            "node_steps_per_trip": round(c[0] / max(c[8], 1), 1), "clock_share_walk": round(c[6] / max(c[6] + c[7], 1), 3)}
+
+
+def timed(sph, cam, w, h, spp, bvh_min, reps=3, mode=api.RT_MODE_PARITY, walk=(0, 0, 0), ratio=0):
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 0))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, *walk))
+        assert not ratio
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         ctx.set_mode(mode)
@@ -179,12 +198,11 @@ def main():
     report = {}
     if args.census:
         for name, mk, (w, h, spp) in [("c3", lambda: scenes.random_spheres(1024), (480, 270, 16)),
-                                      ("c5", lambda: scenes.mirror_box(64), (480, 270, 16)),
-                                      ("mirror_box_256", lambda: scenes.mirror_box(256), (480, 270, 16)),
-                                      ("mirror_box_1024", lambda: scenes.mirror_box(1024), (480, 270, 16)),
-                                      ("c256", lambda: scenes.random_spheres(256), (480, 270, 16))]:
+                                      ("mirror_box_256", lambda: scenes.mirror_box(256), (480, 270, 16))]:
             sph, orig, target = mk()
             print("census", name, json.dumps(census(sph, host.compute_camera(orig, target, w, h), w, h, spp)), flush=True)
+            for steps, gate in ((64, 16), (16, 16), (16, 48)):
+                print("census_walk", name, steps, gate, json.dumps(census_walk(sph, host.compute_camera(orig, target, w, h), w, h, spp, steps, gate)), flush=True)
         return 0
     if args.timing_only:
         return timing(args, report)
@@ -262,10 +280,9 @@ def timing(args, report):
         t_call, px_call, st_call = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 1))
         t_auto, px_auto, st_auto = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 0))
         sweep = {}
-        for steps in (64,):
-            for gate in (16,):
-                tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 2))
-                sweep[f"{steps}/{gate}"] = round(tt, 2) if np.array_equal(pp, px_off) else "FRAME DIFFERS"
+        for steps, gate in ((32, 16), (64, 16), (128, 16), (64, 32)):
+            tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 2))
+            sweep[f"{steps}/{gate}"] = round(tt, 2) if np.array_equal(pp, px_off) else "FRAME DIFFERS"
         rays = st_on["samples"] + st_on["shadow_rays"]
         report["timing_" + name] = {"plain_ms": round(t_off, 3), "hierarchy_ms": round(t_on, 3), "per_call_ms": round(t_call, 3), "measured_choice_ms": round(t_auto, 3), "measured_choice": st_auto.get("pick"),
                                     "frames_equal": bool(np.array_equal(px_off, px_on) and np.array_equal(px_off, px_call) and np.array_equal(px_off, px_auto)), "steps/gate_ms": sweep,
