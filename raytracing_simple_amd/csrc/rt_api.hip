@@ -321,6 +321,32 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
         hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
         hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(s_bad));
     }
+    // ---- 5. the same tree as sibling pairs (rt_device.h BvhTables `pairs`): one thread per inner node ----
+    float4 *pairs = reinterpret_cast<float4 *>(index) + (n_slots + 3) / 4;
+    for (uint32_t m = 1 + tid; m < n_leaves; m += 1024) {
+        uint32_t a = 0, b = n_leaves, mid;
+        for (;;) {
+            mid = (a + b) / 2;
+            if (mid == m) break;
+            if (m < mid) b = mid;
+            else a = mid;
+        }
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t ca = side ? mid : a, cb = side ? b : mid;
+            float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+            uint32_t low = 0xffffffffu;
+            for (uint32_t l = ca; l < cb; ++l) {
+                const float4 A = s_leaf[2 * l], B = s_leaf[2 * l + 1];
+                lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
+                hi[0] = fmaxf(hi[0], B.x); hi[1] = fmaxf(hi[1], B.y); hi[2] = fmaxf(hi[2], B.z);
+                const uint32_t q = __float_as_uint(B.w);
+                low = q < low ? q : low;
+            }
+            const uint32_t ref = (cb - ca == 1) ? (rt::kBvhLeafRef | ca) : (ca + cb) / 2 - 1;
+            pairs[4 * (size_t)(m - 1) + 2 * side] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(ref));
+            pairs[4 * (size_t)(m - 1) + 2 * side + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+        }
+    }
 }
 
 // rt_deinterleave_rows: full[y] = row (t/n)*tile_rows + y%tile_rows of rank t%n's block, t = y/tile_rows.
@@ -475,12 +501,20 @@ rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
     return p;
 }
 
+// LDS of the instance that walks the hierarchy in the context's form (walk_form: 0 / 3 = sibling pairs with a stack,
+// 1 = walk per call, 2 = depth-first nodes as lane state)
+size_t bvh_lds(const rt_ctx *c, bool mat, int n_samples) {
+    if (c->walk_form == 1 || c->walk_form == 2)
+        return rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_nodes, c->bvh.n_slots, false, c->walk_form == 1);
+    return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
+}
+
 // the scene has a hierarchy and the instance that walks it fits
 bool bvh_usable(const rt_ctx *c, int n_samples) {
     if (!c->bvh_ok || c->wg_waves == 1 || c->persist != 0) return false;
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     const bool mat = lds_all <= (size_t)c->mat_lds_limit;
-    return rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_nodes, c->bvh.n_slots, false, c->walk_form == 1) <= (size_t)c->bvh_lds_limit;
+    return bvh_lds(c, mat, n_samples) <= (size_t)c->bvh_lds_limit;
 }
 
 // `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one that fits), 2 = the plain sweep
@@ -513,11 +547,12 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     bool persist = false;
     // large scenes: the instance that walks the hierarchy, while its tables leave room for two workgroups per CU
     size_t lds_use = lds;
-    const size_t lds_bvh = c->bvh_ok ? rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples,
-                                                        c->bvh.n_nodes, c->bvh.n_slots, false, c->walk_form == 1) : 0;
+    const size_t lds_bvh = c->bvh_ok ? bvh_lds(c, p.mat_in_lds != 0, n_samples) : 0;
     if (form != 2 && bvh_usable(c, n_samples)) {
         const bool per_call = c->walk_form == 1;
-        variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant) : (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant);
+        variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant)
+                           : c->walk_form == 2 ? (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant)
+                                               : (fast ? rt::kFastPairsVariant : rt::kParityPairsVariant);
         p.bvh = c->bvh;
         lds_use = lds_bvh;
         if (!per_call && c->regen_gate <= 0) p.regen_gate = c->walk_gate;
@@ -530,8 +565,8 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     else if (c->mode >= 200) { variant = c->mode - 200; use_fast_table = true; }
     else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
     if (c->mode >= 100) {
-        const bool wants_bvh = use_fast_table ? (variant == rt::kFastBvhVariant || variant == rt::kFastWalkVariant)
-                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityWalkVariant + 1);
+        const bool wants_bvh = use_fast_table ? (variant >= rt::kFastBvhVariant && variant <= rt::kFastPairsVariant)
+                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityPairsVariant);
         p.bvh = rt::BvhTables{};
         lds_use = lds;
         if (wants_bvh) {
@@ -539,8 +574,11 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
             const bool full = !use_fast_table && variant == rt::kParityBvhCheckVariant;
             p.bvh = c->bvh;
             const bool walk = use_fast_table ? variant == rt::kFastWalkVariant : variant >= rt::kParityWalkVariant;
-            lds_use = rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
-                                        c->bvh.n_slots, full, !walk);
+            const bool pairs = use_fast_table ? variant == rt::kFastPairsVariant : variant == rt::kParityPairsVariant;
+            lds_use = pairs ? rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_leaves,
+                                                  c->bvh.n_slots, c->bvh.stack_depth, 256)
+                            : rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
+                                                c->bvh.n_slots, full, !walk);
             if (lds_use > 152 * 1024) return fail(RT_ERR_ARG, "mode %d needs %zu B of LDS", c->mode, lds_use);
         }
     }
@@ -685,8 +723,8 @@ int ensure_scene_capacity(rt_ctx *c, uint32_t count) {
     HIP_TRY(hipMalloc(&ns, (size_t)cap * sizeof(rt_sphere)));
     float4 *nb = nullptr;
     hipError_t e = hipMalloc(&nt, ((size_t)cap * 5 + 1) * sizeof(float4));
-    // blob: 2 + 2 * nodes + slots + index, nodes < cap / 2 + 2, slots < cap + 4
-    if (e == hipSuccess) e = hipMalloc(&nb, ((size_t)cap * 5 / 2 + 32) * sizeof(float4));
+    // blob: hdr 2 + nodes (< cap / 2 + 4) + slots (< cap + 8) + index (< cap / 4 + 3) + pairs (< cap / 2 + 4) float4
+    if (e == hipSuccess) e = hipMalloc(&nb, ((size_t)cap * 3 + 64) * sizeof(float4));
     if (e != hipSuccess) {
         (void)hipFree(ns);
         (void)hipFree(nt);
@@ -746,7 +784,9 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
     const size_t lds = std::max((size_t)n_pad * 8, (size_t)n_leaves * 32);
     hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
     HIP_TRY(hipGetLastError());
-    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, 2 * n_leaves - 1, n_always + rt::kBvhLeaf * n_leaves };
+    uint32_t depth = 1;
+    while ((1u << depth) < n_leaves) depth += 1;
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, 2 * n_leaves - 1, n_always + rt::kBvhLeaf * n_leaves, depth + 1 };
     c->bvh_ok = true;
     return RT_OK;
 }
@@ -1375,7 +1415,7 @@ static int dbg_set_walk_form(rt_ctx *c, int v) { c->walk_form = v; c->bvh_pick =
 // form: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = always the walk-per-call form,
 // 2 = always the walk
 RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int per_call) {
-    if (!c || steps < 0 || gate < 0 || gate > 64 || per_call < 0 || per_call > 2) return fail(RT_ERR_ARG, "steps %d, gate %d, form %d", steps, gate, per_call);
+    if (!c || steps < 0 || gate < 0 || gate > 64 || per_call < 0 || per_call > 3) return fail(RT_ERR_ARG, "steps %d, gate %d, form %d", steps, gate, per_call);
     int rc = dbg_apply(c, dbg_set_walk_steps, steps);
     if (rc == RT_OK) rc = dbg_apply(c, dbg_set_walk_gate, gate);
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_form, per_call);
@@ -1401,7 +1441,7 @@ RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, ui
     counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
     if (!c->bvh_ok) return RT_OK;
     counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.n_nodes; counts4[3] = c->bvh.n_slots;
-    const size_t need = rt::bvh_blob_float4s(c->bvh.n_nodes, c->bvh.n_slots);
+    const size_t need = rt::bvh_blob_float4s(c->bvh.n_nodes, c->bvh.n_slots) + 4 * (size_t)(c->bvh.n_leaves - 1);   // ... | pairs
     if (blob_out) {
         if (cap_float4 < need) return fail(RT_ERR_ARG, "blob needs %zu float4", need);
         HIP_TRY(hipMemcpy(blob_out, c->d_bvh, need * sizeof(float4), hipMemcpyDeviceToHost));

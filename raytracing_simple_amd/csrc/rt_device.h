@@ -45,12 +45,29 @@ struct SceneTables {
 //   slots[j] = { p, rad*rad } for j < n_always: the spheres that stay outside the tree (large or non-finite), in
 //            scene order, swept by every ray as before; then 4 per leaf, in leaf order (padded with NaN records)
 //   index[j] = scene index of slot j
+//   pairs[4m .. 4m+3] = the two children of inner node m as { lo.xyz, bits(ref) }, { hi.xyz, bits(lowest scene index) }
+//            twice; ref = kBvhLeafRef | leaf number, or the number of the child's own pair.  The same tree as `nodes`,
+//            for a walk that takes the nearer child first and keeps the other on a per-lane stack (rt_walk.inc.h).
+//            Inner node m - 1 is the one that splits its range of leaves in front of leaf m; the root is pair
+//            n_leaves / 2 - 1 (a tree of one leaf has no pairs).
 constexpr int kBvhLeaf = 8;
+constexpr uint32_t kBvhLeafRef = 0x8000u;
 struct BvhTables {
-    const float4 *blob;     // hdr | nodes | slots | index
+    const float4 *blob;     // hdr | nodes | slots | index | pairs
     uint32_t n_always, n_leaves, n_nodes, n_slots;
+    uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1)
 };
 inline size_t bvh_blob_float4s(uint32_t n_nodes, uint32_t n_slots) { return 2 + 2 * (size_t)n_nodes + n_slots + (n_slots + 3) / 4; }
+inline size_t bvh_pairs_offset(uint32_t n_nodes, uint32_t n_slots) { return bvh_blob_float4s(n_nodes, n_slots); }   // float4 units; 4 * (n_leaves - 1) follow
+// LDS of the instance that walks the pairs: hdr | pairs | slots | per-lane stacks (u16) for `threads` lanes
+inline size_t lds_bytes_pairs(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples, uint32_t n_leaves,
+                              uint32_t n_slots, uint32_t stack_depth, int threads) {
+    size_t b = (2 + 4 * (size_t)(n_leaves ? n_leaves - 1 : 0) + n_slots) * 16 + (size_t)n_lights * 32;
+    b += (((size_t)stack_depth * threads * 2) + 15) & ~(size_t)15;
+    if (mat_in_lds) b += (size_t)n_spheres * 32;
+    if (n_samples <= kMaxK2Table) b += (size_t)(n_samples > 0 ? n_samples : 0) * 4;
+    return (b + 15) & ~(size_t)15;
+}
 
 struct LaunchParams {
     SceneTables scene;
@@ -119,6 +136,7 @@ constexpr int kFastW1Variant = 6, kFastCoopW1Variant = 7;
 constexpr int kParityBvhVariant = 12, kParityBvhCheckVariant = 13;  // hierarchy over the small spheres (large scenes)
 constexpr int kFastBvhVariant = 8;
 constexpr int kParityWalkVariant = 15, kFastWalkVariant = 9;       // ... with the walk as lane state (rt_walk.inc.h)
+constexpr int kParityPairsVariant = 17, kFastPairsVariant = 10;    // ... nearer child first, over the sibling pairs
 int parity_variant_waves(int variant);   // wavefronts per workgroup of an instance: 4 (32x8 tile) or 1 (8x8 tile)
 int fast_variant_waves(int variant);
 int parity_variant_count();

@@ -60,6 +60,12 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_pairs
+#define RT_KERNEL_NAME rt_trace_fast_pairs
+#define RT_OPT_BVH 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS fast_persist
 #define RT_KERNEL_NAME rt_trace_fast_persist
@@ -97,6 +103,7 @@ static KernelFn const kFastKernels[] = {
     fast_coop_w1::rt_trace_fast_coop_w1,             // 7 = kFastCoopW1Variant
     fast_bvh::rt_trace_fast_bvh,                     // 8 = kFastBvhVariant
     fast_walk::rt_trace_fast_walk,                   // 9 = kFastWalkVariant
+    fast_pairs::rt_trace_fast_pairs,                 // 10 = kFastPairsVariant
 };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 

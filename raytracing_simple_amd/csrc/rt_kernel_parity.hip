@@ -70,6 +70,14 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs           /* ... over sibling pairs, nearer child first, the other on a per-lane stack */
+#define RT_KERNEL_NAME rt_trace_parity_pairs
+#define RT_OPT_BVH 6
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS parity_bvhv            /* the walk + the plain sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_bvhv
@@ -174,7 +182,10 @@ static KernelFn const kParityKernels[] = {
     parity_walk::rt_trace_parity_walk,                  // 15 = kParityWalkVariant
 #if RT_DIAGNOSTICS
     parity_walks::rt_trace_parity_walks,                // 16   its census
+#else
+    nullptr,
 #endif
+    parity_pairs::rt_trace_parity_pairs,                // 17 = kParityPairsVariant
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 

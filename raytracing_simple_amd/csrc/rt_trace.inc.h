@@ -632,7 +632,7 @@ RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
     return R;
 }
 // true when the ray stretch [-tback, t_far + tback] misses the grown box for certain
-RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
+RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far, float &t_near) {
     const float x0 = (A.x - R.olo.x) * R.inv.x, x1 = (B.x - R.ohi.x) * R.inv.x;
     const float y0 = (A.y - R.olo.y) * R.inv.y, y1 = (B.y - R.ohi.y) * R.inv.y;
     const float z0 = (A.z - R.olo.z) * R.inv.z, z1 = (B.z - R.ohi.z) * R.inv.z;
@@ -640,7 +640,12 @@ RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
     tn = __builtin_fmaf(-fabsf(tn), 0x1p-20f, tn);
     tf = __builtin_fmaf(fabsf(tf), 0x1p-20f, tf);
+    t_near = tn;                        // where the ray enters the grown box (an ordering hint, nothing more)
     return tn > tf;
+}
+RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
+    float unused;
+    return bvh_misses(R, A, B, t_far, unused);
 }
 
 // closest hit among the spheres of the tree, .cl:215-232 restated: (t, idx) only ever moves to a smaller distance

@@ -19,21 +19,40 @@
 // the wavefront that is ready.  Nothing here depends on which trip a lane does what: per pixel the sequence of
 // operations and random draws is the reference's.
 
+#undef RT_OPT_WALK_PAIRS
+#undef RT_WALKING
+#undef RT_WALK_START
+#undef RT_WALK_COUNT
+#undef RT_WALK_CLOCK
+#define RT_OPT_WALK_PAIRS (RT_OPT_BVH >= 6)     /* 6: sibling pairs, nearer child first (the shipped form); 4: depth-first nodes with skip links */
+
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
     constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
-    // the blob of rt_device.h BvhTables, copied as it lies: hdr | nodes | slots | index
     const uint32_t n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
-    float4 *s_hdr = lds;
-    float4 *s_nodes = s_hdr + 2;
-    float4 *s_slots = s_nodes + 2 * n_nodes;
     // (the scene index of a slot is only read for a candidate that passes the test: from HBM / L2, not staged)
     const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + 2u + 2u * n_nodes + n_slots);
+    float4 *s_hdr = lds;
+#if RT_OPT_WALK_PAIRS
+    // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane])
+    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
+    float4 *s_pairs = s_hdr + 2;
+    float4 *s_slots = s_pairs + 4 * n_pairs;
+    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
+    const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
+    float4 *s_lightA = s_slots + n_slots + stack_f4;     // {centre, radius}
+    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
+    constexpr uint32_t kNone = 0xffffffffu;
+#else
+    // staged: hdr | nodes | slots of rt_device.h BvhTables, as they lie
+    float4 *s_nodes = s_hdr + 2;
+    float4 *s_slots = s_nodes + 2 * n_nodes;
     const uint32_t blob_n = 2u + 2u * n_nodes + n_slots;
     float4 *s_lightA = lds + blob_n;              // {centre, radius}
+#endif
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;                  // {colour, radius}
@@ -45,7 +64,17 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     __shared__ unsigned s_tile_cost;
     if (tid < 5) s_stat[tid] = 0;
     if (tid == 5) s_tile_cost = 0u;
+#if RT_OPT_WALK_PAIRS
+    if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
+    {
+        const float4 *g_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
+        const float4 *g_slots = P.bvh.blob + 2u + 2u * n_nodes;
+        for (uint32_t i = tid; i < 4u * n_pairs; i += kBlockThreads) s_pairs[i] = g_pairs[i];
+        for (uint32_t i = tid; i < n_slots; i += kBlockThreads) s_slots[i] = g_slots[i];
+    }
+#else
     for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
+#endif
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
         s_lightA[i] = P.scene.lightA[i];
         s_lightB[i] = P.scene.lightB[i];
@@ -102,7 +131,17 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     int depth = 0;
     bool after_specular = true;
     // the walk: next node, distance bound, best sphere so far (scene index and slot)
+#if RT_OPT_WALK_PAIRS
+    uint32_t cur = kNone;               // what the lane looks at next: a pair, kBvhLeafRef | leaf, or nothing (walk over)
+    int sp = 0;                         // entries on its stack
+    uint32_t w_idx = 0xffffffffu, w_slot = 0;
+#define RT_WALKING (cur != kNone)
+#define RT_WALK_START do { cur = root_ref; sp = 0; } while (0)
+#else
     uint32_t node = n_nodes, w_idx = 0xffffffffu, w_slot = 0;
+#define RT_WALKING (node < n_nodes)
+#define RT_WALK_START do { node = 0; } while (0)
+#endif
     float w_far = 0.f;
     BvhRay R = bvh_ray(s_hdr, o, d);
     // a diffuse hit being lit: its normal, the light sum, the light in flight and what it adds if unblocked
@@ -138,6 +177,71 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #endif
 
         // ---- T: walk ----
+#if RT_OPT_WALK_PAIRS
+        // Sibling pairs, nearer child first: one step loads a pair (64 bytes), tests both boxes against the ray's
+        // stretch, goes on with the nearer of the children that are hit and keeps the other on the lane's stack;
+        // with neither hit it takes the last kept one.  Which child comes first only decides how soon the bound
+        // shrinks -- every sphere whose box chain the ray meets is still tested, so the result is the same set of
+        // candidates run through the same rule.  (Shadow rays keep looking for the lowest blocking index: a subtree
+        // that only holds higher indices than the best so far is skipped.)
+        if (cur != kNone) {
+            int budget = P.walk_steps;
+            const bool shadow = st == kShadow;
+            uint16_t *my_stack = s_stack + tid;
+            while (cur != kNone && budget > 0) {
+                while (cur < kBvhLeafRef && budget > 0) {
+                    budget -= 1;
+                    RT_WALK_COUNT(0);
+                    const float4 *pp = s_pairs + 4u * cur;
+                    const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
+                    float tn0, tn1;
+                    const bool m0 = bvh_misses(R, A0, B0, w_far, tn0) | (shadow & (__float_as_uint(B0.w) > w_idx));
+                    const bool m1 = bvh_misses(R, A1, B1, w_far, tn1) | (shadow & (__float_as_uint(B1.w) > w_idx));
+                    const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
+                    const bool both = !m0 & !m1, none = m0 & m1;
+                    const bool second_first = both ? (tn1 < tn0) : m0;
+                    const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
+                    if (both) {
+                        my_stack[sp * kBlockThreads] = (uint16_t)far;
+                        sp += 1;
+                    }
+                    if (none) {
+                        sp -= 1;
+                        cur = sp >= 0 ? (uint32_t)my_stack[sp * kBlockThreads] : kNone;
+                        sp = sp < 0 ? 0 : sp;
+                    } else {
+                        cur = near;
+                    }
+                }
+                if (cur != kNone && cur >= kBvhLeafRef) {
+                    RT_WALK_COUNT(2);
+                    const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
+                    HitPre p[kBvhLeaf];
+#pragma unroll
+                    for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
+#pragma unroll
+                    for (int k = 0; k < kBvhLeaf; ++k) {
+                        if (p[k].det >= 0.f) {
+                            const HitRoots hr = hit_roots(p[k]);
+                            if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
+                                const uint32_t ix = s_index[sl + k];
+                                if (shadow) {
+                                    w_idx = ix < w_idx ? ix : w_idx;
+                                } else if (hr.t < w_far || ix < w_idx) {
+                                    w_far = hr.t;
+                                    w_slot = sl + (uint32_t)k;
+                                    w_idx = ix;
+                                }
+                            }
+                        }
+                    }
+                    sp -= 1;
+                    cur = sp >= 0 ? (uint32_t)my_stack[sp * kBlockThreads] : kNone;
+                    sp = sp < 0 ? 0 : sp;
+                }
+            }
+        }
+#else
         if (node < n_nodes) {
             int budget = P.walk_steps;
             const bool shadow = st == kShadow;
@@ -186,13 +290,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 }
             }
         }
+#endif
 
 #if RT_OPT_BVH == 5
         RT_WALK_CLOCK(6, t_trip);
         const unsigned long long t_s = __builtin_amdgcn_s_memtime();
 #endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
-        const bool ready = node >= n_nodes;
+        const bool ready = !RT_WALKING;
         const unsigned long long br = __builtin_amdgcn_ballot_w64(ready);
         const unsigned long long bw = __builtin_amdgcn_ballot_w64(!ready);
         const bool go = (__popcll(br) >= P.regen_gate) || (bw == 0ull);
@@ -324,7 +429,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     const uint32_t first_large = sweep_any(s_slots, n_always, o, d, w_far, unused_roots);
                     w_idx = first_large < n_always ? s_index[first_large] : n;
                     R = bvh_ray(s_hdr, o, d);
-                    node = 0;
+                    RT_WALK_START;
                     st = kShadow;
                 }
             }
@@ -367,7 +472,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 w_slot = slot;
                 w_idx = (t < 1e20f) ? s_index[slot] : 0xffffffffu;
                 R = bvh_ray(s_hdr, o, d);
-                node = 0;
+                RT_WALK_START;
                 st = kClosest;
             }
         }

@@ -17,7 +17,7 @@ import bvh_check  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _render(sph, cam, w, h, spp, bvh_min=1, form=2, mode=api.RT_MODE_PARITY, passes=None):
+def _render(sph, cam, w, h, spp, bvh_min=1, form=3, mode=api.RT_MODE_PARITY, passes=None):
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
@@ -62,11 +62,12 @@ def test_device_built_tables_are_a_valid_hierarchy(maker):
     (lambda: scenes.mirror_box(200), 48, 48, 3),
     (lambda: scenes.demo_plus(16), 96, 64, 4),
 ])
-def test_both_forms_of_the_walk_equal_the_oracle(maker, w, h, spp):
+def test_every_form_of_the_walk_equals_the_oracle(maker, w, h, spp):
+    """1 = walk per call, 2 = depth-first nodes as lane state, 3 = sibling pairs, nearer child first (the shipped form)"""
     sph, orig, target = maker()
     cam = host.compute_camera(orig, target, w, h)
     want = O.render(sph, cam, w, h, spp)
-    for form in (1, 2):
+    for form in (1, 2, 3):
         _same(_render(sph, cam, w, h, spp, form=form), want)
 
 
@@ -114,6 +115,7 @@ def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
     cam = host.compute_camera(orig, target, w, h)
     want = O.render(sph, cam, w, h, spp)
     _same(_render(sph, cam, w, h, spp, form=2), want)
+    _same(_render(sph, cam, w, h, spp, form=3), want)
     r = bvh_check.agreement(sph, cam, w, h, spp)
     assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
 
@@ -142,7 +144,7 @@ def test_moving_spheres_rebuild_the_hierarchy_on_the_stream():
     cam = host.compute_camera(orig, target, w, h)
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
-        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 2))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 3))
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         for step in range(3):
@@ -163,11 +165,11 @@ def test_fast_mode_with_the_hierarchy_is_as_close_as_fast_mode_without():
     sph, orig, target = scenes.random_spheres(400)
     w, h, spp = 160, 96, 16
     cam = host.compute_camera(orig, target, w, h)
-    par = _render(sph, cam, w, h, spp, form=2)
+    par = _render(sph, cam, w, h, spp, form=3)
     plain = _render(sph, cam, w, h, spp, bvh_min=0, mode=api.RT_MODE_FAST)
     base = host.psnr(plain["pixels"], par["pixels"])
     assert base >= 30.0
-    for form in (1, 2):
+    for form in (1, 2, 3):
         fast = _render(sph, cam, w, h, spp, form=form, mode=api.RT_MODE_FAST)
         assert fast["stats"]["samples"] == par["stats"]["samples"]
         assert host.psnr(fast["pixels"], par["pixels"]) >= min(50.0, base - 3.0)

@@ -275,7 +275,7 @@ def test_every_kernel_instance_in_the_libraries_has_parity():
     cooperative any-hit shapes run (coop_min = 12 spheres)."""
     lib = api.load_library(diag=True)
     n_par, n_fast = lib.rt_debug_variant_count(0), lib.rt_debug_variant_count(1)
-    assert n_par >= 16 and n_fast >= 10
+    assert n_par >= 18 and n_fast >= 11
     for maker, w, h, spp in ((lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 96, 64, 6),
                              (lambda: scenes.mirror_box(64), 64, 48, 4)):
         sph, orig, target = maker()

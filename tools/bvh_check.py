@@ -33,14 +33,16 @@ def read_bvh(ctx):
     n_always, n_leaves, n_nodes, n_slots = list(counts)
     if n_nodes == 0:
         return None
-    n4 = 2 + 2 * n_nodes + n_slots + (n_slots + 3) // 4
+    n4_nodes = 2 + 2 * n_nodes + n_slots + (n_slots + 3) // 4
+    n4 = n4_nodes + 4 * (n_leaves - 1)
     blob = np.zeros(4 * n4, np.float32)
     ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, blob.ctypes.data_as(C.c_void_p), n4, counts))
     b4 = blob.reshape(n4, 4)
     nodes = b4[2:2 + 2 * n_nodes]
     slots = b4[2 + 2 * n_nodes:2 + 2 * n_nodes + n_slots]
     index = blob[4 * (2 + 2 * n_nodes + n_slots):].view(np.uint32)[:n_slots]
-    return {"hdr": b4[:2], "lo": nodes[0::2, :3], "hi": nodes[1::2, :3], "link": nodes[0::2, 3].view(np.uint32),
+    pairs = b4[n4_nodes:]
+    return {"pairs": pairs, "hdr": b4[:2], "lo": nodes[0::2, :3], "hi": nodes[1::2, :3], "link": nodes[0::2, 3].view(np.uint32),
             "low": nodes[1::2, 3].view(np.uint32), "slots": slots, "index": index, "n_always": n_always,
             "n_leaves": n_leaves, "n_nodes": n_nodes, "n_slots": n_slots}
 
@@ -107,6 +109,47 @@ def check_structure(sph, b):
             bad.append(f"node {k}: lowest index {b['low'][k]} != {m.min()}")
     if leaf_of_node[0] < 0 and nn > 1 and len(node_leaves[0]) != nl:
         bad.append("the root does not reach every leaf")
+    # the same tree as sibling pairs: from the root every leaf is reached exactly once, every child box holds the
+    # spheres below it and knows their lowest scene index
+    LEAF = 0x8000
+    pr = b["pairs"]
+    seen_leaves, seen_pairs = [], set()
+
+    def below(ref):
+        """(spheres below ref), walking the pairs"""
+        if ref & LEAF:
+            lf = ref & (LEAF - 1)
+            seen_leaves.append(lf)
+            return [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size] if i != 0xffffffff]
+        if ref in seen_pairs or ref >= nl - 1:
+            bad.append(f"pair {ref} reached twice or out of range")
+            return []
+        seen_pairs.add(ref)
+        out = []
+        for side in (0, 1):
+            A, B = pr[4 * ref + 2 * side], pr[4 * ref + 2 * side + 1]
+            child = int(A[3:4].view(np.uint32)[0])
+            members = below(child)
+            if members:
+                m = np.array(members)
+                ar = np.abs(rad[m]).astype(np.float64)
+                if np.any(A[:3] > (p[m].astype(np.float64) - ar[:, None]).min(0)) or np.any(B[:3] < (p[m].astype(np.float64) + ar[:, None]).max(0)):
+                    bad.append(f"pair {ref} side {side}: box does not hold its spheres")
+                if int(B[3:4].view(np.uint32)[0]) != m.min():
+                    bad.append(f"pair {ref} side {side}: lowest index wrong")
+            else:
+                bad.append(f"pair {ref} side {side}: nothing below")
+            out += members
+        return out
+
+    import sys as _sys
+    _sys.setrecursionlimit(10000)
+    root = (nl // 2 - 1) if nl > 1 else LEAF
+    everything = below(root)
+    if sorted(seen_leaves) != list(range(nl)):
+        bad.append("the pairs do not reach every leaf exactly once")
+    if sorted(everything) != sorted(int(i) for i in real):
+        bad.append("the pairs do not reach every tree sphere exactly once")
     return bad
 
 
@@ -244,9 +287,10 @@ def main():
         sph, orig, target = mk()
         cam = host.compute_camera(orig, target, w, h)
         want = O.render(sph, cam, w, h, spp)
-        with api.RtContext(w, h, diag=True) as ctx:
+        for form in (2, 3):
+          with api.RtContext(w, h, diag=True) as ctx:
             ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
-            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 2))
+            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
             ctx.set_scene(sph)
             ctx.set_camera(cam)
             px = ctx.render_pass(spp)
@@ -255,8 +299,10 @@ def main():
                         and np.array_equal(ctx.read_seeds(), want["seeds"]))
             cnt = (st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"], st["rng_draws"]) == \
                   (want["stats"]["samples"], want["stats"]["closest_calls"], want["stats"]["shadow_calls"], want["stats"]["sphere_tests"], want["stats"]["rng_draws"])
-        report["oracle_" + name] = {"frame_equal": same, "counters_equal": cnt}
-        print("oracle", name, report["oracle_" + name], flush=True)
+          report[f"oracle_{name}_form{form}"] = {"frame_equal": same, "counters_equal": cnt}
+          print("oracle", name, "form", form, report[f"oracle_{name}_form{form}"], flush=True)
+          if not (same and cnt):
+              return 1
     return timing(args, report)
 
 
@@ -279,12 +325,13 @@ def timing(args, report):
         t_on, px_on, st_on = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 2))
         t_call, px_call, st_call = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 1))
         t_auto, px_auto, st_auto = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 0))
+        t_pairs, px_pairs, _ = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 3))
         sweep = {}
         for steps, gate in ((32, 16), (64, 16), (128, 16), (64, 32)):
-            tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 2))
+            tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 3))
             sweep[f"{steps}/{gate}"] = round(tt, 2) if np.array_equal(pp, px_off) else "FRAME DIFFERS"
         rays = st_on["samples"] + st_on["shadow_rays"]
-        report["timing_" + name] = {"plain_ms": round(t_off, 3), "hierarchy_ms": round(t_on, 3), "per_call_ms": round(t_call, 3), "measured_choice_ms": round(t_auto, 3), "measured_choice": st_auto.get("pick"),
+        report["timing_" + name] = {"plain_ms": round(t_off, 3), "hierarchy_ms": round(t_on, 3), "per_call_ms": round(t_call, 3), "pairs_ms": round(t_pairs, 3) if np.array_equal(px_pairs, px_off) else "FRAME DIFFERS", "measured_choice_ms": round(t_auto, 3), "measured_choice": st_auto.get("pick"),
                                     "frames_equal": bool(np.array_equal(px_off, px_on) and np.array_equal(px_off, px_call) and np.array_equal(px_off, px_auto)), "steps/gate_ms": sweep,
                                     "counters_equal": st_off["sphere_tests"] == st_on["sphere_tests"],
                                     "Mray_s_hierarchy": round(rays / t_on / 1e3, 1), "Mray_s_plain": round(rays / t_off / 1e3, 1)}

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Many fuzzed scenes (the generator of tests/test_gpu_parity.py) through the HIP path and the oracle:
-python tools/fuzz_parity.py FIRST COUNT -- prints the seeds that differ (none expected)."""
+python tools/fuzz_parity.py FIRST COUNT [FAMILY] -- prints the seeds that differ (none expected).
+RT_FUZZ_BVH=1|2 forces the hierarchy of large scenes on every scene (1 = walk per call, 2 = walk as lane state;
+diagnostics library); family 4 = hundreds of spheres in clusters, radii over three orders of magnitude."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,8 +64,40 @@ def family3(seed):
     return sph, orig, target
 
 
+def family4(seed):
+    """Scenes the hierarchy is built for, made nasty: 60..600 spheres in a few clusters, radii log-uniform over three
+    orders of magnitude (the largest stay outside the tree), exact duplicates, a cluster far away, the whole scene
+    scaled by 10^-2 ... 10^3, the camera inside a cluster or inside a glass sphere."""
+    rng = np.random.default_rng(300000 + seed)
+    n = int(rng.choice([60, 90, 150, 260, 400, 600]))
+    k = int(rng.integers(1, 6))
+    centres = rng.uniform(-60, 60, (k, 3))
+    spread = rng.uniform(3, 40, k)
+    which = rng.integers(0, k, n)
+    sph = np.zeros(n, api.SPHERE_DT)
+    sph["p"] = (centres[which] + rng.normal(0, 1, (n, 3)) * spread[which, None]).astype(np.float32)
+    sph["rad"] = (10.0 ** rng.uniform(-1.0, 2.0, n) * 0.5).astype(np.float32)
+    sph["c"] = rng.uniform(0.05, 0.95, (n, 3)).astype(np.float32)
+    sph["refl"] = rng.choice([api.DIFF, api.DIFF, api.SPEC, api.REFR], n)
+    dup = rng.integers(0, n // 2, 6)
+    sph[n - 6:] = sph[dup]
+    sph["refl"][n - 6:] = rng.choice([api.DIFF, api.SPEC, api.REFR], 6)
+    if seed % 3 == 0:
+        sph["p"][n // 2:n // 2 + 5] += np.float32(5000.0)
+    for j in rng.choice(n, int(rng.integers(1, 4)), replace=False):
+        sph["e"][j] = rng.uniform(2.0, 25.0, 3).astype(np.float32)
+    scale = np.float32(10.0 ** rng.uniform(-2, 3)) if seed % 2 else np.float32(1.0)
+    sph["p"] *= scale
+    sph["rad"] *= scale
+    j = int(rng.integers(0, n))
+    orig = sph["p"][j] + np.float32(0.3) * sph["rad"][j] if seed % 4 == 1 else (centres[0] + rng.normal(0, 1, 3) * 90).astype(np.float32) * scale
+    target = (centres[int(rng.integers(0, k))] * scale).astype(np.float32)
+    return sph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
+
+
 first, count = int(sys.argv[1]), int(sys.argv[2])
-gen = {"2": family2, "3": family3}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
+bvh_form = int(os.environ.get("RT_FUZZ_BVH", "0"))
+gen = {"2": family2, "3": family3, "4": family4}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
 bad = []
 for seed in range(first, first + count):
     sph, orig, target = gen(seed)
@@ -71,7 +105,10 @@ for seed in range(first, first + count):
     cam = host.compute_camera(orig, target, w, h)
     with np.errstate(all="ignore"):
         want = O.render(sph, cam, w, h, spp)
-    with api.RtContext(w, h) as ctx:
+    with api.RtContext(w, h, diag=bvh_form != 0) as ctx:
+        if bvh_form:
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, bvh_form))
         ctx.set_scene(sph); ctx.set_camera(cam)
         px = ctx.render_pass(spp); col = ctx.read_colors(); sd = ctx.read_seeds(); st = ctx.stats()
     o = want["stats"]
