@@ -213,6 +213,11 @@ RT_API int rt_read_colors(rt_ctx *ctx, float *out_host);
 RT_API int rt_read_seeds(rt_ctx *ctx, uint32_t *out_host);
 
 RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+/* The kernel instance the context's last launch used, by its symbol (what a profiler lists): the library picks it
+ * from the scene -- "rt_trace_parity_w1" (few spheres: one wavefront per workgroup), "..._coop_w1" / "..._coop"
+ * (12 and more: wave-ballot any-hit sharing), "..._pairs" (hundreds of small spheres: a hierarchy, where it measured
+ * faster than the sweep on this scene), the same with "fast".  "" before the first launch.  Frames do not depend on it. */
+RT_API const char *rt_last_kernel(const rt_ctx *ctx);
 
 /* Text of the calling thread's last failure ("" if none).                                    */
 RT_API const char *rt_last_error(void);

@@ -566,7 +566,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
     if (c->mode >= 100) {
         const bool wants_bvh = use_fast_table ? (variant >= rt::kFastBvhVariant && variant <= rt::kFastPairsVariant)
-                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityPairsVariant);
+                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityPairsVariant + 1);
         p.bvh = rt::BvhTables{};
         lds_use = lds;
         if (wants_bvh) {
@@ -574,7 +574,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
             const bool full = !use_fast_table && variant == rt::kParityBvhCheckVariant;
             p.bvh = c->bvh;
             const bool walk = use_fast_table ? variant == rt::kFastWalkVariant : variant >= rt::kParityWalkVariant;
-            const bool pairs = use_fast_table ? variant == rt::kFastPairsVariant : variant == rt::kParityPairsVariant;
+            const bool pairs = use_fast_table ? variant == rt::kFastPairsVariant : variant >= rt::kParityPairsVariant;
             lds_use = pairs ? rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_leaves,
                                                   c->bvh.n_slots, c->bvh.stack_depth, 256)
                             : rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
@@ -633,6 +633,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
                     hipGetErrorString(e), grid.x, grid.y, lds_use);
     c->current_sample += n_samples;
     c->launches += 1;
+    c->last_kernel = use_fast_table ? rt::fast_variant_name(variant) : rt::parity_variant_name(variant);
     if (p.tile_cost && n_samples >= 4) {
         c->cost_valid = true;
         c->cost_tiles = n_tiles;
@@ -952,6 +953,8 @@ RT_API void rt_destroy(rt_ctx *c) {
     }
     delete c;
 }
+
+RT_API const char *rt_last_kernel(const rt_ctx *c) { return !c ? "" : (c->multi ? rt::multi_last_kernel(c) : c->last_kernel); }
 
 RT_API int rt_shard_count(const rt_ctx *c) { return !c ? RT_ERR_ARG : (c->multi ? rt::multi_shards(c) : 1); }
 

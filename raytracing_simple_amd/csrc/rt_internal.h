@@ -70,6 +70,7 @@ struct rt_ctx {
     int n_cus = 256;
     int current_sample = 0;
     uint64_t launches = 0;
+    const char *last_kernel = "";       // symbol of the instance the last launch used
     double last_ms = 0.0;
     unsigned long long debug_counters[24] = {};   // diagnostic instances only
     hipStream_t stream = nullptr;       // the context's own (non-blocking) stream
@@ -112,6 +113,7 @@ int multi_device_pixels(rt_ctx *front, void **dptr, size_t *count);
 int multi_pin_output(rt_ctx *front, uint32_t *out_host, size_t count);
 void *multi_stream(rt_ctx *front);
 int multi_shards(const rt_ctx *front);
+const char *multi_last_kernel(const rt_ctx *front);
 int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg);
 
 }  // namespace rt

@@ -1,7 +1,7 @@
 // rt_kernel_fast.hip -- fused-arithmetic instances of the path-trace kernel
 // (-ffp-contract=fast, hardware rcp/rsq/sqrt/sin/cos/exp2/log2).  Gated by PSNR >= 50 dB
 // against the parity instance at equal spp (tests/test_gpu_parity.py).
-//   [0] rt_trace_fast, [3] rt_trace_fast_coop, [6] rt_trace_fast_w1, [7] rt_trace_fast_coop_w1, [8] rt_trace_fast_bvh: shipped; the
+//   [0] rt_trace_fast, [3] rt_trace_fast_coop, [6] rt_trace_fast_w1, [7] rt_trace_fast_coop_w1, [10] rt_trace_fast_pairs: shipped; the
 //   others are A/B shapes (mode 200+k) of the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1).
 #define RT_FAST 1
 #ifndef RT_DIAGNOSTICS
@@ -48,6 +48,13 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_pairs
+#define RT_KERNEL_NAME rt_trace_fast_pairs
+#define RT_OPT_BVH 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#if RT_DIAGNOSTICS
 #define RT_NS fast_bvh
 #define RT_KERNEL_NAME rt_trace_fast_bvh
 #define RT_OPT_BVH 1
@@ -60,13 +67,6 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS fast_pairs
-#define RT_KERNEL_NAME rt_trace_fast_pairs
-#define RT_OPT_BVH 6
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#if RT_DIAGNOSTICS
 #define RT_NS fast_persist
 #define RT_KERNEL_NAME rt_trace_fast_persist
 #define RT_OPT_PERSIST 1
@@ -101,13 +101,27 @@ static KernelFn const kFastKernels[] = {
 #endif
     fast_w1::rt_trace_fast_w1,                       // 6 = kFastW1Variant
     fast_coop_w1::rt_trace_fast_coop_w1,             // 7 = kFastCoopW1Variant
-    fast_bvh::rt_trace_fast_bvh,                     // 8 = kFastBvhVariant
+#if RT_DIAGNOSTICS
+    fast_bvh::rt_trace_fast_bvh,                     // 8 = kFastBvhVariant     A/B forms of the hierarchy walk
     fast_walk::rt_trace_fast_walk,                   // 9 = kFastWalkVariant
-    fast_pairs::rt_trace_fast_pairs,                 // 10 = kFastPairsVariant
+#else
+    nullptr, nullptr,
+#endif
+    fast_pairs::rt_trace_fast_pairs,                 // 10 = kFastPairsVariant  shipped: large scenes
 };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 
 int fast_variant_count() { return kFastCount; }
+const char *fast_variant_name(int variant) {
+    switch (variant) {
+        case 0: return "rt_trace_fast";
+        case kFastCoopVariant: return "rt_trace_fast_coop";
+        case kFastW1Variant: return "rt_trace_fast_w1";
+        case kFastCoopW1Variant: return "rt_trace_fast_coop_w1";
+        case kFastPairsVariant: return "rt_trace_fast_pairs";
+        default: return "rt_trace_fast (a diagnostics instance)";
+    }
+}
 int fast_variant_waves(int variant) { return (variant == kFastW1Variant || variant == kFastCoopW1Variant) ? 1 : 4; }
 
 hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {

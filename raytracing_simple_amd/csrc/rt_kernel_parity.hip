@@ -2,7 +2,7 @@
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
 //   [0] rt_trace_parity, [10] rt_trace_parity_w1            shipped: small scenes (4-wave / single-wave workgroups)
 //   [4] rt_trace_parity_coop, [11] rt_trace_parity_coop_w1  shipped: scenes with >= 12 spheres (cooperative any-hit)
-//   [12] rt_trace_parity_bvh                                shipped: scenes with many small spheres (hierarchy)
+//   [17] rt_trace_parity_pairs                              shipped: scenes with many small spheres (hierarchy, rt_walk.inc.h)
 //   (rt_api.hip launch() takes the single-wavefront shape while the scene tables leave LDS room for 6 waves per SIMD)
 // Everything else exists only in the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1):
 // A/B and verification shapes of the same arithmetic (mode 100+k, tools/ab_bench.py) and the
@@ -54,22 +54,6 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS parity_bvh             /* large scenes: the small spheres in a hierarchy, walked per lane */
-#define RT_KERNEL_NAME rt_trace_parity_bvh
-#define RT_OPT_BVH 1
-#define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_MINWAVES 4
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_walk            /* ... with the walk as lane state that survives loop trips (rt_walk.inc.h) */
-#define RT_KERNEL_NAME rt_trace_parity_walk
-#define RT_OPT_BVH 4
-#define RT_OPT_LEAN_SQRT 1
-#define RT_OPT_MINWAVES 6
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
 #define RT_NS parity_pairs           /* ... over sibling pairs, nearer child first, the other on a per-lane stack */
 #define RT_KERNEL_NAME rt_trace_parity_pairs
 #define RT_OPT_BVH 6
@@ -79,6 +63,22 @@
 #include "rt_opts_reset.h"
 
 #if RT_DIAGNOSTICS
+#define RT_NS parity_bvh             /* A/B: depth-first nodes with skip links, walked to the end inside each closest-hit / shadow call */
+#define RT_KERNEL_NAME rt_trace_parity_bvh
+#define RT_OPT_BVH 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 4
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_walk            /* A/B: the same nodes, the walk as lane state (rt_walk.inc.h) */
+#define RT_KERNEL_NAME rt_trace_parity_walk
+#define RT_OPT_BVH 4
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_bvhv            /* the walk + the plain sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_bvhv
 #define RT_OPT_BVH 2
@@ -96,6 +96,13 @@
 #define RT_NS parity_walks           /* rt_walk.inc.h with a census of its two phases (counters[20..28]) */
 #define RT_KERNEL_NAME rt_trace_parity_walks
 #define RT_OPT_BVH 5
+#define RT_OPT_LEAN_SQRT 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairss          /* the pair walk with a census of its two phases (counters[20..28]) */
+#define RT_KERNEL_NAME rt_trace_parity_pairss
+#define RT_OPT_BVH 7
 #define RT_OPT_LEAN_SQRT 1
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
@@ -172,24 +179,33 @@ static KernelFn const kParityKernels[] = {
 #endif
     parity_w1::rt_trace_parity_w1,                      // 10 = kParityW1Variant
     parity_coop_w1::rt_trace_parity_coop_w1,            // 11 = kParityCoopW1Variant
-    parity_bvh::rt_trace_parity_bvh,                    // 12 = kParityBvhVariant
 #if RT_DIAGNOSTICS
-    parity_bvhv::rt_trace_parity_bvhv,                  // 13 = kParityBvhCheckVariant
-    parity_bvhs::rt_trace_parity_bvhs,                  // 14   census of the walk
-#else
-    nullptr, nullptr,
-#endif
-    parity_walk::rt_trace_parity_walk,                  // 15 = kParityWalkVariant
-#if RT_DIAGNOSTICS
+    parity_bvh::rt_trace_parity_bvh,                    // 12 = kParityBvhVariant     A/B: walk per call
+    parity_bvhv::rt_trace_parity_bvhv,                  // 13 = kParityBvhCheckVariant    ... with the plain sweep beside it
+    parity_bvhs::rt_trace_parity_bvhs,                  // 14   ... with a census of its steps
+    parity_walk::rt_trace_parity_walk,                  // 15 = kParityWalkVariant    A/B: walk as lane state, depth-first nodes
     parity_walks::rt_trace_parity_walks,                // 16   its census
 #else
-    nullptr,
+    nullptr, nullptr, nullptr, nullptr, nullptr,
 #endif
-    parity_pairs::rt_trace_parity_pairs,                // 17 = kParityPairsVariant
+    parity_pairs::rt_trace_parity_pairs,                // 17 = kParityPairsVariant   shipped: large scenes
+#if RT_DIAGNOSTICS
+    parity_pairss::rt_trace_parity_pairss,              // 18   its census
+#endif
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
 int parity_variant_count() { return kParityCount; }
+const char *parity_variant_name(int variant) {
+    switch (variant) {
+        case 0: return "rt_trace_parity";
+        case kParityCoopVariant: return "rt_trace_parity_coop";
+        case kParityW1Variant: return "rt_trace_parity_w1";
+        case kParityCoopW1Variant: return "rt_trace_parity_coop_w1";
+        case kParityPairsVariant: return "rt_trace_parity_pairs";
+        default: return "rt_trace_parity (a diagnostics instance)";
+    }
+}
 int parity_variant_waves(int variant) { return (variant == kParityW1Variant || variant == kParityCoopW1Variant) ? 1 : 4; }
 
 hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream) {

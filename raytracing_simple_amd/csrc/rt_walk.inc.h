@@ -149,7 +149,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     uint32_t lj = 0;
     float l_k = 0.f;
     unsigned long long unused_roots = 0;
-#if RT_OPT_BVH == 5
+#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
     // census instance: wave-level trips and lane participation of the two phases, and where the clock goes
     unsigned long long cen[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #define RT_WALK_COUNT(k)                                                                         \
@@ -171,7 +171,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
     for (;;) {
         if (st == kNew && s >= s_end) break;
-#if RT_OPT_BVH == 5
+#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
         const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
 #endif
@@ -292,7 +292,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         }
 #endif
 
-#if RT_OPT_BVH == 5
+#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
         RT_WALK_CLOCK(6, t_trip);
         const unsigned long long t_s = __builtin_amdgcn_s_memtime();
 #endif
@@ -476,11 +476,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 st = kClosest;
             }
         }
-#if RT_OPT_BVH == 5
+#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
         RT_WALK_CLOCK(7, t_s);
 #endif
     }
-#if RT_OPT_BVH == 5
+#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
     for (int k = 0; k < 9; ++k) {
         unsigned long long v = cen[k];
 #pragma unroll

@@ -173,3 +173,32 @@ def test_fast_mode_with_the_hierarchy_is_as_close_as_fast_mode_without():
         fast = _render(sph, cam, w, h, spp, form=form, mode=api.RT_MODE_FAST)
         assert fast["stats"]["samples"] == par["stats"]["samples"]
         assert host.psnr(fast["pixels"], par["pixels"]) >= min(50.0, base - 3.0)
+
+
+def test_last_kernel_names_the_instance_the_scene_got():
+    """rt_last_kernel: which instance the library picked (what a profiler will list)."""
+    w, h = 64, 48
+    with api.RtContext(w, h) as ctx:
+        assert ctx.last_kernel == ""
+        ctx.set_scene(host.demo_scene())
+        ctx.set_camera(host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h))
+        ctx.render_pass(2)
+        assert ctx.last_kernel == "rt_trace_parity_w1"
+        ctx.set_mode(api.RT_MODE_FAST)
+        ctx.render_pass(2)
+        assert ctx.last_kernel == "rt_trace_fast_w1"
+        ctx.set_mode(api.RT_MODE_PARITY)
+        sph, orig, target = scenes.demo_plus(16)
+        ctx.set_scene(sph)
+        ctx.render_pass(2)
+        assert ctx.last_kernel == "rt_trace_parity_coop_w1"
+        sph, orig, target = scenes.random_spheres(600)
+        ctx.set_scene(sph)
+        ctx.set_camera(host.compute_camera(orig, target, w, h))
+        ctx.reset()
+        ctx.render_pass(1)                    # the first pass of a new large scene walks the hierarchy,
+        assert ctx.last_kernel == "rt_trace_parity_pairs"
+        ctx.render_pass(1)                    # the second sweeps; the faster form renders the rest
+        assert ctx.last_kernel == "rt_trace_parity_coop"
+        ctx.render_pass(40)
+        assert ctx.last_kernel in ("rt_trace_parity_pairs", "rt_trace_parity_coop")

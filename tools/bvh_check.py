@@ -193,14 +193,14 @@ def census(sph, cam, w, h, spp):
     return out
 
 
-def census_walk(sph, cam, w, h, spp, steps=0, gate=0):
+def census_walk(sph, cam, w, h, spp, steps=0, gate=0, mode=116):
     """mode 116: the two phases of rt_walk.inc.h -- wave-level trips, lanes taking part, clock ticks"""
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, steps, gate, 2))
         ctx.set_scene(sph)
         ctx.set_camera(cam)
-        ctx.set_mode(116)
+        ctx.set_mode(mode)
         ctx.render_pass(spp)
         c = counters_raw(ctx)[20:29]
         st = ctx.stats()
@@ -244,8 +244,9 @@ def main():
                                       ("mirror_box_256", lambda: scenes.mirror_box(256), (480, 270, 16))]:
             sph, orig, target = mk()
             print("census", name, json.dumps(census(sph, host.compute_camera(orig, target, w, h), w, h, spp)), flush=True)
-            for steps, gate in ((64, 16), (16, 16), (16, 48)):
+            for steps, gate in ((64, 16), (16, 16)):
                 print("census_walk", name, steps, gate, json.dumps(census_walk(sph, host.compute_camera(orig, target, w, h), w, h, spp, steps, gate)), flush=True)
+                print("census_pairs", name, steps, gate, json.dumps(census_walk(sph, host.compute_camera(orig, target, w, h), w, h, spp, steps, gate, mode=118)), flush=True)
         return 0
     if args.timing_only:
         return timing(args, report)

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Quick timing of one form of the walk on the open scenes: python tools/bvh_quick.py [FORM] [STEPS] [GATE]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from raytracing_simple_amd import host, scenes
+import bvh_check
+form = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+gate = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+out = {}
+for name, n, spp in (("1024", 1024, 16), ("512", 512, 16), ("256", 256, 16), ("2048", 2048, 8), ("box256", -256, 16)):
+    sph, orig, target = scenes.random_spheres(n) if n > 0 else scenes.mirror_box(-n)
+    cam = host.compute_camera(orig, target, 1920, 1080)
+    t, px, st = bvh_check.timed(sph, cam, 1920, 1080, spp, 1, reps=3, walk=(steps, gate, form))
+    out[name] = round(t, 2)
+print("quick form", form, steps, gate, out)
