@@ -1,16 +1,17 @@
 #!/bin/bash
-# tools/profile_gpu.sh TAG MODE -- run on the GPU box (via gpurun): kernel-trace stats + separate
-# PMC passes of `bench.py --mode MODE` (C2 workload).  Writes CSVs under gpurun_out/TAG/.
+# tools/profile_gpu.sh TAG MODE [WORKLOAD] -- run on the GPU box (via gpurun): kernel-trace stats + separate
+# PMC passes of `bench.py --mode MODE --workload WORKLOAD` (default c2).  Writes CSVs under gpurun_out/TAG/.
 # PMC passes never combine with anything but --kernel-trace (pool rule).
 set -u
 TAG=${1:-prof}
 MODE=${2:-parity}
+WL=${3:-c2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --mode $MODE --steps 10 --warmup 3 --no-cpu --no-extras"
+BENCH="python3 $R/bench.py --mode $MODE --workload $WL --steps 10 --warmup 3 --no-cpu --no-extras"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {
   name=$1; shift

@@ -81,7 +81,8 @@ def main():
     with open(os.path.join(root, "profiles", out_name + ".json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     with open(os.path.join(root, "profiles", out_name + ".md"), "w") as f:
-        f.write(f"# {out_name}: rocprofv3 summary, bench.py --mode {mode} (C2: Demo, 1920x1080, 64 spp)\n\n")
+        label = sys.argv[5] if len(sys.argv) > 5 else "C2: Demo, 1920x1080, 64 spp"
+        f.write(f"# {out_name}: rocprofv3 summary, bench.py --mode {mode} ({label})\n\n")
         f.write("## --kernel-trace --stats\n\n" + "\n".join(lines) + "\n\n")
         f.write("## launch\n\n```\n" + json.dumps(summary.get("launch", {}), indent=1) + "\n```\n\n")
         f.write("## PMC, average per launch of the render kernel (separate passes)\n\n| counter | value |\n|---|---|\n")
