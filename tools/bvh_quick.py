@@ -14,5 +14,6 @@ for name, n, spp in (("1024", 1024, 16), ("512", 512, 16), ("256", 256, 16), ("2
     sph, orig, target = scenes.random_spheres(n) if n > 0 else scenes.mirror_box(-n)
     cam = host.compute_camera(orig, target, 1920, 1080)
     t, px, st = bvh_check.timed(sph, cam, 1920, 1080, spp, 1, reps=3, walk=(steps, gate, form))
-    out[name] = round(t, 2)
+    t0, px0, _ = bvh_check.timed(sph, cam, 1920, 1080, spp, 0, reps=2)
+    out[name] = (round(t, 2), "plain", round(t0, 2), "equal" if np.array_equal(px, px0) else "DIFFERENT")
 print("quick form", form, steps, gate, out)
