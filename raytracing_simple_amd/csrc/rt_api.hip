@@ -558,6 +558,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
         if (!per_call && c->regen_gate <= 0) p.regen_gate = c->walk_gate;
     }
     p.walk_steps = c->walk_steps;
+    p.walk_round = c->walk_round;
 #if RT_DIAGNOSTICS
     persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
     if (persist) variant = fast ? (coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant)
@@ -1412,6 +1413,11 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
 }
 static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
+static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v; return RT_OK; }
+RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
+    if (!c || steps < 1) return fail(RT_ERR_ARG, "steps %d", steps);
+    return dbg_apply(c, dbg_set_walk_round, steps);
+}
 
 static int dbg_set_walk_form(rt_ctx *c, int v) { c->walk_form = v; c->bvh_pick = 0; c->probe_state = 0; return RT_OK; }
 // rt_walk.inc.h: node tests per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and

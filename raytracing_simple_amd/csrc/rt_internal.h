@@ -36,7 +36,7 @@ struct rt_ctx {
     bool bvh_ok = false;                // the blob describes the current scene
     int bvh_min = 64;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 64 * 1024;      // ... while the instance's LDS stays below this
-    int walk_steps = 64, walk_gate = 16;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
+    int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
     int walk_form = 0;                  // 0 = measured choice (below); diagnostics: 1 = the walk-per-call form, 2 = the walk, unmeasured
     // hierarchy or plain sweep?  Decided per scene by measurement: the first launch of a new scene walks the
     // hierarchy, the second sweeps, both between events; whichever took less time per pass renders the rest

@@ -189,7 +189,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             const bool shadow = st == kShadow;
             uint16_t *my_stack = s_stack + tid;
             while (cur != kNone && budget > 0) {
-                while (cur < kBvhLeafRef && budget > 0) {
+                // at most P.walk_round pair steps, then the leaf step for whoever holds a leaf: a lane that is
+                // still looking goes on looking in the next round instead of keeping the others waiting (the
+                // number of steps to the next leaf has a long tail)
+                for (int round = P.walk_round; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
                     budget -= 1;
                     RT_WALK_COUNT(0);
                     const float4 *pp = s_pairs + 4u * cur;

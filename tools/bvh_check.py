@@ -215,7 +215,8 @@ def timed(sph, cam, w, h, spp, bvh_min, reps=3, mode=api.RT_MODE_PARITY, walk=(0
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 0))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, *walk))
-        assert not ratio
+        if ratio:
+            ctx._check(ctx._lib.rt_debug_set_walk_round(ctx._h, ratio))
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         ctx.set_mode(mode)
