@@ -202,3 +202,22 @@ def test_last_kernel_names_the_instance_the_scene_got():
         assert ctx.last_kernel == "rt_trace_parity_coop"
         ctx.render_pass(40)
         assert ctx.last_kernel in ("rt_trace_parity_pairs", "rt_trace_parity_coop")
+
+
+def test_multi_device_context_with_a_large_scene():
+    """Every shard builds its own hierarchy and measures its own choice; the assembled frames are the oracle's."""
+    sph, orig, target = scenes.random_spheres(300)
+    w, h = 96, 72
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h, devices=[0, 0, 0]) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        done = 0
+        for n in (1, 1, 2, 20):                  # the first two passes are the shards' probes
+            px = ctx.render_pass(n)
+            done += n
+            want = O.render(sph, cam, w, h, done)
+            assert np.array_equal(px, want["pixels"])
+        st = ctx.stats()
+        assert (st["samples"], st["sphere_tests"]) == (want["stats"]["samples"], want["stats"]["sphere_tests"])
+        assert np.array_equal(ctx.read_seeds(), want["seeds"])

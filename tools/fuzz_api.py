@@ -17,12 +17,14 @@ from raytracing_simple_amd import api, host, scenes
 from raytracing_simple_amd import dist as rdist
 
 SCENES = [lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), lambda: scenes.demo_plus(16),
-          lambda: scenes.random_spheres(40), lambda: scenes.mirror_box(20)]
+          lambda: scenes.random_spheres(40), lambda: scenes.mirror_box(20),
+          # large enough for the hierarchy: the first two launches of the sequence are its timing probes
+          lambda: scenes.random_spheres(150), lambda: scenes.mirror_box(90)]
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = []
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    sph, orig, target = SCENES[seed % 4]()
+    sph, orig, target = SCENES[seed % 6]()
     w, h = int(rng.integers(9, 90)), int(rng.integers(5, 70))
     cam = host.compute_camera(orig, target, w, h)
     nranks = int(rng.choice([1, 1, 2, 3]))
