@@ -1310,7 +1310,7 @@ RT_API int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out,
         if (r == RT_OK) r = rt_set_pixel_buffer(c, nullptr, 0);
         if (r == RT_OK) r = rt_set_scene(c, scene->spheres, scene->count);
         if (r == RT_OK) r = rt_set_camera(c, cam);
-        if (r == RT_OK) r = rt_render_async(c, spp, c->stream);
+        if (r == RT_OK) r = launch(c, spp, c->stream, true);        // (blocking call: a new large scene may be probed first)
         if (r != RT_OK) return r;
         if (spp == 0) {                 // no pass ran: getPixels() of a fresh backend is the zero-filled buffer
             HIP_TRY(hipStreamSynchronize(c->stream));

@@ -221,3 +221,18 @@ def test_multi_device_context_with_a_large_scene():
         st = ctx.stats()
         assert (st["samples"], st["sphere_tests"]) == (want["stats"]["samples"], want["stats"]["sphere_tests"])
         assert np.array_equal(ctx.read_seeds(), want["seeds"])
+
+
+def test_headline_call_on_a_large_scene():
+    """rt_render(scene, cam, out, w, h, spp): a blocking call, so a new large scene is probed inside it; repeated
+    calls with the same scene reuse the verdict.  Either way the frame is the oracle's."""
+    sph, orig, target = scenes.random_spheres(220)
+    w, h, spp = 88, 56, 18
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)["pixels"]
+    for _ in range(3):
+        assert np.array_equal(api.render(sph, cam, w, h, spp), want)
+    box, orig, target = scenes.mirror_box(100)
+    cam = host.compute_camera(orig, target, w, h)
+    assert np.array_equal(api.render(box, cam, w, h, spp), O.render(box, cam, w, h, spp)["pixels"])
+    api.load_library().rt_release_cache()
