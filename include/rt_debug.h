@@ -41,6 +41,11 @@ RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
 RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int form);   /* node tests per lane per loop trip; ready lanes that make a wavefront shade; form 0 = hierarchy or plain sweep by measurement (default), 1 = always the walk-per-call form, 2 = always the walk */
 RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a lane takes in a row before the leaf step of the lanes that hold a leaf (default 3; large = until every lane has one) */
+/* n_rays rays { o.xyz, t_max, d.xyz, shadow != 0 } (8 floats each; the last as a bit pattern) through the hierarchy walk
+ * AND the plain sweep, one lane per ray; out4 (4 words per ray) = the walk's answer, then the sweep's -- closest hit:
+ * distance bits and scene index (~0 for a miss); shadow ray: the first blocking scene index (the sphere count for
+ * none) and 0.  The two must be equal for every ray whatever its origin and direction. */
+RT_API int rt_debug_walk_rays(rt_ctx *ctx, const float *rays8, uint32_t n_rays, uint32_t *out4);
 RT_API int rt_debug_bvh_pick(rt_ctx *ctx);   /* 0 = not decided yet, 1 = the hierarchy, 2 = the plain sweep (of this scene, by measurement) */
 RT_API int rt_debug_read_bvh(rt_ctx *ctx, float *blob_out, uint32_t cap_float4, uint32_t *counts4);
 RT_API int rt_debug_set_wg_waves(rt_ctx *ctx, int waves);          /* 0 = automatic, 1 or 4 wavefronts per workgroup */

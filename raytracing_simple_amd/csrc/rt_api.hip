@@ -1429,6 +1429,34 @@ RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int per_call) {
     if (rc == RT_OK) rc = dbg_apply(c, dbg_set_walk_gate, gate);
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_form, per_call);
 }
+// rays8[i] = { o.xyz, t_max, d.xyz, shadow != 0 } through the hierarchy walk and through the plain sweep (csrc/rt_walk.inc.h
+// rt_walk_rays kernel); out4[i] = the walk's answer, then the sweep's (closest: distance bits, scene index; shadow: first
+// blocking index, 0)
+RT_API int rt_debug_walk_rays(rt_ctx *c, const float *rays8, uint32_t n_rays, uint32_t *out4) {
+    if (!c || c->multi || !rays8 || !out4) return fail(RT_ERR_ARG, "null / multi-device context");
+    if (!c->bvh_ok) return fail(RT_ERR_STATE, "the scene has no hierarchy (rt_debug_set_bvh)");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    if (!c->have_cam) c->cam = rt_camera{};
+    rt::LaunchParams p = make_params(c, 1);
+    p.bvh = c->bvh;
+    const size_t lds = rt::lds_bytes_pairs(0, 0, false, 0, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
+    if (lds > 152 * 1024) return fail(RT_ERR_ARG, "tables need %zu B of LDS", lds);
+    float4 *d_rays = nullptr;
+    uint4 *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_rays, (size_t)n_rays * 32 + 32));
+    hipError_t e = hipMalloc(&d_out, (size_t)n_rays * 16 + 16);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays8, (size_t)n_rays * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt::launch_walk_rays(p, d_rays, n_rays, d_out, lds, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out4, d_out, (size_t)n_rays * 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_walk_rays: %s", hipGetErrorString(e));
+    return RT_OK;
+}
 RT_API int rt_debug_bvh_pick(rt_ctx *c) {
     if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
     if (select_device(c) == RT_OK) probe_poll(c, false);

@@ -144,6 +144,7 @@ int parity_variant_count();
 int fast_variant_count();
 const char *parity_variant_name(int variant);   // the kernel's symbol (what rocprofv3 lists), for rt_last_kernel
 const char *fast_variant_name(int variant);
+hipError_t launch_walk_rays(const LaunchParams &p, const float4 *rays, uint32_t n_rays, uint4 *out, size_t lds, hipStream_t stream);   // diagnostics
 hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream, int which = 0);
 hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream);
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream);

@@ -56,6 +56,7 @@
 
 #define RT_NS parity_pairs           /* ... over sibling pairs, nearer child first, the other on a per-lane stack */
 #define RT_KERNEL_NAME rt_trace_parity_pairs
+#define RT_WALK_RAYS_KERNEL_NAME rt_walk_rays_parity   /* diagnostics build: rays through the walk and the sweep */
 #define RT_OPT_BVH 6
 #define RT_OPT_LEAN_SQRT 1
 #define RT_OPT_MINWAVES 5
@@ -222,6 +223,16 @@ hipError_t launch_pack_parity(const LaunchParams &p, hipStream_t stream) {
 }
 
 #if RT_DIAGNOSTICS
+hipError_t launch_walk_rays(const LaunchParams &p, const float4 *rays, uint32_t n_rays, uint4 *out, size_t lds, hipStream_t stream) {
+    if (n_rays == 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(parity_pairs::rt_walk_rays_parity),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (n_rays + 255) / 256 < 512 ? (n_rays + 255) / 256 : 512;
+    hipLaunchKernelGGL(parity_pairs::rt_walk_rays_parity, dim3(blocks), dim3(256), lds, stream, p, rays, n_rays, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_eval_parity(int op, const float *in, float *out, size_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(parity::rt_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,

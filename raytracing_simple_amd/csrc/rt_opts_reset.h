@@ -22,3 +22,4 @@
 #undef RT_PACK_KERNEL_NAME
 #undef RT_OPT_WG_WAVES
 #undef RT_OPT_BVH
+#undef RT_WALK_RAYS_KERNEL_NAME

@@ -585,13 +585,12 @@ RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d
 //               = r^2 + e + 2 th det + tau^2 (dd - 1) + 2 tau db,      |tau| <= OP + |r|, tau^2 <= 2 M^2,
 // so |X - p|^2 <= r^2 + (19u + 2 |dd - 1|) M^2 <= r^2 + eps with eps := (64u + 4 |dd - 1|) M^2: X lies within
 // |r| + min(sqrt(eps), eps / 2|r|) of the centre -- inside the sphere's box grown by that `pad` -- at a ray parameter
-// in (0, t_max].  (The rounding of t itself, of p - o and of the shifted origin below move X by a few u (OP + |o|),
-// which the linear term of the pad covers eight times over.)  The walk therefore tests each node's box, grown by
+// in (0, t_max].  (The rounding of t itself and of p - o move X by at most 3u (OP + |o|); together with the slab
+// arithmetic's own rounding, bvh_misses below, that is an eighth of the linear term 64u (|o| + OP + |r|) of the pad.)  The walk therefore tests each node's box, grown by
 // `pad`, against the stretch [-pad, t_max + pad] of the ray, with OP bounded by the distance to the far side of the
-// root box and |r| by the largest radius in the tree; the slab arithmetic itself is made one-sided by widening its
-// results by 2^-20 relative (16 ulps against the four roundings of a slab distance and the 1-ulp v_rcp_f32).  A
-// lane whose direction is not a unit vector to within 10^-3, or not finite, gets an infinite pad: it visits
-// everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
+// root box and |r| by the largest radius in the tree; the slab arithmetic's own rounding is inside the pad's linear
+// term (bvh_misses below).  A lane whose direction is not a unit vector to within 10^-3, or not finite, gets an
+// infinite pad: it visits everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
 #if RT_OPT_BVH == 3
 struct BvhCount {                // census instance: [0] node steps of the wavefront, [1] node tests of this lane, [2]/[3] the same for leaves
     uint32_t v[4];
@@ -607,7 +606,7 @@ struct BvhCount {};
 #define RT_BVH_COUNT(C, k)
 #endif
 struct BvhRay {
-    V3 olo, ohi, inv;      // origin shifted by +-pad; 1 / direction
+    V3 clo, chi, inv;      // 1 / direction and -(origin +- pad) / direction: a slab distance is one fused multiply-add
     float tback;           // how far behind the origin / beyond the current best a box still counts
 };
 RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
@@ -619,33 +618,125 @@ RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
     const float skew = fabsf(dd - 1.f);
     const float eps = (64.f * u + 4.f * skew) * (far * far + h1.y * h1.y);
     float pad = fminf(__builtin_amdgcn_sqrtf(eps), eps * h1.z);                 // sqrt(r^2 + eps) - r, from above
-    pad = pad * 1.01f + 32.f * u * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far + h1.y);
+    pad = pad * 1.01f + 64.f * u * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far + h1.y);
     float tback = pad + 1e-6f * far;
-    const bool sane = skew < 1e-3f;                                             // false for NaN
+    // (the products below must stay finite: origins and trees beyond 10^18 are walked in full as well)
+    const bool sane = (skew < 1e-3f) & (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far < 1e18f);    // false for NaN
     pad = sane ? pad : inf;
     tback = sane ? tback : inf;
     BvhRay R;
-    R.olo = mk(o.x + pad, o.y + pad, o.z + pad);
-    R.ohi = mk(o.x - pad, o.y - pad, o.z - pad);
-    R.inv = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    // A direction component of (nearly) zero -- cosine-weighted bounces off an axis-aligned normal produce exact
+    // zeros a dozen times per frame -- is taken as +-10^-18: the ray then misses its true line by 10^-18 per unit of
+    // length, and 1 / d and the products with it stay finite (an infinite 1 / d would turn both slab distances of
+    // an axis into the same infinity, or into NaN, whichever side of the slab the origin is on).
+    const float tiny = 1e-18f;
+    R.inv = mk(__builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.x), tiny), d.x)),
+               __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.y), tiny), d.y)),
+               __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.z), tiny), d.z)));
+    R.clo = mk(-(o.x + pad) * R.inv.x, -(o.y + pad) * R.inv.y, -(o.z + pad) * R.inv.z);
+    R.chi = mk(-(o.x - pad) * R.inv.x, -(o.y - pad) * R.inv.y, -(o.z - pad) * R.inv.z);
     R.tback = tback;
     return R;
 }
-// true when the ray stretch [-tback, t_far + tback] misses the grown box for certain
+// True when the ray stretch [-tback, t_far + tback] misses the grown box for certain.  A slab distance is
+// fma(plane, 1/d, -(o +- pad)/d): the plane this computed distance really belongs to -- o +- pad + t d, exactly -- lies
+// within  4u |plane - o| + 2u |o|  of the box's (one ulp of v_rcp_f32, the rounded shifted origin, its rounded product,
+// the fused operation's own rounding), which the pad's linear term covers with the rest (above); so the point X of
+// the derivation above, which is inside the grown box by that margin, is between the computed planes on every axis and
+// its parameter inside [tn, tf].  Minimum and maximum drop NaN operands (a direction component of 0 against a plane
+// through the origin): that axis then does not constrain.
 RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far, float &t_near) {
-    const float x0 = (A.x - R.olo.x) * R.inv.x, x1 = (B.x - R.ohi.x) * R.inv.x;
-    const float y0 = (A.y - R.olo.y) * R.inv.y, y1 = (B.y - R.ohi.y) * R.inv.y;
-    const float z0 = (A.z - R.olo.z) * R.inv.z, z1 = (B.z - R.ohi.z) * R.inv.z;
-    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -R.tback));
-    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
-    tn = __builtin_fmaf(-fabsf(tn), 0x1p-20f, tn);
-    tf = __builtin_fmaf(fabsf(tf), 0x1p-20f, tf);
+    const float x0 = __builtin_fmaf(A.x, R.inv.x, R.clo.x), x1 = __builtin_fmaf(B.x, R.inv.x, R.chi.x);
+    const float y0 = __builtin_fmaf(A.y, R.inv.y, R.clo.y), y1 = __builtin_fmaf(B.y, R.inv.y, R.chi.y);
+    const float z0 = __builtin_fmaf(A.z, R.inv.z, R.clo.z), z1 = __builtin_fmaf(B.z, R.inv.z, R.chi.z);
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -R.tback));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
     t_near = tn;                        // where the ray enters the grown box (an ordering hint, nothing more)
     return tn > tf;
 }
 RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
     float unused;
     return bvh_misses(R, A, B, t_far, unused);
+}
+
+// ---- the walk over sibling pairs (rt_device.h BvhTables `pairs`), nearer child first ----
+// One step loads a pair (64 bytes), tests both boxes against the ray's stretch, goes on with the nearer of the
+// children that are hit and keeps the other on the lane's stack (16 bits per entry, [level][lane]); with neither hit
+// it takes the last kept one.  Which child comes first only decides how soon the bound shrinks: every sphere whose
+// chain of boxes the ray meets is still tested, so the result is the same set of candidates run through the same rule.
+// Shadow rays look for the LOWEST blocking scene index (that is what .cl:234-247 returns at): a subtree that only
+// holds higher indices than the best so far is skipped.  The walk's place (cur, sp) and its result so far (w_far,
+// w_idx, w_slot) are the caller's: `budget` pair steps at most per call, the rest next time.  At most `round_len`
+// pair steps are taken in a row before the leaf step of the lanes that hold a leaf -- a lane that is still looking
+// goes on looking in the next round instead of keeping the others waiting (the number of steps to the next leaf has
+// a long tail).  cen (census instances only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps.
+constexpr uint32_t kWalkDone = 0xffffffffu;
+RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
+                       uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
+                       int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen) {
+    const int lane_ = threadIdx.x & 63;
+    while (cur != kWalkDone && budget > 0) {
+        for (int round = round_len; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
+            budget -= 1;
+            if (cen) {
+                const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
+                if (lane_ == __ffsll((long long)act_) - 1) cen[0] += 1ull;
+                cen[1] += 1ull;
+            }
+            const float4 *pp = s_pairs + 4u * cur;
+            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
+            float tn0, tn1;
+            const bool m0 = bvh_misses(R, A0, B0, w_far, tn0) | (shadow & (__float_as_uint(B0.w) > w_idx));
+            const bool m1 = bvh_misses(R, A1, B1, w_far, tn1) | (shadow & (__float_as_uint(B1.w) > w_idx));
+            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
+            const bool both = !m0 & !m1, none = m0 & m1;
+            const bool second_first = both ? (tn1 < tn0) : m0;
+            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
+            if (both) {
+                my_stack[sp * stack_stride] = (uint16_t)far;
+                sp += 1;
+            }
+            if (none) {
+                sp -= 1;
+                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+                sp = sp < 0 ? 0 : sp;
+            } else {
+                cur = near;
+            }
+        }
+        if (cur != kWalkDone && cur >= kBvhLeafRef) {
+            if (cen) {
+                const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
+                if (lane_ == __ffsll((long long)act_) - 1) cen[2] += 1ull;
+                cen[3] += 1ull;
+            }
+            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
+            HitPre p[kBvhLeaf];
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) {
+                if (p[k].det >= 0.f) {
+                    const HitRoots hr = hit_roots(p[k]);
+                    // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
+                    // shadow ray (.cl:234-247): the lowest scene index that blocks
+                    if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
+                        const uint32_t ix = index[sl + k];
+                        if (shadow) {
+                            w_idx = ix < w_idx ? ix : w_idx;
+                        } else if (hr.t < w_far || ix < w_idx) {
+                            w_far = hr.t;
+                            w_slot = sl + (uint32_t)k;
+                            w_idx = ix;
+                        }
+                    }
+                }
+            }
+            sp -= 1;
+            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+            sp = sp < 0 ? 0 : sp;
+        }
+    }
 }
 
 // closest hit among the spheres of the tree, .cl:215-232 restated: (t, idx) only ever moves to a smaller distance

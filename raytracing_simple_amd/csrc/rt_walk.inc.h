@@ -45,7 +45,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
     float4 *s_lightA = s_slots + n_slots + stack_f4;     // {centre, radius}
     const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
-    constexpr uint32_t kNone = 0xffffffffu;
+    constexpr uint32_t kNone = kWalkDone;
 #else
     // staged: hdr | nodes | slots of rt_device.h BvhTables, as they lie
     float4 *s_nodes = s_hdr + 2;
@@ -178,71 +178,15 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
         // ---- T: walk ----
 #if RT_OPT_WALK_PAIRS
-        // Sibling pairs, nearer child first: one step loads a pair (64 bytes), tests both boxes against the ray's
-        // stretch, goes on with the nearer of the children that are hit and keeps the other on the lane's stack;
-        // with neither hit it takes the last kept one.  Which child comes first only decides how soon the bound
-        // shrinks -- every sphere whose box chain the ray meets is still tested, so the result is the same set of
-        // candidates run through the same rule.  (Shadow rays keep looking for the lowest blocking index: a subtree
-        // that only holds higher indices than the best so far is skipped.)
+        // (walk_pairs in rt_trace.inc.h: up to P.walk_steps pair steps of this lane's walk, leaf steps in between)
         if (cur != kNone) {
-            int budget = P.walk_steps;
-            const bool shadow = st == kShadow;
-            uint16_t *my_stack = s_stack + tid;
-            while (cur != kNone && budget > 0) {
-                // at most P.walk_round pair steps, then the leaf step for whoever holds a leaf: a lane that is
-                // still looking goes on looking in the next round instead of keeping the others waiting (the
-                // number of steps to the next leaf has a long tail)
-                for (int round = P.walk_round; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
-                    budget -= 1;
-                    RT_WALK_COUNT(0);
-                    const float4 *pp = s_pairs + 4u * cur;
-                    const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
-                    float tn0, tn1;
-                    const bool m0 = bvh_misses(R, A0, B0, w_far, tn0) | (shadow & (__float_as_uint(B0.w) > w_idx));
-                    const bool m1 = bvh_misses(R, A1, B1, w_far, tn1) | (shadow & (__float_as_uint(B1.w) > w_idx));
-                    const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
-                    const bool both = !m0 & !m1, none = m0 & m1;
-                    const bool second_first = both ? (tn1 < tn0) : m0;
-                    const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
-                    if (both) {
-                        my_stack[sp * kBlockThreads] = (uint16_t)far;
-                        sp += 1;
-                    }
-                    if (none) {
-                        sp -= 1;
-                        cur = sp >= 0 ? (uint32_t)my_stack[sp * kBlockThreads] : kNone;
-                        sp = sp < 0 ? 0 : sp;
-                    } else {
-                        cur = near;
-                    }
-                }
-                if (cur != kNone && cur >= kBvhLeafRef) {
-                    RT_WALK_COUNT(2);
-                    const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-                    HitPre p[kBvhLeaf];
-#pragma unroll
-                    for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
-#pragma unroll
-                    for (int k = 0; k < kBvhLeaf; ++k) {
-                        if (p[k].det >= 0.f) {
-                            const HitRoots hr = hit_roots(p[k]);
-                            if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
-                                const uint32_t ix = s_index[sl + k];
-                                if (shadow) {
-                                    w_idx = ix < w_idx ? ix : w_idx;
-                                } else if (hr.t < w_far || ix < w_idx) {
-                                    w_far = hr.t;
-                                    w_slot = sl + (uint32_t)k;
-                                    w_idx = ix;
-                                }
-                            }
-                        }
-                    }
-                    sp -= 1;
-                    cur = sp >= 0 ? (uint32_t)my_stack[sp * kBlockThreads] : kNone;
-                    sp = sp < 0 ? 0 : sp;
-                }
-            }
+#if RT_OPT_BVH == 7
+            unsigned long long *cen_p = cen;
+#else
+            unsigned long long *cen_p = nullptr;
+#endif
+            walk_pairs(s_pairs, s_slots, s_index, s_stack + tid, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_steps,
+                       P.walk_round, cur, sp, w_far, w_idx, w_slot, cen_p);
         }
 #else
         if (node < n_nodes) {
@@ -531,3 +475,75 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
+
+#if RT_OPT_BVH == 6 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
+// Diagnostics (rt_debug_walk_rays): arbitrary rays through the walk AND through the plain sweep over the full table,
+// one lane per ray -- the unit test of the one-sided culling with rays a path tracer produces once in 10^8 (exact
+// zeros and denormals in the direction, origins on box planes, far away, non-unit and non-finite directions).
+//   rays[2i] = { o.xyz, t_max }, rays[2i+1] = { d.xyz, bits(shadow) }
+//   out[i]   = closest: { bits(t) or ~0, scene index or ~0 } of the walk, then of the sweep;
+//              shadow:  { first blocking index or n, 0 } of the walk, then of the sweep
+extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const LaunchParams P, const float4 *rays, uint32_t n_rays,
+                                                                            uint4 *out) {
+    constexpr int kThreads = 256;
+    extern __shared__ float4 lds[];
+    const uint32_t n = P.scene.n_spheres, n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
+    const uint32_t *g_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + 2u + 2u * n_nodes + n_slots);
+    float4 *s_hdr = lds;
+    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
+    float4 *s_pairs = s_hdr + 2;
+    float4 *s_slots = s_pairs + 4 * n_pairs;
+    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
+    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
+    const int tid = threadIdx.x;
+    if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
+    {
+        const float4 *g_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
+        const float4 *g_slots = P.bvh.blob + 2u + 2u * n_nodes;
+        for (uint32_t i = tid; i < 4u * n_pairs; i += kThreads) s_pairs[i] = g_pairs[i];
+        for (uint32_t i = tid; i < n_slots; i += kThreads) s_slots[i] = g_slots[i];
+    }
+    __syncthreads();
+    const uint32_t rounds = (n_rays + gridDim.x * kThreads - 1) / (gridDim.x * kThreads);
+    for (uint32_t k = 0; k < rounds; ++k) {                 // (every lane takes part in every round: the sweeps use wave ballots)
+        const uint32_t i = (k * gridDim.x + blockIdx.x) * kThreads + (uint32_t)tid;
+        const bool live = i < n_rays;
+        const float4 ra = live ? rays[2 * i] : make_float4(0.f, 0.f, 0.f, 1.f);
+        const float4 rb = live ? rays[2 * i + 1] : make_float4(0.f, 0.f, 1.f, 0.f);
+        const V3 o = mk(ra.x, ra.y, ra.z), d = mk(rb.x, rb.y, rb.z);
+        const bool shadow = __float_as_uint(rb.w) != 0u;
+        unsigned long long roots = 0;
+        uint4 res;
+        const BvhRay R = bvh_ray(s_hdr, o, d);
+        uint32_t cur = root_ref, w_slot = 0, w_idx;
+        int sp = 0;
+        float w_far;
+        // the two kinds of ray diverge here; each sweep's ballots see the lanes of its own kind
+        if (shadow) {
+            const uint32_t first_large = sweep_any(s_slots, n_always, o, d, ra.w, roots);
+            w_idx = first_large < n_always ? g_index[first_large] : n;
+            w_far = ra.w;
+            walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, true, 0x7fffffff, 3, cur, sp, w_far, w_idx,
+                       w_slot, nullptr);
+            const uint32_t ref = sweep_any(P.scene.geom, n, o, d, ra.w, roots);
+            res = make_uint4(w_idx, 0u, ref, 0u);
+        } else {
+            float t = 1e20f;
+            uint32_t slot = 0;
+            sweep_closest(s_slots, n_always, o, d, t, slot, roots);
+            w_far = t;
+            w_slot = slot;
+            w_idx = (t < 1e20f) ? g_index[slot] : 0xffffffffu;
+            walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, false, 0x7fffffff, 3, cur, sp, w_far, w_idx,
+                       w_slot, nullptr);
+            float t_ref = 1e20f;
+            uint32_t id_ref = 0;
+            sweep_closest(P.scene.geom, n, o, d, t_ref, id_ref, roots);
+            const bool hit = w_far < 1e20f, hit_ref = t_ref < 1e20f;
+            res = make_uint4(hit ? __float_as_uint(w_far) : 0xffffffffu, hit ? w_idx : 0xffffffffu,
+                             hit_ref ? __float_as_uint(t_ref) : 0xffffffffu, hit_ref ? id_ref : 0xffffffffu);
+        }
+        if (live) out[i] = res;
+    }
+}
+#endif

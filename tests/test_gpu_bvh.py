@@ -236,3 +236,70 @@ def test_headline_call_on_a_large_scene():
     cam = host.compute_camera(orig, target, w, h)
     assert np.array_equal(api.render(box, cam, w, h, spp), O.render(box, cam, w, h, spp)["pixels"])
     api.load_library().rt_release_cache()
+
+
+def _adversarial_rays(sph, rng, n):
+    """Rays a path tracer produces once in 10^8 samples, by the thousand: exact zeros and denormals in the
+    direction, origins on box planes and sphere surfaces, inside spheres, far away; tangent rays; directions that are
+    not unit vectors, zero, or not finite."""
+    c = np.ascontiguousarray(sph["p"]).astype(np.float64)
+    r = np.abs(sph["rad"].astype(np.float64))
+    ok = np.isfinite(c).all(1) & np.isfinite(r) & (r < 500)
+    c, r = c[ok], r[ok]
+    lo, hi = c.min(0) - 5, c.max(0) + 5
+    rays = np.zeros((n, 8), np.float32)
+    for i in range(n):
+        kind = i % 12
+        j = int(rng.integers(0, len(c)))
+        o = rng.uniform(lo, hi)
+        d = rng.normal(0, 1, 3)
+        d /= np.linalg.norm(d)
+        if kind == 1:                                   # axis-aligned: two exact zeros
+            d = np.zeros(3); d[int(rng.integers(0, 3))] = rng.choice([-1.0, 1.0])
+        elif kind == 2:                                 # one exact zero
+            d[int(rng.integers(0, 3))] = 0.0; d /= np.linalg.norm(d)
+        elif kind == 3:                                 # denormal / tiny components
+            k = int(rng.integers(0, 3)); d[k] = rng.choice([1e-40, -1e-42, 1e-30, -1e-20, 1e-12])
+        elif kind == 4:                                 # origin exactly on a box plane of sphere j, sliding along it
+            k = int(rng.integers(0, 3)); o = c[j].copy(); o[k] += rng.choice([-1.0, 1.0]) * r[j]
+            o[(k + 1) % 3] -= 3 * r[j]
+            d = np.zeros(3); d[(k + 1) % 3] = 1.0
+        elif kind == 5:                                 # a bounce ray: from the surface of sphere j (or from inside it)
+            nrm = rng.normal(0, 1, 3); nrm /= np.linalg.norm(nrm)
+            o = c[j] + nrm * r[j] * rng.choice([1.0, 1.0, 0.5, 0.0])
+        elif kind == 6:                                 # far away, aimed at the scene
+            o = d * -rng.choice([1e4, 1e6, 1e9, 1e12, 1e19, 1e25]) + c[j]
+        elif kind == 7:                                 # not a unit vector / not finite
+            d = d * rng.choice([0.5, 2.0, 1e-3, 1e3, 0.0, 1.0005, 0.9995])
+            if i % 5 == 0:
+                d[int(rng.integers(0, 3))] = rng.choice([np.nan, np.inf, -np.inf])
+        elif kind == 8:                                 # tangent to sphere j, a hair inside or outside
+            t = np.cross(d, rng.normal(0, 1, 3)); t /= np.linalg.norm(t)
+            o = c[j] + t * r[j] * (1 + rng.choice([-1e-6, 1e-6, -1e-7, 1e-7, 0.0])) - d * rng.uniform(0, 40)
+        elif kind == 9:                                 # aimed at a centre: a certain hit
+            d = c[j] - o; d /= max(np.linalg.norm(d), 1e-30)
+        elif kind == 10:                                # origin non-finite
+            o[int(rng.integers(0, 3))] = rng.choice([np.nan, np.inf])
+        rays[i, 0:3] = o
+        rays[i, 3] = rng.choice([1e20, 10.0, 50.0, 0.5, 1e-3])
+        rays[i, 4:7] = d
+        rays[i, 7:8].view(np.uint32)[0] = i & 1        # odd: shadow ray
+    return rays
+
+
+@pytest.mark.parametrize("maker", [lambda: scenes.random_spheres(1024), lambda: scenes.mirror_box(120), lambda: _adversarial(3)])
+def test_walk_equals_sweep_for_adversarial_rays(maker):
+    sph = api.as_spheres(maker()[0])
+    rng = np.random.default_rng(len(sph))
+    rays = _adversarial_rays(sph, rng, 60000)
+    with api.RtContext(32, 32, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+        ctx.set_scene(sph)
+        out = np.zeros((len(rays), 4), np.uint32)
+        with np.errstate(all="ignore"):
+            ctx._check(ctx._lib.rt_debug_walk_rays(ctx._h, rays.ctypes.data_as(C.c_void_p), len(rays), out.ctypes.data_as(C.c_void_p)))
+    differ = np.nonzero((out[:, 0] != out[:, 2]) | (out[:, 1] != out[:, 3]))[0]
+    assert len(differ) == 0, (differ[:5], rays[differ[:5]], out[differ[:5]])
+    closest = out[0::2]
+    assert (closest[:, 0] != 0xffffffff).sum() > 1000          # the harness is not vacuous: thousands of hits
+    assert (out[1::2, 0] < len(sph)).sum() > 1000               # ... and of blocked shadow rays
