@@ -1,0 +1,261 @@
+// rt_bvh.hip -- the hierarchy of large scenes (rt_device.h BvhTables), built on the device behind the scene tables:
+// the build kernel and the host function that sizes and launches it.  Walked by rt_walk.inc.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace {
+
+// The hierarchy of rt_device.h BvhTables from the raw records, ONE workgroup of 1024 threads:
+//   1. a sphere stays outside the tree ("always" list, scene order kept) unless its radius and centre are finite and
+//      |rad| <= r_cut (the host derives r_cut from the median radius: ground planes, walls and lights the size of
+//      the scene would blow up every box above them);
+//   2. the tree's spheres are sorted along a 30-bit Morton curve through the box of their centres (bitonic sort of
+//      key << 32 | scene index in LDS);
+//   3. leaves take kBvhLeaf consecutive spheres; the tree over the leaves splits every range in the middle and is
+//      laid out depth-first, so a node's first child is the next node and `skip` = node + size of its subtree;
+//   4. boxes are rounded outwards; every node also carries the lowest scene index below it.
+// Host and device agree on the counts because they apply the same test to the same bits (bvh_outside).
+__host__ __device__ inline bool bvh_outside(float rad, float px, float py, float pz, float r_cut) {
+    const float big = 3.0e38f;
+    const bool finite = (fabsf(rad) <= big) && (fabsf(px) <= big) && (fabsf(py) <= big) && (fabsf(pz) <= big);   // false for NaN
+    return !(finite && fabsf(rad) <= r_cut);
+}
+__device__ inline unsigned bvh_ordered(float f) {          // unsigned order = float order
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float bvh_unordered(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__device__ inline unsigned bvh_spread(unsigned v) {        // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ inline float bvh_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
+__device__ inline float bvh_up(float v) { return v + (fabsf(v) * 0x1p-22f + 1e-30f); }
+
+__global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, uint32_t n, float r_cut, uint32_t n_always,
+                                                            uint32_t n_tree, uint32_t n_pad, float4 *blob) {
+    extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, later 2 float4 per leaf
+    __shared__ unsigned s_lo[3], s_hi[3], s_rmin, s_rmax;
+    __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad;
+    const unsigned tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    const uint32_t n_nodes = n_leaves ? 2 * n_leaves - 1 : 0;
+    const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
+    float4 *hdr = blob, *nodes = blob + 2, *slots = nodes + 2 * (size_t)n_nodes;
+    uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
+    if (tid < 3) { s_lo[tid] = 0xffffffffu; s_hi[tid] = 0u; }
+    if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; }
+    for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
+    __syncthreads();
+    // ---- 1. box of the tree's centres, radius range ----
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const float *r = reinterpret_cast<const float *>(sph + i);
+        if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
+            atomicMin(&s_lo[0], bvh_ordered(r[1])); atomicMax(&s_hi[0], bvh_ordered(r[1]));
+            atomicMin(&s_lo[1], bvh_ordered(r[2])); atomicMax(&s_hi[1], bvh_ordered(r[2]));
+            atomicMin(&s_lo[2], bvh_ordered(r[3])); atomicMax(&s_hi[2], bvh_ordered(r[3]));
+            atomicMin(&s_rmin, __float_as_uint(fabsf(r[0]))); atomicMax(&s_rmax, __float_as_uint(fabsf(r[0])));
+        }
+    }
+    __syncthreads();
+    const float lox = bvh_unordered(s_lo[0]), loy = bvh_unordered(s_lo[1]), loz = bvh_unordered(s_lo[2]);
+    const float kx = 1023.f / fmaxf(bvh_unordered(s_hi[0]) - lox, 1e-30f), ky = 1023.f / fmaxf(bvh_unordered(s_hi[1]) - loy, 1e-30f),
+                kz = 1023.f / fmaxf(bvh_unordered(s_hi[2]) - loz, 1e-30f);
+    // ---- 2. the always list in scene order, the tree's keys in any order (ballot prefix per 1024 records) ----
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        bool out = false, in = false;
+        float rad = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+        if (i < n) {
+            const float *r = reinterpret_cast<const float *>(sph + i);
+            rad = r[0]; px = r[1]; py = r[2]; pz = r[3];
+            out = bvh_outside(rad, px, py, pz, r_cut);
+            in = !out;
+        }
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(out), mt = __builtin_amdgcn_ballot_w64(in);
+        const uint32_t before_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+        const uint32_t before_t = __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
+        if ((tid & 63) == 0) { s_wave_a[wave] = (uint32_t)__popcll(ma); s_wave_t[wave] = (uint32_t)__popcll(mt); }
+        __syncthreads();
+        uint32_t off_a = s_base_a, off_t = s_base_t;
+        for (unsigned k = 0; k < wave; ++k) { off_a += s_wave_a[k]; off_t += s_wave_t[k]; }
+        if (out) {
+            const uint32_t j = off_a + before_a;
+            if (j < n_always) { slots[j] = make_float4(px, py, pz, rad * rad); index[j] = i; }
+            else atomicAdd(&s_bad, 1u);
+        }
+        if (in) {
+            const uint32_t j = off_t + before_t;
+            const unsigned qx = (unsigned)fminf(fmaxf((px - lox) * kx, 0.f), 1023.f), qy = (unsigned)fminf(fmaxf((py - loy) * ky, 0.f), 1023.f),
+                           qz = (unsigned)fminf(fmaxf((pz - loz) * kz, 0.f), 1023.f);
+            const unsigned code = (bvh_spread(qx) << 2) | (bvh_spread(qy) << 1) | bvh_spread(qz);
+            if (j < n_tree) s_keys[j] = ((unsigned long long)code << 32) | i;
+            else atomicAdd(&s_bad, 1u);
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < 16; ++k) { s_base_a += s_wave_a[k]; s_base_t += s_wave_t[k]; }
+        __syncthreads();
+    }
+    for (uint32_t k = 2; k <= n_pad; k <<= 1) {             // bitonic sort, ascending
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n_pad; i += 1024) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[l];
+                    if ((a > b) == ((i & k) == 0)) { s_keys[i] = b; s_keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 3. records in leaf order; padding records never hit (NaN centre: every comparison of the test is false) ----
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (uint32_t j = tid; j < rt::kBvhLeaf * n_leaves; j += 1024) {
+        const uint32_t ix = j < n_tree ? (uint32_t)s_keys[j] : 0xffffffffu;
+        if (ix != 0xffffffffu) {
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            slots[n_always + j] = make_float4(r[1], r[2], r[3], r[0] * r[0]);
+        } else {
+            slots[n_always + j] = make_float4(qnan, qnan, qnan, qnan);
+        }
+        index[n_always + j] = ix;
+    }
+    __threadfence_block();                                  // the index written above is read back below by other threads
+    __syncthreads();                                        // the keys are dead: the same LDS now holds the leaf boxes
+    float4 *s_leaf = reinterpret_cast<float4 *>(s_keys);
+    for (uint32_t leaf = tid; leaf < n_leaves; leaf += 1024) {
+        float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        uint32_t low = 0xffffffffu;
+        for (int k = 0; k < rt::kBvhLeaf; ++k) {
+            const uint32_t ix = index[n_always + rt::kBvhLeaf * leaf + k];
+            if (ix == 0xffffffffu) continue;
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            const float ar = fabsf(r[0]);
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], bvh_down(r[1 + a] - ar));
+                hi[a] = fmaxf(hi[a], bvh_up(r[1 + a] + ar));
+            }
+            low = ix < low ? ix : low;
+        }
+        s_leaf[2 * leaf] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        s_leaf[2 * leaf + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+    }
+    __syncthreads();
+    // ---- 4. one thread per node: leaves by number, inner nodes by the place where they split their range ----
+    for (uint32_t w = tid; w < n_nodes; w += 1024) {
+        const bool is_leaf = w < n_leaves;
+        const uint32_t want = is_leaf ? w : w - n_leaves + 1;       // leaf number, or split point in [1, n_leaves)
+        uint32_t a = 0, b = n_leaves, at = 0;
+        while (b - a > 1) {                                          // (a leaf's walk ends on a range of one)
+            const uint32_t mid = (a + b) / 2;
+            if (!is_leaf && mid == want) break;
+            if (want < mid) { at += 1; b = mid; }
+            else { at += 2 * (mid - a); a = mid; }
+        }
+        float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        uint32_t low = 0xffffffffu;
+        for (uint32_t l = a; l < b; ++l) {
+            const float4 A = s_leaf[2 * l], B = s_leaf[2 * l + 1];
+            lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
+            hi[0] = fmaxf(hi[0], B.x); hi[1] = fmaxf(hi[1], B.y); hi[2] = fmaxf(hi[2], B.z);
+            const uint32_t q = __float_as_uint(B.w);
+            low = q < low ? q : low;
+        }
+        const uint32_t skip = at + 2 * (b - a) - 1;
+        const uint32_t link = skip | (is_leaf ? (a + 1) << 16 : 0u);
+        nodes[2 * (size_t)at] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(link));
+        nodes[2 * (size_t)at + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+        if (at == 0) {
+            const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
+            const float ex = hi[0] - cx, ey = hi[1] - cy, ez = hi[2] - cz;
+            hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
+            const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
+            hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float(s_bad));
+        }
+    }
+    if (n_nodes == 0 && tid == 0) {
+        hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(s_bad));
+    }
+    // ---- 5. the same tree as sibling pairs (rt_device.h BvhTables `pairs`): one thread per inner node ----
+    float4 *pairs = reinterpret_cast<float4 *>(index) + (n_slots + 3) / 4;
+    for (uint32_t m = 1 + tid; m < n_leaves; m += 1024) {
+        uint32_t a = 0, b = n_leaves, mid;
+        for (;;) {
+            mid = (a + b) / 2;
+            if (mid == m) break;
+            if (m < mid) b = mid;
+            else a = mid;
+        }
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t ca = side ? mid : a, cb = side ? b : mid;
+            float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+            uint32_t low = 0xffffffffu;
+            for (uint32_t l = ca; l < cb; ++l) {
+                const float4 A = s_leaf[2 * l], B = s_leaf[2 * l + 1];
+                lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
+                hi[0] = fmaxf(hi[0], B.x); hi[1] = fmaxf(hi[1], B.y); hi[2] = fmaxf(hi[2], B.z);
+                const uint32_t q = __float_as_uint(B.w);
+                low = q < low ? q : low;
+            }
+            const uint32_t ref = (cb - ca == 1) ? (rt::kBvhLeafRef | ca) : (ca + cb) / 2 - 1;
+            pairs[4 * (size_t)(m - 1) + 2 * side] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(ref));
+            pairs[4 * (size_t)(m - 1) + 2 * side + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+        }
+    }
+}
+
+}  // namespace
+
+namespace rt {
+
+hipError_t prepare_bvh_build() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(rt_bvh_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+
+// The hierarchy of a large scene (rt_bvh_build_kernel), on `stream` behind the records.  Which spheres stay outside
+// the tree is decided here, from the host mirror, with the test the device applies to the same bits: 16 times the
+// median |radius| is the cut (ground, walls, big lights), non-finite records stay outside as well.
+int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
+    c->bvh_ok = false;
+    c->bvh = rt::BvhTables{};
+    if (c->bvh_min <= 0 || n_total < (uint32_t)c->bvh_min || !c->d_bvh) return RT_OK;
+    std::vector<float> radii;
+    radii.reserve(n_total);
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const float r = fabsf(c->h_spheres[i].rad);
+        if (r <= 3.0e38f) radii.push_back(r);
+    }
+    if (radii.empty()) return RT_OK;
+    std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+    const float r_cut = 16.f * radii[radii.size() / 2];
+    uint32_t n_tree = 0;
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const rt_sphere &s = c->h_spheres[i];
+        n_tree += bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut) ? 0u : 1u;
+    }
+    if (n_tree < (uint32_t)c->bvh_min) return RT_OK;
+    const uint32_t n_always = n_total - n_tree;
+    uint32_t n_pad = 2;
+    while (n_pad < n_tree) n_pad *= 2;
+    const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    const size_t lds = std::max((size_t)n_pad * 8, (size_t)n_leaves * 32);
+    hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
+    HIP_TRY(hipGetLastError());
+    uint32_t depth = 1;
+    while ((1u << depth) < n_leaves) depth += 1;
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, 2 * n_leaves - 1, n_always + rt::kBvhLeaf * n_leaves, depth + 1 };
+    c->bvh_ok = true;
+    return RT_OK;
+}
+
+}  // namespace rt

@@ -96,6 +96,11 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
                             __FILE__, __LINE__);                                               \
     } while (0)
 
+// the hierarchy of large scenes (rt_bvh.hip): per-device set-up of the build kernel; build on `stream` for the scene the
+// context's host mirror holds (sets c->bvh / c->bvh_ok; nothing is read back)
+hipError_t prepare_bvh_build();
+int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream);
+
 // multi-device context (rt_multi.hip); `front` is the rt_ctx whose `multi` points at the record
 void multi_destroy(rt_ctx *front);
 int multi_set_scene(rt_ctx *front, const rt_sphere *spheres, uint32_t count);
