@@ -71,7 +71,6 @@ inline size_t lds_bytes_pairs(uint32_t n_spheres, uint32_t n_lights, bool mat_in
 
 struct LaunchParams {
     SceneTables scene;
-    BvhTables bvh;          // instances with RT_OPT_BVH only
     rt_camera cam;
     uint32_t *seeds;        // [2*w*h], pair per pixel at gid = y*w + x        (.cl:570-571); written at the end of a launch
     const uint32_t *seeds_in;   // read at the start of a launch: `seeds`, or the pristine default stream for the
@@ -86,8 +85,6 @@ struct LaunchParams {
     int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
     int n_tiles, tiles_x;   // persistent instances: 8x8 pixel tiles of this rank's rows, and tiles per row
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
-    int walk_steps;         // rt_walk.inc.h: node tests a lane may take per loop trip
-    int walk_round;         // ... and in a row before the leaf step of the lanes that hold a leaf
     float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
     const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order
@@ -98,6 +95,11 @@ struct LaunchParams {
     unsigned long long tl_tag;
     unsigned long long *wavelog;   // [workgroup*4 + wave][3]: start, end, xcc_id << 32 | HW_ID
     uint32_t seq;
+    // instances that walk the hierarchy of a large scene (RT_OPT_BVH) -- at the end: the other instances' argument
+    // offsets, and with them their scalar loads and SGPR allocation, are what they were without it
+    int walk_steps;         // rt_walk.inc.h: pair steps a lane may take per loop trip
+    int walk_round;         // ... and in a row before the leaf step of the lanes that hold a leaf
+    BvhTables bvh;
 };
 
 // LDS bytes the kernels need for a scene
