@@ -76,7 +76,8 @@ enum rt_mode {
     RT_MODE_FAST   = 1       /* FMA contraction + hardware rcp/rsq/sin/cos/exp2/log2           */
 };
 
-#define RT_MAX_SPHERES 8192u /* geometry table (16 B per sphere) must fit the CU's LDS        */
+#define RT_MAX_SPHERES 262144u /* (the hierarchy numbers its leaves of 8 spheres with 15 bits; up to ~9000 spheres
+                                 * the tables are staged in LDS, beyond that they are read from HBM / L2)        */
 
 typedef struct rt_ctx rt_ctx;
 

@@ -305,12 +305,25 @@ size_t bvh_lds(const rt_ctx *c, bool mat, int n_samples) {
     return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
 }
 
-// the scene has a hierarchy and the instance that walks it fits
-bool bvh_usable(const rt_ctx *c, int n_samples) {
-    if (!c->bvh_ok || c->wg_waves == 1 || c->persist != 0) return false;
+constexpr size_t kLdsMax = 152 * 1024;     // what the kernels' dynamic-LDS attribute allows
+
+// the plain sweep's tables (geometry and lights) fit LDS for this launch
+bool tables_fit_lds(const rt_ctx *c, int n_samples) {
+    return rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, false, n_samples) <= kLdsMax;
+}
+
+// the hierarchy's tables fit the LDS budget given to them; otherwise the walk reads them from HBM / L2
+bool bvh_fits_lds(const rt_ctx *c, int n_samples) {
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     const bool mat = lds_all <= (size_t)c->mat_lds_limit;
     return bvh_lds(c, mat, n_samples) <= (size_t)c->bvh_lds_limit;
+}
+
+// the scene has a hierarchy and there is an instance that can walk it
+bool bvh_usable(const rt_ctx *c, int n_samples) {
+    if (!c->bvh_ok || c->wg_waves == 1 || c->persist != 0) return false;
+    if (c->walk_form == 1 || c->walk_form == 2) return bvh_fits_lds(c, n_samples);      // the A/B forms exist for LDS tables only
+    return true;
 }
 
 // `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one that fits), 2 = the plain sweep
@@ -344,14 +357,27 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     // large scenes: the instance that walks the hierarchy, while its tables leave room for two workgroups per CU
     size_t lds_use = lds;
     const size_t lds_bvh = c->bvh_ok ? bvh_lds(c, p.mat_in_lds != 0, n_samples) : 0;
+    const bool in_lds = tables_fit_lds(c, n_samples);
     if (form != 2 && bvh_usable(c, n_samples)) {
         const bool per_call = c->walk_form == 1;
-        variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant)
-                           : c->walk_form == 2 ? (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant)
-                                               : (fast ? rt::kFastPairsVariant : rt::kParityPairsVariant);
         p.bvh = c->bvh;
-        lds_use = lds_bvh;
+        if (per_call || c->walk_form == 2 || bvh_fits_lds(c, n_samples)) {
+            variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant)
+                               : c->walk_form == 2 ? (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant)
+                                                   : (fast ? rt::kFastPairsVariant : rt::kParityPairsVariant);
+            lds_use = lds_bvh;
+        } else {
+            // tables beyond the LDS budget: the same walk over pairs and slots where they lie; staged: header, stacks
+            variant = fast ? rt::kFastPairsGlobalVariant : rt::kParityPairsGlobalVariant;
+            p.mat_in_lds = 0;
+            lds_use = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256);
+        }
         if (!per_call && c->regen_gate <= 0) p.regen_gate = c->walk_gate;
+    } else if (!in_lds) {
+        // no hierarchy (or it lost the measurement) and a table beyond LDS: the plain sweep over the table in HBM / L2
+        variant = fast ? rt::kFastGlobalVariant : rt::kParityGlobalVariant;
+        p.mat_in_lds = 0;
+        lds_use = rt::lds_bytes(0, 0, false, n_samples);
     }
     p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
@@ -479,6 +505,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false)
     const bool measured = c->walk_form == 0 && c->mode < 100;
     if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c, n_samples))
         return launch_form(c, n_samples, stream, measured ? 2 : 0);
+    if (!tables_fit_lds(c, n_samples)) return launch_form(c, n_samples, stream, 1);     // (no probe: a sweep over a table beyond LDS takes seconds)
     probe_poll(c, false);
     if (c->bvh_pick != 0) return launch_form(c, n_samples, stream, c->bvh_pick);
     if (c->probe_state == 2) return launch_form(c, n_samples, stream, 1);    // both probes in flight: the usual winner meanwhile
@@ -706,6 +733,8 @@ RT_API void rt_destroy(rt_ctx *c) {
         if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (int k = 0; k < 4; ++k)
             if (c->probe_ev[k]) (void)hipEventDestroy(c->probe_ev[k]);
+        if (c->bvh_stage_ev) (void)hipEventDestroy(c->bvh_stage_ev);
+        if (c->h_bvh_stage) (void)hipHostFree(c->h_bvh_stage);
         if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
         for (int k = 0; k < 4; ++k)
             if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
@@ -722,11 +751,6 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     if (count > 0 && !spheres) return fail(RT_ERR_ARG, "spheres is null");
     if (count > RT_MAX_SPHERES) return fail(RT_ERR_ARG, "%u spheres > RT_MAX_SPHERES (%u)", count, RT_MAX_SPHERES);
-    // everything that can refuse the scene is checked before the current one is touched
-    uint32_t nl = 0;
-    for (uint32_t i = 0; i < count; ++i) nl += light_test(spheres[i]) ? 1u : 0u;
-    if (rt::lds_bytes(count, nl, false) > 152 * 1024)
-        return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(count, nl, false));
     if (c->multi) return rt::multi_set_scene(c, spheres, count);
     // the very scene the context already holds (a host that sets it before every frame): nothing to do
     if (c->have_scene && count == c->scene.n_spheres && c->h_spheres.size() == count &&
@@ -757,12 +781,6 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     if (c->multi) return rt::multi_update_spheres(c, first, count, spheres);
     const uint32_t n = c->scene.n_spheres;
     if (first > n || count > n - first) return fail(RT_ERR_ARG, "spheres [%u, %u) of a scene of %u", first, first + count, n);
-    // the light list may grow: check the LDS budget with the new flags before anything is queued
-    uint32_t nl = 0;
-    for (uint32_t i = 0; i < n; ++i)
-        nl += (i >= first && i < first + count) ? (light_test(spheres[i - first]) ? 1u : 0u) : c->is_light[i];
-    if (rt::lds_bytes(n, nl, false) > 152 * 1024)
-        return fail(RT_ERR_ARG, "scene needs %zu B of LDS (> 152 KiB)", rt::lds_bytes(n, nl, false));
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));

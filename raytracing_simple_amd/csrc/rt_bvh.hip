@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "rt_internal.h"
@@ -214,6 +215,143 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
     }
 }
 
+// Trees beyond what one workgroup sorts in LDS (more than 16 384 spheres in the tree): the same tables from the host
+// mirror of the records -- same split, same Morton order (ties broken by scene index, as the device's 64-bit keys
+// do), same leaves, same sibling pairs, boxes rounded outwards the same way -- written into a page-locked buffer and
+// copied on `stream`.  Milliseconds of host time per build for scenes of this size; nothing is waited for.  The
+// depth-first `nodes` section of the blob (the A/B forms of the walk, LDS tables only) is left out.
+constexpr uint32_t kDeviceBuildMax = 16384;
+
+inline float host_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
+inline float host_up(float v) { return v + (fabsf(v) * 0x1p-22f + 1e-30f); }
+inline uint32_t host_spread(uint32_t v) {
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+inline float bits_float(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct HostBox {
+    float lo[3], hi[3];
+    uint32_t low;
+};
+
+int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, uint32_t n_tree, hipStream_t stream) {
+    const std::vector<rt_sphere> &sph = c->h_spheres;
+    const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    const uint32_t n_nodes = 2 * n_leaves - 1, n_slots = n_always + rt::kBvhLeaf * n_leaves;
+    const size_t total4 = rt::bvh_blob_float4s(n_nodes, n_slots) + 4 * (size_t)(n_leaves - 1);
+    if (c->bvh_stage_cap < total4) {
+        if (c->bvh_stage_used) HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));
+        if (c->h_bvh_stage) (void)hipHostFree(c->h_bvh_stage);
+        c->h_bvh_stage = nullptr;
+        c->bvh_stage_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_bvh_stage), total4 * sizeof(float4), hipHostMallocDefault));
+        c->bvh_stage_cap = total4;
+    } else if (c->bvh_stage_used) {
+        HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));       // the last build's copy still reads the buffer
+    }
+    float4 *blob = c->h_bvh_stage;
+    float4 *hdr = blob, *slots = blob + 2 + 2 * (size_t)n_nodes;
+    uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
+    float4 *pairs = reinterpret_cast<float4 *>(index) + (n_slots + 3) / 4;
+    // split; box of the tree's centres; radius range
+    std::vector<uint64_t> keys;
+    keys.reserve(n_tree);
+    float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f }, rmin = 3.4e38f, rmax = 0.f;
+    uint32_t na = 0;
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const rt_sphere &s = sph[i];
+        if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) {
+            slots[na] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
+            index[na] = i;
+            na += 1;
+        } else {
+            const float p[3] = { s.p.x, s.p.y, s.p.z };
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], p[a]);
+                hi[a] = fmaxf(hi[a], p[a]);
+            }
+            rmin = fminf(rmin, fabsf(s.rad));
+            rmax = fmaxf(rmax, fabsf(s.rad));
+        }
+    }
+    const float k[3] = { 1023.f / fmaxf(hi[0] - lo[0], 1e-30f), 1023.f / fmaxf(hi[1] - lo[1], 1e-30f), 1023.f / fmaxf(hi[2] - lo[2], 1e-30f) };
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const rt_sphere &s = sph[i];
+        if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) continue;
+        const uint32_t qx = (uint32_t)fminf(fmaxf((s.p.x - lo[0]) * k[0], 0.f), 1023.f), qy = (uint32_t)fminf(fmaxf((s.p.y - lo[1]) * k[1], 0.f), 1023.f),
+                       qz = (uint32_t)fminf(fmaxf((s.p.z - lo[2]) * k[2], 0.f), 1023.f);
+        keys.push_back(((uint64_t)((host_spread(qx) << 2) | (host_spread(qy) << 1) | host_spread(qz)) << 32) | i);
+    }
+    if (na != n_always || keys.size() != n_tree) return rt::fail(RT_ERR_STATE, "hierarchy: the split changed under the build");
+    std::sort(keys.begin(), keys.end());
+    // records in leaf order, leaf boxes
+    std::vector<HostBox> leaf(n_leaves);
+    const float qnan = bits_float(0x7fc00000u);
+    for (uint32_t l = 0; l < n_leaves; ++l) {
+        HostBox b{ { 3.4e38f, 3.4e38f, 3.4e38f }, { -3.4e38f, -3.4e38f, -3.4e38f }, 0xffffffffu };
+        for (int q = 0; q < rt::kBvhLeaf; ++q) {
+            const uint32_t j = rt::kBvhLeaf * l + q;
+            if (j >= n_tree) {
+                slots[n_always + j] = make_float4(qnan, qnan, qnan, qnan);
+                index[n_always + j] = 0xffffffffu;
+                continue;
+            }
+            const uint32_t ix = (uint32_t)keys[j];
+            const rt_sphere &s = sph[ix];
+            slots[n_always + j] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
+            index[n_always + j] = ix;
+            const float p[3] = { s.p.x, s.p.y, s.p.z }, ar = fabsf(s.rad);
+            for (int a = 0; a < 3; ++a) {
+                b.lo[a] = fminf(b.lo[a], host_down(p[a] - ar));
+                b.hi[a] = fmaxf(b.hi[a], host_up(p[a] + ar));
+            }
+            b.low = ix < b.low ? ix : b.low;
+        }
+        leaf[l] = b;
+    }
+    // sibling pairs: a recursion over leaf ranges (a range's box is the union of its halves')
+    auto range_box = [&](uint32_t a, uint32_t b, auto &&self) -> HostBox {
+        if (b - a == 1) return leaf[a];
+        const uint32_t mid = (a + b) / 2;
+        const HostBox L = self(a, mid, self), R = self(mid, b, self);
+        const HostBox side[2] = { L, R };
+        const uint32_t ca[2] = { a, mid }, cb[2] = { mid, b };
+        for (int sd = 0; sd < 2; ++sd) {
+            const uint32_t ref = (cb[sd] - ca[sd] == 1) ? (rt::kBvhLeafRef | ca[sd]) : (ca[sd] + cb[sd]) / 2 - 1;
+            pairs[4 * (size_t)(mid - 1) + 2 * sd] = make_float4(side[sd].lo[0], side[sd].lo[1], side[sd].lo[2], bits_float(ref));
+            pairs[4 * (size_t)(mid - 1) + 2 * sd + 1] = make_float4(side[sd].hi[0], side[sd].hi[1], side[sd].hi[2], bits_float(side[sd].low));
+        }
+        HostBox u = L;
+        for (int a3 = 0; a3 < 3; ++a3) {
+            u.lo[a3] = fminf(L.lo[a3], R.lo[a3]);
+            u.hi[a3] = fmaxf(L.hi[a3], R.hi[a3]);
+        }
+        u.low = L.low < R.low ? L.low : R.low;
+        return u;
+    };
+    const HostBox root = range_box(0, n_leaves, range_box);     // (depth = log2 of the leaf count: 15 at most)
+    const float cx = 0.5f * root.lo[0] + 0.5f * root.hi[0], cy = 0.5f * root.lo[1] + 0.5f * root.hi[1], cz = 0.5f * root.lo[2] + 0.5f * root.hi[2];
+    const float ex = root.hi[0] - cx, ey = root.hi[1] - cy, ez = root.hi[2] - cz;
+    hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
+    hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
+    // one copy: header, then everything from the slots on (the depth-first nodes in between are not written)
+    HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, 2 * sizeof(float4), hipMemcpyHostToDevice, stream));
+    const size_t from = 2 + 2 * (size_t)n_nodes;
+    HIP_TRY(hipMemcpyAsync(c->d_bvh + from, blob + from, (total4 - from) * sizeof(float4), hipMemcpyHostToDevice, stream));
+    if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
+    HIP_TRY(hipEventRecord(c->bvh_stage_ev, stream));
+    c->bvh_stage_used = true;
+    return RT_OK;
+}
+
 }  // namespace
 
 namespace rt {
@@ -245,12 +383,17 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
     }
     if (n_tree < (uint32_t)c->bvh_min) return RT_OK;
     const uint32_t n_always = n_total - n_tree;
-    uint32_t n_pad = 2;
-    while (n_pad < n_tree) n_pad *= 2;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
-    const size_t lds = std::max((size_t)n_pad * 8, (size_t)n_leaves * 32);
-    hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
-    HIP_TRY(hipGetLastError());
+    if (n_tree <= kDeviceBuildMax) {
+        uint32_t n_pad = 2;
+        while (n_pad < n_tree) n_pad *= 2;
+        const size_t lds = std::max((size_t)n_pad * 8, (size_t)n_leaves * 32);
+        hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
+        HIP_TRY(hipGetLastError());
+    } else {
+        const int rc = build_on_host(c, n_total, r_cut, n_always, n_tree, stream);
+        if (rc != RT_OK) return rc;
+    }
     uint32_t depth = 1;
     while ((1u << depth) < n_leaves) depth += 1;
     c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, 2 * n_leaves - 1, n_always + rt::kBvhLeaf * n_leaves, depth + 1 };

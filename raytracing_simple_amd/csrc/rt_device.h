@@ -140,6 +140,8 @@ constexpr int kParityBvhVariant = 12, kParityBvhCheckVariant = 13;  // hierarchy
 constexpr int kFastBvhVariant = 8;
 constexpr int kParityWalkVariant = 15, kFastWalkVariant = 9;       // ... with the walk as lane state (rt_walk.inc.h)
 constexpr int kParityPairsVariant = 17, kFastPairsVariant = 10;    // ... nearer child first, over the sibling pairs
+constexpr int kParityPairsGlobalVariant = 19, kFastPairsGlobalVariant = 11;   // tables beyond LDS: read where they lie
+constexpr int kParityGlobalVariant = 20, kFastGlobalVariant = 12;
 int parity_variant_waves(int variant);   // wavefronts per workgroup of an instance: 4 (32x8 tile) or 1 (8x8 tile)
 int fast_variant_waves(int variant);
 int parity_variant_count();

@@ -34,6 +34,10 @@ struct rt_ctx {
     float4 *d_bvh = nullptr;            // blob, sized for scene_cap
     rt::BvhTables bvh{};
     bool bvh_ok = false;                // the blob describes the current scene
+    float4 *h_bvh_stage = nullptr;      // page-locked buffer of the host-side build (trees beyond the one-workgroup device build)
+    size_t bvh_stage_cap = 0;           // float4
+    hipEvent_t bvh_stage_ev = nullptr;
+    bool bvh_stage_used = false;
     int bvh_min = 64;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 64 * 1024;      // ... while the instance's LDS stays below this
     int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade

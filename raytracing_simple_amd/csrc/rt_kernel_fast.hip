@@ -54,6 +54,19 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_pairs_g           /* tables too large for LDS */
+#define RT_KERNEL_NAME rt_trace_fast_pairs_g
+#define RT_OPT_BVH 6
+#define RT_OPT_GLOBAL_TABLES 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fast_g
+#define RT_KERNEL_NAME rt_trace_fast_g
+#define RT_OPT_GLOBAL_TABLES 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS fast_bvh
 #define RT_KERNEL_NAME rt_trace_fast_bvh
@@ -108,6 +121,8 @@ static KernelFn const kFastKernels[] = {
     nullptr, nullptr,
 #endif
     fast_pairs::rt_trace_fast_pairs,                 // 10 = kFastPairsVariant  shipped: large scenes
+    fast_pairs_g::rt_trace_fast_pairs_g,             // 11 = kFastPairsGlobalVariant   shipped: tables beyond LDS
+    fast_g::rt_trace_fast_g,                         // 12 = kFastGlobalVariant
 };
 constexpr int kFastCount = sizeof(kFastKernels) / sizeof(kFastKernels[0]);
 
@@ -119,6 +134,8 @@ const char *fast_variant_name(int variant) {
         case kFastW1Variant: return "rt_trace_fast_w1";
         case kFastCoopW1Variant: return "rt_trace_fast_coop_w1";
         case kFastPairsVariant: return "rt_trace_fast_pairs";
+        case kFastPairsGlobalVariant: return "rt_trace_fast_pairs_g";
+        case kFastGlobalVariant: return "rt_trace_fast_g";
         default: return "rt_trace_fast (a diagnostics instance)";
     }
 }

@@ -63,6 +63,23 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs_g         /* tables too large for LDS: the same walk over pairs and slots where they lie in HBM / L2 */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_g
+#define RT_OPT_BVH 6
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 4
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_g               /* ... and the plain sweep over the table in HBM / L2 (no hierarchy, or it lost the measurement) */
+#define RT_KERNEL_NAME rt_trace_parity_g
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_LEAN_SQRT 1
+#define RT_OPT_MINWAVES 6
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #if RT_DIAGNOSTICS
 #define RT_NS parity_bvh             /* A/B: depth-first nodes with skip links, walked to the end inside each closest-hit / shadow call */
 #define RT_KERNEL_NAME rt_trace_parity_bvh
@@ -192,7 +209,11 @@ static KernelFn const kParityKernels[] = {
     parity_pairs::rt_trace_parity_pairs,                // 17 = kParityPairsVariant   shipped: large scenes
 #if RT_DIAGNOSTICS
     parity_pairss::rt_trace_parity_pairss,              // 18   its census
+#else
+    nullptr,
 #endif
+    parity_pairs_g::rt_trace_parity_pairs_g,            // 19 = kParityPairsGlobalVariant   shipped: tables beyond LDS
+    parity_g::rt_trace_parity_g,                        // 20 = kParityGlobalVariant
 };
 constexpr int kParityCount = sizeof(kParityKernels) / sizeof(kParityKernels[0]);
 
@@ -204,6 +225,8 @@ const char *parity_variant_name(int variant) {
         case kParityW1Variant: return "rt_trace_parity_w1";
         case kParityCoopW1Variant: return "rt_trace_parity_coop_w1";
         case kParityPairsVariant: return "rt_trace_parity_pairs";
+        case kParityPairsGlobalVariant: return "rt_trace_parity_pairs_g";
+        case kParityGlobalVariant: return "rt_trace_parity_g";
         default: return "rt_trace_parity (a diagnostics instance)";
     }
 }

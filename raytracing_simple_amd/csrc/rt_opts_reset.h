@@ -23,3 +23,4 @@
 #undef RT_OPT_WG_WAVES
 #undef RT_OPT_BVH
 #undef RT_WALK_RAYS_KERNEL_NAME
+#undef RT_OPT_GLOBAL_TABLES

@@ -85,6 +85,12 @@
 #ifndef RT_OPT_BVH
 #define RT_OPT_BVH 0
 #endif
+// RT_OPT_GLOBAL_TABLES: scenes whose tables do not fit LDS (more than ~9000 spheres, or thousands of lights): the
+// sweeps and the walk read geometry, lights and the hierarchy from HBM / L2 instead of a staged copy.  Same code, same
+// results; the tables are then read through the vector cache at whatever rate that gives.
+#ifndef RT_OPT_GLOBAL_TABLES
+#define RT_OPT_GLOBAL_TABLES 0
+#endif
 // RT_OPT_PERSIST: persistent wavefronts.  The grid only fills the machine; each wavefront pulls
 // 8x8 pixel tiles from a global queue and hands their pixels to its lanes one by one as lanes
 // finish (wave ballot + prefix count), so no lane idles at the end of its pixel while the others
@@ -591,6 +597,7 @@ RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d
 // root box and |r| by the largest radius in the tree; the slab arithmetic's own rounding is inside the pad's linear
 // term (bvh_misses below).  A lane whose direction is not a unit vector to within 10^-3, or not finite, gets an
 // infinite pad: it visits everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
+#undef RT_BVH_COUNT
 #if RT_OPT_BVH == 3
 struct BvhCount {                // census instance: [0] node steps of the wavefront, [1] node tests of this lane, [2]/[3] the same for leaves
     uint32_t v[4];
@@ -686,8 +693,9 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             const float4 *pp = s_pairs + 4u * cur;
             const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
             float tn0, tn1;
-            const bool m0 = bvh_misses(R, A0, B0, w_far, tn0) | (shadow & (__float_as_uint(B0.w) > w_idx));
-            const bool m1 = bvh_misses(R, A1, B1, w_far, tn1) | (shadow & (__float_as_uint(B1.w) > w_idx));
+            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
+            const bool m0 = out0 || (shadow && __float_as_uint(B0.w) > w_idx);
+            const bool m1 = out1 || (shadow && __float_as_uint(B1.w) > w_idx);
             const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
             const bool both = !m0 & !m1, none = m0 & m1;
             const bool second_first = both ? (tn1 < tn0) : m0;
@@ -800,7 +808,8 @@ RT_DEV uint32_t bvh_any(const float4 *s_nodes, const float4 *s_slots, const uint
             const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
             const uint32_t link = __float_as_uint(A.w);
             const uint32_t next = max(link & 0xffffu, node + 1u);
-            const bool miss = (__float_as_uint(B.w) > first) | bvh_misses(R, A, B, max_t);
+            const bool outside = bvh_misses(R, A, B, max_t);
+            const bool miss = outside || __float_as_uint(B.w) > first;
             const bool is_leaf = (link >> 16) != 0u;
             const bool take = !miss & is_leaf;
             leaf = take ? (link >> 16) - 1u : leaf;
@@ -876,13 +885,22 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #else
     float4 *s_lightA = lds + blob_n;
 #endif
+#elif RT_OPT_GLOBAL_TABLES
+    const float4 *s_geom = P.scene.geom;     // nothing staged but the reciprocals of the running average
+    const float4 *s_lightA = P.scene.lightA;
 #else
     float4 *s_geom = lds;
     float4 *s_lightA = s_geom + n;           // {centre, radius}
 #endif
+#if RT_OPT_GLOBAL_TABLES
+    const float4 *s_lightB = P.scene.lightB;
+    float4 *s_emis = lds;                    // (never read: the host keeps mat_in_lds off)
+    float4 *s_colr = lds;
+#else
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;             // {colour, radius}
+#endif
     // 1/(s+1) of the running average (.cl:585), one IEEE division per sample index per
     // workgroup instead of one per lane per sample
     float *s_k2 = reinterpret_cast<float *>(P.mat_in_lds ? s_colr + n : s_emis);
@@ -897,6 +915,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #if RT_OPT_BVH
     for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
 #endif
+#if !RT_OPT_GLOBAL_TABLES
 #if RT_OPT_BVH == 0 || RT_OPT_BVH == 2
     for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
 #endif
@@ -904,6 +923,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         s_lightA[i] = P.scene.lightA[i];
         s_lightB[i] = P.scene.lightB[i];
     }
+#endif
     if (P.mat_in_lds) {
         for (uint32_t i = tid; i < n; i += kBlockThreads) {
             s_emis[i] = P.scene.emis[i];

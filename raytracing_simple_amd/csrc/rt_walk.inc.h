@@ -36,7 +36,19 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // (the scene index of a slot is only read for a candidate that passes the test: from HBM / L2, not staged)
     const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + 2u + 2u * n_nodes + n_slots);
     float4 *s_hdr = lds;
-#if RT_OPT_WALK_PAIRS
+#if RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES
+    // tables too large for LDS: pairs, slots and lights are read where they lie; staged: hdr | one stack per lane
+    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
+    const float4 *s_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
+    const float4 *s_slots = P.bvh.blob + 2u + 2u * n_nodes;
+    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_hdr + 2);
+    const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
+    const float4 *s_lightA = P.scene.lightA, *s_lightB = P.scene.lightB;
+    float4 *s_emis = s_hdr + 2 + stack_f4;        // (never read: the host keeps mat_in_lds off)
+    float4 *s_colr = s_emis;
+    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
+    constexpr uint32_t kNone = kWalkDone;
+#elif RT_OPT_WALK_PAIRS
     // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane])
     const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     float4 *s_pairs = s_hdr + 2;
@@ -53,9 +65,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const uint32_t blob_n = 2u + 2u * n_nodes + n_slots;
     float4 *s_lightA = lds + blob_n;              // {centre, radius}
 #endif
+#if !(RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES)
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;                  // {colour, radius}
+#endif
     float *s_k2 = reinterpret_cast<float *>(P.mat_in_lds ? s_colr + n : s_emis);
     const bool k2_in_lds = P.n_samples <= kMaxK2Table;
 
@@ -64,7 +78,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     __shared__ unsigned s_tile_cost;
     if (tid < 5) s_stat[tid] = 0;
     if (tid == 5) s_tile_cost = 0u;
-#if RT_OPT_WALK_PAIRS
+#if RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES
+    if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
+#elif RT_OPT_WALK_PAIRS
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
     {
         const float4 *g_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
@@ -75,10 +91,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #else
     for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
 #endif
+#if !(RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES)
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
         s_lightA[i] = P.scene.lightA[i];
         s_lightB[i] = P.scene.lightB[i];
     }
+#endif
     if (P.mat_in_lds) {
         for (uint32_t i = tid; i < n; i += kBlockThreads) {
             s_emis[i] = P.scene.emis[i];

@@ -303,3 +303,48 @@ def test_walk_equals_sweep_for_adversarial_rays(maker):
     closest = out[0::2]
     assert (closest[:, 0] != 0xffffffff).sum() > 1000          # the harness is not vacuous: thousands of hits
     assert (out[1::2, 0] < len(sph)).sum() > 1000               # ... and of blocked shadow rays
+
+
+def _many_spheres(n, seed=7):
+    """n small spheres in a slab above a ground sphere, one light: beyond what LDS holds for n > ~9000."""
+    rng = np.random.default_rng(seed)
+    sph = np.zeros(n, api.SPHERE_DT)
+    sph["rad"] = rng.uniform(0.3, 1.2, n).astype(np.float32)
+    sph["p"] = np.stack([rng.uniform(-90, 90, n), rng.uniform(0.5, 9, n), rng.uniform(-90, 90, n)], 1).astype(np.float32)
+    sph["c"] = rng.uniform(0.1, 0.9, (n, 3)).astype(np.float32)
+    sph["refl"] = rng.choice([api.DIFF, api.DIFF, api.SPEC, api.REFR], n)
+    sph["rad"][0], sph["p"][0], sph["refl"][0], sph["c"][0] = 1000.0, (0, -1000, 0), api.DIFF, (.75, .75, .75)
+    sph["rad"][1], sph["p"][1], sph["e"][1], sph["refl"][1] = 9.0, (0, 70, 0), (14, 14, 14), api.DIFF
+    return sph, host.DEMO_ORIG, host.DEMO_TARGET
+
+
+@pytest.mark.parametrize("n", [9500, 16384 + 2, 30000])
+def test_scenes_beyond_lds(n):
+    """More spheres than LDS can hold (the hierarchy's tables stop at ~2700 spheres, the sweep's at ~9700): the walk reads pairs and slots from HBM / L2
+    (rt_trace_parity_pairs_g); beyond 16 384 spheres in the tree the tables are built on the host.  Frames, seeds and
+    counters are still the oracle's."""
+    sph, orig, target = _many_spheres(n)
+    w, h, spp = 48, 32, 2
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp, threads=16)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        assert ctx.last_kernel == "rt_trace_parity_pairs_g"
+        _same(got, want)
+        b = bvh_check.read_bvh(ctx)
+        assert bvh_check.check_structure(api.as_spheres(sph), b, dfs=n <= 16384) == []   # (host-built trees leave the depth-first nodes out)
+        # the plain sweep over the table in HBM / L2 (what a scene without a hierarchy gets)
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
+        ctx.reset()
+        got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        assert ctx.last_kernel == ("rt_trace_parity_coop" if 16 * n + 64 <= 152 * 1024 else "rt_trace_parity_g")
+        _same(got, want)
+
+
+def test_the_scene_size_limit():
+    too_many = np.zeros(262144 + 1, api.SPHERE_DT)
+    with api.RtContext(32, 32) as ctx:
+        with pytest.raises(api.RtError):
+            ctx.set_scene(too_many)

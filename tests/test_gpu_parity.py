@@ -578,16 +578,20 @@ def test_random_operation_sequences_keep_the_running_average_exact():
     assert res.stdout.strip().splitlines()[-1].endswith("mismatches: []"), res.stdout[-2000:]
 
 
-def test_maximum_scene_size():
-    """RT_MAX_SPHERES (8192) spheres: 128 KiB of geometry in LDS, one workgroup per CU; one more is
-    refused with RT_ERR_ARG."""
+def test_largest_scene_with_its_tables_in_lds():
+    """8192 spheres: 128 KiB of geometry in LDS for the plain sweep, one workgroup per CU (the hierarchy, which
+    a scene of this size normally renders through, is switched off here); larger scenes: tests/test_gpu_bvh.py."""
     sph, orig, target = scenes.random_spheres(8192)
     cam = host.compute_camera(orig, target, 64, 40)
-    _assert_same(_gpu(sph, cam, 64, 40, 2), O.render(sph, cam, 64, 40, 2, threads=16))
-    too_many, _, _ = scenes.random_spheres(8193)
-    with api.RtContext(32, 32) as ctx:
-        with pytest.raises(api.RtError):
-            ctx.set_scene(too_many)
+    want = O.render(sph, cam, 64, 40, 2, threads=16)
+    _assert_same(_gpu(sph, cam, 64, 40, 2), want)
+    with api.RtContext(64, 40, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        got = {"pixels": ctx.render_pass(2), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        assert ctx.last_kernel == "rt_trace_parity_coop"
+    _assert_same(got, want)
 
 
 def test_long_accumulation_both_reciprocal_paths():

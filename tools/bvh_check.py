@@ -47,8 +47,9 @@ def read_bvh(ctx):
             "n_leaves": n_leaves, "n_nodes": n_nodes, "n_slots": n_slots}
 
 
-def check_structure(sph, b):
-    """Host-side walk of the device-built tables; returns a list of complaints (empty = fine)."""
+def check_structure(sph, b, dfs=True):
+    """Host-side walk of the tables the library built; returns a list of complaints (empty = fine).
+    dfs=False: skip the depth-first `nodes` section (trees built on the host leave it out)."""
     bad = []
     n = len(sph)
     na, nn, nl = b["n_always"], b["n_nodes"], b["n_leaves"]
@@ -73,42 +74,43 @@ def check_structure(sph, b):
         want = np.array([p[ix, 0], p[ix, 1], p[ix, 2], np.float32(rad[ix]) * np.float32(rad[ix])], np.float32)
         if not np.array_equal(want.view(np.uint32), b["slots"][j].view(np.uint32)):
             bad.append(f"slot {j} != record {ix}")
-    skip = b["link"] & 0xffff
-    leaf = (b["link"] >> 16).astype(np.int64) - 1
-    if not np.all(skip > np.arange(nn)):
-        bad.append("a skip link does not point forward")
-    if np.any(skip > nn):
-        bad.append("a skip link points past the end")
-    if sorted(leaf[leaf >= 0]) != list(range(nl)):
-        bad.append("leaf numbers are not 0..n_leaves-1, each once")
-    # subtree of node k = [k, skip[k]); every sphere below it inside its box, lowest index right
-    leaf_of_node = leaf
-    node_leaves = [[] for _ in range(nn)]
-    stack = []
-    for k in range(nn):
-        while stack and skip[stack[-1]] <= k:
-            stack.pop()
-        stack.append(k)
-        if leaf_of_node[k] >= 0:
-            for a in stack:
-                node_leaves[a].append(int(leaf_of_node[k]))
-    for k in range(nn):
-        members = []
-        for lf in node_leaves[k]:
-            members += [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size] if i != 0xffffffff]
-        if not members:
-            bad.append(f"node {k} has no sphere below it")
-            continue
-        m = np.array(members)
-        ar = np.abs(rad[m]).astype(np.float64)
-        lo = (p[m].astype(np.float64) - ar[:, None]).min(0)
-        hi = (p[m].astype(np.float64) + ar[:, None]).max(0)
-        if np.any(b["lo"][k] > lo) or np.any(b["hi"][k] < hi):
-            bad.append(f"node {k}: box does not hold its spheres")
-        if b["low"][k] != m.min():
-            bad.append(f"node {k}: lowest index {b['low'][k]} != {m.min()}")
-    if leaf_of_node[0] < 0 and nn > 1 and len(node_leaves[0]) != nl:
-        bad.append("the root does not reach every leaf")
+    if dfs:
+        skip = b["link"] & 0xffff
+        leaf = (b["link"] >> 16).astype(np.int64) - 1
+        if not np.all(skip > np.arange(nn)):
+            bad.append("a skip link does not point forward")
+        if np.any(skip > nn):
+            bad.append("a skip link points past the end")
+        if sorted(leaf[leaf >= 0]) != list(range(nl)):
+            bad.append("leaf numbers are not 0..n_leaves-1, each once")
+        # subtree of node k = [k, skip[k]); every sphere below it inside its box, lowest index right
+        leaf_of_node = leaf
+        node_leaves = [[] for _ in range(nn)]
+        stack = []
+        for k in range(nn):
+            while stack and skip[stack[-1]] <= k:
+                stack.pop()
+            stack.append(k)
+            if leaf_of_node[k] >= 0:
+                for a in stack:
+                    node_leaves[a].append(int(leaf_of_node[k]))
+        for k in range(nn):
+            members = []
+            for lf in node_leaves[k]:
+                members += [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size] if i != 0xffffffff]
+            if not members:
+                bad.append(f"node {k} has no sphere below it")
+                continue
+            m = np.array(members)
+            ar = np.abs(rad[m]).astype(np.float64)
+            lo = (p[m].astype(np.float64) - ar[:, None]).min(0)
+            hi = (p[m].astype(np.float64) + ar[:, None]).max(0)
+            if np.any(b["lo"][k] > lo) or np.any(b["hi"][k] < hi):
+                bad.append(f"node {k}: box does not hold its spheres")
+            if b["low"][k] != m.min():
+                bad.append(f"node {k}: lowest index {b['low'][k]} != {m.min()}")
+        if leaf_of_node[0] < 0 and nn > 1 and len(node_leaves[0]) != nl:
+            bad.append("the root does not reach every leaf")
     # the same tree as sibling pairs: from the root every leaf is reached exactly once, every child box holds the
     # spheres below it and knows their lowest scene index
     LEAF = 0x8000
