@@ -388,8 +388,10 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     else if (c->mode >= 200) { variant = c->mode - 200; use_fast_table = true; }
     else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
     if (c->mode >= 100) {
-        const bool wants_bvh = use_fast_table ? (variant >= rt::kFastBvhVariant && variant <= rt::kFastPairsVariant)
-                                              : (variant >= rt::kParityBvhVariant && variant <= rt::kParityPairsVariant + 1);
+        const bool pairs_g = variant == (use_fast_table ? rt::kFastPairsGlobalVariant : rt::kParityPairsGlobalVariant);
+        const bool plain_g = variant == (use_fast_table ? rt::kFastGlobalVariant : rt::kParityGlobalVariant);
+        const bool wants_bvh = pairs_g || (use_fast_table ? (variant >= rt::kFastBvhVariant && variant <= rt::kFastPairsVariant)
+                                                          : (variant >= rt::kParityBvhVariant && variant <= rt::kParityPairsVariant + 1));
         p.bvh = rt::BvhTables{};
         lds_use = lds;
         if (wants_bvh) {
@@ -398,12 +400,15 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
             p.bvh = c->bvh;
             const bool walk = use_fast_table ? variant == rt::kFastWalkVariant : variant >= rt::kParityWalkVariant;
             const bool pairs = use_fast_table ? variant == rt::kFastPairsVariant : variant >= rt::kParityPairsVariant;
-            lds_use = pairs ? rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_leaves,
-                                                  c->bvh.n_slots, c->bvh.stack_depth, 256)
-                            : rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
-                                                c->bvh.n_slots, full, !walk);
+            lds_use = pairs_g ? rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256)
+                      : pairs ? rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_leaves,
+                                                    c->bvh.n_slots, c->bvh.stack_depth, 256)
+                              : rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
+                                                  c->bvh.n_slots, full, !walk);
             if (lds_use > 152 * 1024) return fail(RT_ERR_ARG, "mode %d needs %zu B of LDS", c->mode, lds_use);
         }
+        if (pairs_g || plain_g) p.mat_in_lds = 0;
+        if (plain_g) lds_use = rt::lds_bytes(0, 0, false, n_samples);
     }
 #endif
     const int waves = use_fast_table ? rt::fast_variant_waves(variant) : rt::parity_variant_waves(variant);

@@ -153,14 +153,31 @@ def test_update_spheres_argument_checks_and_refused_scene_keeps_the_old_one():
         ctx.set_camera(cam)
         with pytest.raises(api.RtError):
             ctx.update_spheres(5, sph[:2])                                     # runs past the end
-        too_many = np.zeros(8193, api.SPHERE_DT)
+        too_many = np.zeros(262144 + 1, api.SPHERE_DT)                         # RT_MAX_SPHERES + 1
         with pytest.raises(api.RtError):
             ctx.set_scene(too_many)
-        lit = np.zeros(8000, api.SPHERE_DT)
-        lit["e"][:] = 1.0                                                      # 8000 lights: the light list alone overflows the LDS
-        with pytest.raises(api.RtError):
-            ctx.set_scene(lit)
         assert np.array_equal(ctx.render_pass(2), want)                        # the Demo scene is still in place
+
+
+def test_thousands_of_lights_do_not_need_lds():
+    """6000 emitters: the light list alone (32 B each) is beyond LDS; every diffuse hit samples all of them."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    sph = np.zeros(n, api.SPHERE_DT)
+    sph["rad"] = rng.uniform(0.2, 0.6, n).astype(np.float32)
+    sph["p"] = np.stack([rng.uniform(-60, 60, n), rng.uniform(5, 40, n), rng.uniform(-60, 60, n)], 1).astype(np.float32)
+    sph["e"] = rng.uniform(0.5, 3.0, (n, 3)).astype(np.float32)
+    sph["rad"][0], sph["p"][0], sph["e"][0], sph["c"][0] = 1000.0, (0, -1000, 0), (0, 0, 0), (.7, .7, .7)
+    w, h, spp = 16, 12, 1
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    want = O.render(sph, cam, w, h, spp, threads=16)
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        assert np.array_equal(ctx.render_pass(spp), want["pixels"])
+        assert ctx.last_kernel.endswith("_g")
+        st = ctx.stats()
+        assert (st["shadow_rays"], st["sphere_tests"], st["rng_draws"]) == (want["stats"]["shadow_calls"], want["stats"]["sphere_tests"], want["stats"]["rng_draws"])
 
 
 def test_scene_replaced_between_frames_without_a_device_wide_wait():
@@ -218,7 +235,7 @@ def test_rt_render_repeated_calls_reuse_device_state_and_stay_bit_exact():
             assert np.array_equal(api.render(sph, cam, w, h, spp), O.render(sph, cam, w, h, spp)["pixels"]), (rnd, w, h)
     # a failing call must not poison the cache
     with pytest.raises(api.RtError):
-        api.render(np.zeros(9000, api.SPHERE_DT), host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64), 96, 64, 1)
+        api.render(np.zeros(262144 + 1, api.SPHERE_DT), host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64), 96, 64, 1)
     sph = host.demo_scene()
     cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 96, 64)
     assert np.array_equal(api.render(sph, cam, 96, 64, 2), O.render(sph, cam, 96, 64, 2)["pixels"])
