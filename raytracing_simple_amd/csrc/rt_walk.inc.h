@@ -1,30 +1,33 @@
-// rt_walk.inc.h -- the path-trace kernel for large scenes (RT_OPT_BVH == 4), included by rt_trace.inc.h in
+// rt_walk.inc.h -- the path-trace kernel for large scenes (RT_OPT_BVH >= 4), included by rt_trace.inc.h in
 // place of its own kernel body; everything above it there (vector helpers, RNG, the sphere test, the sweeps,
-// sample_light, the hierarchy walk's ray set-up and slab test) is shared.
+// sample_light, the hierarchy walk's ray set-up, slab test and pair walk) is shared.
 //
 // Same mapping (one lane = one pixel, the spp loop and the path state in registers), same arithmetic, same
 // order of random draws per pixel -- but the lanes of a wavefront are decoupled once more.  A census of the
 // walk-per-call form (RT_OPT_BVH 1: every lane walks the hierarchy to the end inside its closest-hit / shadow
-// call) showed 13 of 64 lanes busy per node step on closest-hit rays and 6 of 64 on shadow rays: a ray takes 28 /
-// 38 node tests on average (1024 spheres), the slowest of a wavefront's rays five times that, and everybody
-// waits for it.  Here a ray's walk is lane state (node, bound, best so far) that survives loop trips:
+// call) showed 13 of 64 lanes busy per node step on closest-hit rays and 6 of 64 on shadow rays: the slowest of
+// a wavefront's rays takes five times the average, and everybody waits for it.  Here a ray's walk is lane state
+// (where it is in the tree, its stack, the bound, the best so far) that survives loop trips:
 //
-//   T  every lane with a walk in flight takes up to P.walk_steps node tests (closest-hit and shadow rays run the
-//      same loop; they differ in how a candidate updates the state);
+//   T  every lane with a walk in flight takes up to P.walk_steps steps of it (walk_pairs in rt_trace.inc.h; closest-
+//      hit and shadow rays run the same loop, they differ in how a candidate updates the state);
 //   S  lanes whose walk has ended (or that have no ray) do what comes next for them -- process the hit, sample
 //      the next light and start its shadow ray, add the light's contribution, bounce, finish the sample, start
 //      a camera ray -- once P.regen_gate of them are waiting or nobody is walking, and then join T again.
 //
-// So the walk runs with nearly all lanes busy, at the price of running the shading sections for the part of
-// the wavefront that is ready.  Nothing here depends on which trip a lane does what: per pixel the sequence of
-// operations and random draws is the reference's.
+// Nothing here depends on which trip a lane does what: per pixel the sequence of operations and random draws is the
+// reference's.  What it buys and what is left (a third of the lane slots busy): DESIGN.md section 5.
+//
+// Forms: RT_OPT_BVH 6 = sibling pairs, nearer child first, a per-lane stack in LDS (shipped; with RT_OPT_GLOBAL_TABLES
+// the pairs and slots are read where they lie in HBM / L2); 4 = depth-first nodes with skip links (A/B); 5 / 7 = the
+// census instances of 4 / 6.
 
 #undef RT_OPT_WALK_PAIRS
 #undef RT_WALKING
 #undef RT_WALK_START
 #undef RT_WALK_COUNT
 #undef RT_WALK_CLOCK
-#define RT_OPT_WALK_PAIRS (RT_OPT_BVH >= 6)     /* 6: sibling pairs, nearer child first (the shipped form); 4: depth-first nodes with skip links */
+#define RT_OPT_WALK_PAIRS (RT_OPT_BVH >= 6)
 
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
