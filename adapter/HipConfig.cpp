@@ -36,7 +36,18 @@ void HipConfig::freeBuffer() {                           // OpenCLConfig.cpp:684
     pPixels = nullptr;
 }
 
+// Passes that execute() has counted but not launched belong to the scene and camera they were asked under.
+void HipConfig::launchPending(bool withPixels) {
+    if (pending == 0) return;
+    if (rt_set_pixel_write(ctx, withPixels ? 1 : 0) != RT_OK ||
+        rt_render_async(ctx, pending, rt_stream(ctx)) != RT_OK)
+        die("Failed to render a pass");
+    pending = 0;
+}
+
 void HipConfig::sceneSetup(const std::vector<Sphere>& spheres, Vec orig, Vec target) {   // :720-747
+    std::lock_guard<std::mutex> lock(guard);
+    launchPending(false);
     if (rt_set_scene(ctx, reinterpret_cast<const rt_sphere*>(spheres.data()),
                      static_cast<uint32_t>(spheres.size())) != RT_OK)
         die("Failed to upload the scene");
@@ -45,6 +56,8 @@ void HipConfig::sceneSetup(const std::vector<Sphere>& spheres, Vec orig, Vec tar
 }
 
 void HipConfig::updateCamera() {                         // OpenCLConfig.cpp:386-392
+    std::lock_guard<std::mutex> lock(guard);
+    launchPending(false);
     computeCameraVariables(&camera, mWidth, mHeight);
     rt_camera c;
     memcpy(&c, &camera, sizeof c);
@@ -60,6 +73,7 @@ void HipConfig::updateCamera() {                         // OpenCLConfig.cpp:386
 unsigned* HipConfig::getPixels() {
     std::lock_guard<std::mutex> lock(guard);
     if (stale) {
+        launchPending(true);
         if (rt_read_pixels(ctx, reinterpret_cast<uint32_t*>(pPixels)) != RT_OK) die("Failed to read the frame back");
         stale = false;
     }
@@ -70,20 +84,35 @@ void HipConfig::setArguments() {}                        // OpenCLConfig.cpp:517
 
 // One pass.  The reference reads the frame back after EVERY pass (OpenCLConfig.cpp:498-512) although
 // the window only looks at it when it redraws (SetupGL.cpp:59-63, unsynchronised).  A pass takes
-// 0.05-0.12 ms on an MI355X and the 8.3 MB readback of a 1080p frame three times that, so the frame
-// is copied when it is due for display: on pass 0 and then every readbackMs (8 ms unless
-// RT_READBACK_MS says otherwise; 0 = after every pass, the reference's cadence).  The passes in
-// between are only queued (rt_render_async on the context's stream); the copy that is due waits for
-// them, which also bounds the queue to readbackMs of work.
+// 0.04-0.12 ms on an MI355X, the 8.3 MB readback of a 1080p frame three times that, and a launch of one pass
+// costs twice what the pass costs inside a longer launch (prologue, epilogue, the seed / colour round trip through
+// HBM).  So: the frame is copied when it is due for display -- on pass 0 and then every readbackMs (8 ms unless
+// RT_READBACK_MS says otherwise; 0 = after every pass, the reference's cadence) -- and the passes in between are
+// counted here and launched `batch` at a time, about a millisecond of work per launch (1080p: 11 900 passes/s one
+// per launch, 21 800 at 16).  The copy that is due launches what is pending and waits for everything queued, which
+// also bounds the queue to readbackMs of work.  Scene and camera changes and getPixels() launch what is pending first.
 void HipConfig::execute() {                              // OpenCLConfig.cpp:407-515
     std::lock_guard<std::mutex> lock(guard);
     const auto now = std::chrono::steady_clock::now();
     const bool due = mCurrentSample == 0 || readbackMs <= 0.0 ||
                      std::chrono::duration<double, std::milli>(now - lastReadback).count() >= readbackMs;
-    rt_set_pixel_write(ctx, due ? 1 : 0);       // passes nobody looks at skip the gamma + pixel store
-    const int rc = due ? rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), 1)
-                       : rt_render_async(ctx, 1, rt_stream(ctx));
-    if (rc != RT_OK) die("Failed to render a pass");
-    stale = !due;
-    if (due) lastReadback = now;
+    pending += 1;
+    if (due) {
+        const int n = pending;
+        pending = 0;
+        if (rt_set_pixel_write(ctx, 1) != RT_OK ||
+            rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), n) != RT_OK)
+            die("Failed to render a pass");
+        stale = false;
+        lastReadback = now;
+        rt_stats st;                                    // size the batches from the launch that just finished
+        if (n >= 4 && rt_get_stats(ctx, &st) == RT_OK && st.last_kernel_ms > 0.0) {
+            const double per_pass = st.last_kernel_ms / n;
+            const int want = static_cast<int>(1.0 / per_pass + 0.5);
+            batch = want < 1 ? 1 : (want > 64 ? 64 : want);
+        }
+    } else {
+        stale = true;
+        if (pending >= batch) launchPending(false);     // passes nobody looks at skip the gamma + pixel store
+    }
 }

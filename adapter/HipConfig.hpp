@@ -31,7 +31,7 @@ public:
 
 private:
     void setArguments() override;   // nothing to bind: the context holds the arguments
-    void execute() override;        // one pass = rt_render_pass(ctx, pPixels or NULL, 1)
+    void execute() override;        // one pass (counted; launched in batches between two display copies)
     void allocateBuffer() override;
     void freeBuffer() override;
 
@@ -43,6 +43,9 @@ private:
     double readbackMs = 8.0;        // copy the frame to pPixels when it is this old (0 = every pass)
     std::chrono::steady_clock::time_point lastReadback{};
     bool stale = false;             // passes have run since pPixels was last brought up to date
+    int pending = 0;                // passes execute() has counted and not launched yet
+    int batch = 16;                 // launch them this many at a time (about a millisecond of work: set from the measured pass time)
+    void launchPending(bool withPixels);
     std::mutex guard;               // execute() runs on the compute thread, getPixels() on the caller's (Main.cpp:96-106)
 };
 

@@ -43,27 +43,29 @@ public:
 private:
     using clock = std::chrono::steady_clock;
 
-    // One pass per trip, like Config::updateRendering.  A pass takes 0.05-0.12 ms on an MI355X and the
-    // read-back of a 1080p frame several times that, so a frame is copied out when it is due for display
-    // (pass 0, then every readback_ms; 0 = after every pass, the reference's cadence); the passes in between
-    // are only queued, without the gamma/pack step nobody would look at (rt_set_pixel_write(0)).
+    // Config::updateRendering's loop.  A pass takes 0.04-0.12 ms on an MI355X and the read-back of a 1080p frame
+    // several times that, so a frame is copied out when it is due for display (pass 0, then every readback_ms;
+    // 0 = after every pass, the reference's cadence); the passes in between are queued `batch` per launch (about a
+    // millisecond of work: a launch of one pass costs twice what the pass costs inside a longer launch), without
+    // the gamma/pack step nobody would look at (rt_set_pixel_write(0)).
     void loop() {
         auto last_copy = clock::now(), caption_t0 = last_copy;
         rt_stats prev{};
-        int pass = 0, caption_pass0 = 0;
+        int pass = 0, caption_pass0 = 0, batch = 1;
         while (!quit.load() && (max_passes <= 0 || pass < max_passes)) {
             const auto now = clock::now();
-            const bool last = max_passes > 0 && pass + 1 == max_passes;
-            const bool due = pass == 0 || last || readback_ms <= 0.0 ||
+            const int left = max_passes > 0 ? max_passes - pass : batch + 1;
+            const bool due = pass == 0 || left == 1 || readback_ms <= 0.0 ||
                              std::chrono::duration<double, std::milli>(now - last_copy).count() >= readback_ms;
+            const int n = due ? 1 : (batch < left - 1 ? batch : left - 1);       // (the last pass is a due one)
             int rc = rt_set_pixel_write(ctx, due ? 1 : 0);
-            if (rc == RT_OK) rc = due ? rt_render_pass(ctx, exchange.back(), 1) : rt_render_async(ctx, 1, rt_stream(ctx));
+            if (rc == RT_OK) rc = due ? rt_render_pass(ctx, exchange.back(), 1) : rt_render_async(ctx, n, rt_stream(ctx));
             if (rc != RT_OK) {
                 fprintf(stderr, "Failed to render a pass: %s\n", rt_last_error());
                 error.store(true);
                 break;
             }
-            ++pass;
+            pass += n;
             if (due) {
                 exchange.publish(static_cast<uint64_t>(pass));
                 last_copy = now;
@@ -78,6 +80,10 @@ private:
                     prev = st;
                     caption_t0 = clock::now();
                     caption_pass0 = pass;
+                    if (st.last_kernel_ms > 0.0 && readback_ms > 0.0) {      // the one-pass launch just timed: size the batches
+                        const int want = static_cast<int>(1.0 / st.last_kernel_ms + 0.5);
+                        batch = want < 1 ? 1 : (want > 64 ? 64 : want);
+                    }
                 }
             }
         }
