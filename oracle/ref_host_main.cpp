@@ -11,7 +11,7 @@
 // (Config.cpp:63-65), so the object is constructed here the way INTEGRATION.md's factory edit
 // would construct it.
 //
-//   ref_host_hip <passes> <width> <height> <out.ppm> [scene.scn]
+//   ref_host_hip <passes> <width> <height> <out.ppm> [scene.scn]        (RT_TEST_MOVE_CAMERA_AT=K: see below)
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -47,7 +47,18 @@ int main(int argc, char** argv) {
 
     char caption[256] = "";
     config->setCaptionBuffer(caption);                                    // SetupGL.cpp:83
-    for (int i = 0; i < passes; ++i) config->updateRendering();           // Main.cpp:96-102
+    // RT_TEST_MOVE_CAMERA_AT=K (tests only): after K passes the eye moves by (5, 3, -4) and the accumulation goes on --
+    // passes the backend had only counted or queued at that point belong to the OLD camera
+    const char* move_at = getenv("RT_TEST_MOVE_CAMERA_AT");
+    const int k_move = move_at ? atoi(move_at) : -1;
+    for (int i = 0; i < passes; ++i) {                                    // Main.cpp:96-102
+        if (i == k_move) {
+            orig = { orig.x + 5.f, orig.y + 3.f, orig.z - 4.f };
+            config->sceneSetup(spheres, orig, target);
+            config->updateCamera();
+        }
+        config->updateRendering();
+    }
     fprintf(stderr, "%s", caption);
 
     const unsigned* px = config->getPixels();                             // SetupGL.cpp:85

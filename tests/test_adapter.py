@@ -206,6 +206,17 @@ def test_reference_host_code_drives_the_hip_backend(tmp_path, golden_dir):
         assert "pass %d" % passes in res.stderr
         wantp = O.render(O.demo_spheres(), O.camera((20.0, 100.0, 120.0), (0.0, 25.0, 0.0), 64, 48), 64, 48, passes)
         assert np.array_equal(frame(out, 64, 48), rgb(wantp["pixels"], 64, 48)), passes
+    # passes the adapter had only counted (it launches them in batches) when the camera moves belong to the old camera
+    w, h, passes, k = 64, 48, 90, 37
+    out = tmp_path / "moved.ppm"
+    res = subprocess.run([REF_HOST, str(passes), str(w), str(h), str(out)], env=dict(os.environ, RT_TEST_MOVE_CAMERA_AT=str(k)),
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    sph = O.demo_spheres()
+    first = O.render(sph, O.camera((20.0, 100.0, 120.0), (0.0, 25.0, 0.0), w, h), w, h, k)
+    both = O.render(sph, O.camera((25.0, 103.0, 116.0), (0.0, 25.0, 0.0), w, h), w, h, passes - k, first_sample=k,
+                    seeds_in=first["seeds"], colors_in=first["colors"])
+    assert np.array_equal(frame(out, w, h), rgb(both["pixels"], w, h))
 
 
 @pytest.mark.gpu
