@@ -336,6 +336,7 @@ def main():
         elF, _, _ = timed_region(ctxs, side_streams, F, args.steps, args.warmup, with_events=False)
     st = frame_counters(ctx)
     kernel_name = ctx.last_kernel           # the instance the library renders this scene with (rt_last_kernel)
+    choice = ctx.scene_choice()             # large scenes: what the library's own measurement of hierarchy against sweep said
 
     samples, closest, shadow, tests = (int(v) for v in all_ranks([st["samples"], st["closest_rays"], st["shadow_rays"], st["sphere_tests"]],
                                                                   dist.ReduceOp.SUM if world > 1 else None))
@@ -494,6 +495,11 @@ def main():
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_max_rank": round(kernel_ms_max, 4),
             "algorithmic_flops_per_launch": flops,
+            "measured_choice": None if choice["picked"] is None else
+            {"picked": choice["picked"], "hierarchy_ms_per_pass": round(choice["hierarchy_ms_per_pass"], 4),
+             "sweep_ms_per_pass": round(choice["sweep_ms_per_pass"], 4),
+             "note": "the library timed one launch of each form on this scene (rt_scene_choice); the sweep is the wave-ballot "
+                     "any-hit instance (rt_trace_*_coop)"},
             "work_model": "the reference's sweep: every ray tests the spheres in scene order (all of them, or up to its first blocker)"
                           + ("; this scene renders through the hierarchy (chosen by measurement), which returns the same frames and counters from "
                              "far fewer executed tests: `achieved` is reference-equivalent work per second, not executed arithmetic"

@@ -14,7 +14,7 @@ RT_MODE_PARITY, RT_MODE_FAST = 0, 1
 DIFF, SPEC, REFR = 0, 1, 2
 
 # every symbol include/rt_api.h declares = the export table of librt_hip.so (tests/test_abi.py)
-SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_create_multi_on", "rt_shard_count", "rt_last_kernel",
+SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_create_multi_on", "rt_shard_count", "rt_last_kernel", "rt_scene_choice",
            "rt_create_sharded", "rt_destroy", "rt_set_scene", "rt_update_spheres_async",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
            "rt_pin_output", "rt_set_pixel_write", "rt_read_pixels", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream",
@@ -76,6 +76,7 @@ def load_library(diag=False):
         "rt_create_multi_on": (i32, [C.POINTER(vp), i32, i32, C.POINTER(i32), i32, i32]),
         "rt_shard_count": (i32, [vp]),
         "rt_last_kernel": (C.c_char_p, [vp]),
+        "rt_scene_choice": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rt_update_spheres_async": (i32, [vp, u32, u32, vp, vp]),
         "rt_read_pixels": (i32, [vp, vp]),
         "rt_deinterleave_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -282,6 +283,12 @@ class RtContext:
     def last_kernel(self):
         """Symbol of the kernel instance the last launch used (rt_last_kernel)."""
         return self._lib.rt_last_kernel(self._h).decode()
+
+    def scene_choice(self):
+        """rt_scene_choice: {'picked': 0 | 'hierarchy' | 'sweep', and the two measured ms per pass}."""
+        a, b = C.c_double(), C.c_double()
+        k = self._lib.rt_scene_choice(self._h, C.byref(a), C.byref(b))
+        return {"picked": {0: None, 1: "hierarchy", 2: "sweep"}.get(k), "hierarchy_ms_per_pass": a.value, "sweep_ms_per_pass": b.value}
 
     @property
     def shard_count(self):

@@ -490,6 +490,8 @@ void probe_poll(rt_ctx *c, bool wait) {
         return;
     }
     const double ta = (double)a / c->probe_samples[0], tb = (double)b / c->probe_samples[1];
+    c->probe_ms[0] = ta;
+    c->probe_ms[1] = tb;
     c->bvh_pick = ta <= 1.1 * tb ? 1 : 2;       // (the second probe may already run heavy tiles first)
 }
 
@@ -748,6 +750,15 @@ RT_API void rt_destroy(rt_ctx *c) {
     delete c;
 }
 
+RT_API int rt_scene_choice(rt_ctx *c, double *hierarchy_ms_per_pass, double *sweep_ms_per_pass) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    rt_ctx *s = c->multi ? rt::multi_first_shard(c) : c;
+    if (select_device(s) == RT_OK) probe_poll(s, false);
+    if (hierarchy_ms_per_pass) *hierarchy_ms_per_pass = s->probe_ms[0];
+    if (sweep_ms_per_pass) *sweep_ms_per_pass = s->probe_ms[1];
+    return s->bvh_pick;
+}
+
 RT_API const char *rt_last_kernel(const rt_ctx *c) { return !c ? "" : (c->multi ? rt::multi_last_kernel(c) : c->last_kernel); }
 
 RT_API int rt_shard_count(const rt_ctx *c) { return !c ? RT_ERR_ARG : (c->multi ? rt::multi_shards(c) : 1); }
@@ -770,6 +781,7 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     c->cost_valid = c->order_valid = false;
     c->bvh_pick = 0;                    // a new scene: hierarchy or plain sweep is measured again
     c->probe_state = 0;
+    c->probe_ms[0] = c->probe_ms[1] = 0.0;
     rc = upload_spheres(c, 0, count, spheres, count, c->stream);
     if (rc != RT_OK) {
         c->have_scene = false;          // the tables are in an unknown state

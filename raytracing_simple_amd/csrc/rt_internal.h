@@ -47,6 +47,7 @@ struct rt_ctx {
     int bvh_pick = 0;                   // 0 = not decided yet, 1 = hierarchy, 2 = plain sweep
     int probe_state = 0;                // probes issued (0..2)
     int probe_samples[2] = { 0, 0 };
+    double probe_ms[2] = { 0.0, 0.0 };  // measured time per pass: hierarchy, plain sweep (0 = not measured)
     hipEvent_t probe_ev[4] = { nullptr, nullptr, nullptr, nullptr };
     std::vector<unsigned char> is_light;   // host mirror of the light test per sphere (sizes the light list)
     std::vector<rt_sphere> h_spheres;      // host mirror of the records (an identical rt_set_scene uploads nothing)
@@ -123,6 +124,7 @@ int multi_pin_output(rt_ctx *front, uint32_t *out_host, size_t count);
 void *multi_stream(rt_ctx *front);
 int multi_shards(const rt_ctx *front);
 const char *multi_last_kernel(const rt_ctx *front);
+rt_ctx *multi_first_shard(rt_ctx *front);
 int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg);
 
 }  // namespace rt

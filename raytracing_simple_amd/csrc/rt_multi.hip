@@ -242,6 +242,7 @@ void multi_destroy(rt_ctx *front) {
 }
 
 int multi_shards(const rt_ctx *front) { return front->multi->n; }
+rt_ctx *multi_first_shard(rt_ctx *front) { return front->multi->shard.empty() ? front : front->multi->shard[0]; }
 const char *multi_last_kernel(const rt_ctx *front) { return front->multi->shard.empty() ? "" : front->multi->shard[0]->last_kernel; }
 
 #define EACH_SHARD(expr)                          \

@@ -200,8 +200,12 @@ def test_last_kernel_names_the_instance_the_scene_got():
         assert ctx.last_kernel == "rt_trace_parity_pairs"
         ctx.render_pass(1)                    # the second sweeps; the faster form renders the rest
         assert ctx.last_kernel == "rt_trace_parity_coop"
+        assert ctx.scene_choice()["picked"] in (None, "hierarchy", "sweep")   # (asked without blocking: may still be open)
         ctx.render_pass(40)
         assert ctx.last_kernel in ("rt_trace_parity_pairs", "rt_trace_parity_coop")
+        ch = ctx.scene_choice()                                    # both probes finished before that blocking call returned
+        assert ch["picked"] == ("hierarchy" if ctx.last_kernel.endswith("pairs") else "sweep")
+        assert ch["hierarchy_ms_per_pass"] > 0 and ch["sweep_ms_per_pass"] > 0
 
 
 def test_multi_device_context_with_a_large_scene():
