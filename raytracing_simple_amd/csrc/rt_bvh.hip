@@ -15,10 +15,12 @@ namespace {
 //   1. a sphere stays outside the tree ("always" list, scene order kept) unless its radius and centre are finite and
 //      |rad| <= r_cut (the host derives r_cut from the median radius: ground planes, walls and lights the size of
 //      the scene would blow up every box above them);
-//   2. the tree's spheres are sorted along a 30-bit Morton curve through the box of their centres (bitonic sort of
-//      key << 32 | scene index in LDS);
-//   3. leaves take kBvhLeaf consecutive spheres; the tree over the leaves splits every range in the middle and is
-//      laid out depth-first, so a node's first child is the next node and `skip` = node + size of its subtree;
+//   2. the tree's shape is fixed: leaves of kBvhLeaf spheres, leaf ranges split in the middle, laid out depth-first
+//      (a node's first child is the next node, `skip` = node + size of its subtree) and as sibling pairs;
+//   3. who sits in which leaf is decided top-down: the spheres of a node are sorted along the longest axis of the box
+//      of their centres, the left child takes the first half of the node's leaves (a median split by count; one
+//      bitonic sort per level in LDS).  Against sorting once along a Morton curve this cuts the surface-area cost of
+//      the tree by a third (tools/tree_quality.py), which is what the walk pays for;
 //   4. boxes are rounded outwards; every node also carries the lowest scene index below it.
 // Host and device agree on the counts because they apply the same test to the same bits (bvh_outside).
 __host__ __device__ inline bool bvh_outside(float rad, float px, float py, float pz, float r_cut) {
@@ -31,20 +33,26 @@ __device__ inline unsigned bvh_ordered(float f) {          // unsigned order = f
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ inline float bvh_unordered(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
-__device__ inline unsigned bvh_spread(unsigned v) {        // 10 bits -> every third bit
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
 __device__ inline float bvh_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
 __device__ inline float bvh_up(float v) { return v + (fabsf(v) * 0x1p-22f + 1e-30f); }
+
+// the node of `level` (or the shallower single-leaf node) that leaf `leaf` lies in, numbered left to right at that level;
+// bit 31 set: the node is one leaf (nothing to order)
+__device__ inline uint32_t bvh_node_of(uint32_t leaf, uint32_t level, uint32_t n_leaves) {
+    uint32_t a = 0, b = n_leaves, rank = 0, s2 = 0;
+    for (; s2 < level; ++s2) {
+        if (b - a == 1) break;
+        const uint32_t mid = (a + b) / 2;
+        if (leaf < mid) { b = mid; rank = 2 * rank; }
+        else { a = mid; rank = 2 * rank + 1; }
+    }
+    return (rank << (level - s2)) | ((b - a == 1) ? 0x80000000u : 0u);
+}
 
 __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, uint32_t n, float r_cut, uint32_t n_always,
                                                             uint32_t n_tree, uint32_t n_pad, float4 *blob) {
     extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, later 2 float4 per leaf
-    __shared__ unsigned s_lo[3], s_hi[3], s_rmin, s_rmax;
+    __shared__ unsigned s_rmin, s_rmax;
     __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad;
     const unsigned tid = threadIdx.x, wave = tid >> 6;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
@@ -52,25 +60,18 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
     const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
     float4 *hdr = blob, *nodes = blob + 2, *slots = nodes + 2 * (size_t)n_nodes;
     uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
-    if (tid < 3) { s_lo[tid] = 0xffffffffu; s_hi[tid] = 0u; }
     if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; }
     for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
     __syncthreads();
-    // ---- 1. box of the tree's centres, radius range ----
+    // ---- 1. radius range of the tree's spheres ----
     for (uint32_t i = tid; i < n; i += 1024) {
         const float *r = reinterpret_cast<const float *>(sph + i);
         if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
-            atomicMin(&s_lo[0], bvh_ordered(r[1])); atomicMax(&s_hi[0], bvh_ordered(r[1]));
-            atomicMin(&s_lo[1], bvh_ordered(r[2])); atomicMax(&s_hi[1], bvh_ordered(r[2]));
-            atomicMin(&s_lo[2], bvh_ordered(r[3])); atomicMax(&s_hi[2], bvh_ordered(r[3]));
-            atomicMin(&s_rmin, __float_as_uint(fabsf(r[0]))); atomicMax(&s_rmax, __float_as_uint(fabsf(r[0])));
+            atomicMin(&s_rmin, __float_as_uint(fabsf(r[0])));
+            atomicMax(&s_rmax, __float_as_uint(fabsf(r[0])));
         }
     }
-    __syncthreads();
-    const float lox = bvh_unordered(s_lo[0]), loy = bvh_unordered(s_lo[1]), loz = bvh_unordered(s_lo[2]);
-    const float kx = 1023.f / fmaxf(bvh_unordered(s_hi[0]) - lox, 1e-30f), ky = 1023.f / fmaxf(bvh_unordered(s_hi[1]) - loy, 1e-30f),
-                kz = 1023.f / fmaxf(bvh_unordered(s_hi[2]) - loz, 1e-30f);
-    // ---- 2. the always list in scene order, the tree's keys in any order (ballot prefix per 1024 records) ----
+    // ---- 2. the always list in scene order, the tree's spheres in scene order for a start (ballot prefix per 1024 records) ----
     for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
         const uint32_t i = i0 + tid;
         bool out = false, in = false;
@@ -95,10 +96,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
         }
         if (in) {
             const uint32_t j = off_t + before_t;
-            const unsigned qx = (unsigned)fminf(fmaxf((px - lox) * kx, 0.f), 1023.f), qy = (unsigned)fminf(fmaxf((py - loy) * ky, 0.f), 1023.f),
-                           qz = (unsigned)fminf(fmaxf((pz - loz) * kz, 0.f), 1023.f);
-            const unsigned code = (bvh_spread(qx) << 2) | (bvh_spread(qy) << 1) | bvh_spread(qz);
-            if (j < n_tree) s_keys[j] = ((unsigned long long)code << 32) | i;
+            if (j < n_tree) s_keys[j] = i;
             else atomicAdd(&s_bad, 1u);
         }
         __syncthreads();
@@ -106,22 +104,71 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
             for (int k = 0; k < 16; ++k) { s_base_a += s_wave_a[k]; s_base_t += s_wave_t[k]; }
         __syncthreads();
     }
-    for (uint32_t k = 2; k <= n_pad; k <<= 1) {             // bitonic sort, ascending
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < n_pad; i += 1024) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = s_keys[i], b = s_keys[l];
-                    if ((a > b) == ((i & k) == 0)) { s_keys[i] = b; s_keys[l] = a; }
-                }
+    // ---- 2b. order: level by level, the spheres of every node are sorted along the longest axis of the box of
+    //      their centres; the node's left child then takes the first half of its leaves, the right child the rest
+    //      (the tree's shape -- leaf ranges split in the middle -- is fixed; this decides who sits where).  One
+    //      bitonic sort per level over keys  node << 50 | ordered(coordinate) << 18 | scene index: segments never mix.
+    uint32_t depth = 0;
+    while ((1u << depth) < n_leaves) depth += 1;
+    unsigned *s_box = reinterpret_cast<unsigned *>(s_keys + n_pad);      // per node of the level: lo[3], hi[3] (ordered), then the axis
+    constexpr unsigned long long kIdxMask = (1ull << 18) - 1;
+    for (uint32_t level = 0; level < depth; ++level) {
+        const uint32_t n_level = 1u << level;
+        for (uint32_t q = tid; q < n_level; q += 1024) {
+            s_box[7 * q + 0] = s_box[7 * q + 1] = s_box[7 * q + 2] = 0xffffffffu;
+            s_box[7 * q + 3] = s_box[7 * q + 4] = s_box[7 * q + 5] = 0u;
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < n_tree; j += 1024) {
+            const uint32_t node = bvh_node_of(j / rt::kBvhLeaf, level, n_leaves);
+            if (node & 0x80000000u) continue;
+            const uint32_t rank = node;
+            const float *r = reinterpret_cast<const float *>(sph + (uint32_t)(s_keys[j] & kIdxMask));
+            for (int a3 = 0; a3 < 3; ++a3) {
+                atomicMin(&s_box[7 * rank + a3], bvh_ordered(r[1 + a3]));
+                atomicMax(&s_box[7 * rank + 3 + a3], bvh_ordered(r[1 + a3]));
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < n_level; q += 1024) {
+            float ext[3];
+            for (int a3 = 0; a3 < 3; ++a3) {
+                const unsigned ulo = s_box[7 * q + a3], uhi = s_box[7 * q + 3 + a3];
+                ext[a3] = uhi >= ulo ? bvh_unordered(uhi) - bvh_unordered(ulo) : 0.f;     // (a node nobody touched: no extent)
+            }
+            unsigned axis = 0;
+            if (ext[1] > ext[axis]) axis = 1;
+            if (ext[2] > ext[axis]) axis = 2;
+            s_box[7 * q + 6] = axis;
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < n_tree; j += 1024) {
+            const uint32_t node = bvh_node_of(j / rt::kBvhLeaf, level, n_leaves), rank = node & 0x7fffffffu;
+            const uint32_t ix = (uint32_t)(s_keys[j] & kIdxMask);
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            const unsigned axis = s_box[7 * rank + 6];
+            const float c3 = axis == 0 ? r[1] : (axis == 1 ? r[2] : r[3]);
+            const unsigned coord = (node & 0x80000000u) ? j : bvh_ordered(c3);   // a node of one leaf keeps its order
+            s_keys[j] = ((unsigned long long)rank << 50) | ((unsigned long long)coord << 18) | ix;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= n_pad; k <<= 1) {             // bitonic sort, ascending (the padding keys stay behind)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < n_pad; i += 1024) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long ka = s_keys[i], kb = s_keys[l];
+                        if ((ka > kb) == ((i & k) == 0)) { s_keys[i] = kb; s_keys[l] = ka; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     // ---- 3. records in leaf order; padding records never hit (NaN centre: every comparison of the test is false) ----
     const float qnan = __uint_as_float(0x7fc00000u);
     for (uint32_t j = tid; j < rt::kBvhLeaf * n_leaves; j += 1024) {
-        const uint32_t ix = j < n_tree ? (uint32_t)s_keys[j] : 0xffffffffu;
+        const uint32_t ix = j < n_tree ? (uint32_t)(s_keys[j] & kIdxMask) : 0xffffffffu;
         if (ix != 0xffffffffu) {
             const float *r = reinterpret_cast<const float *>(sph + ix);
             slots[n_always + j] = make_float4(r[1], r[2], r[3], r[0] * r[0]);
@@ -215,22 +262,15 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
     }
 }
 
-// Trees beyond what one workgroup sorts in LDS (more than 16 384 spheres in the tree): the same tables from the host
-// mirror of the records -- same split, same Morton order (ties broken by scene index, as the device's 64-bit keys
-// do), same leaves, same sibling pairs, boxes rounded outwards the same way -- written into a page-locked buffer and
+// Trees beyond what one workgroup sorts in LDS (more than 8192 spheres in the tree): the same tables from the host
+// mirror of the records -- same split, same top-down median ordering, same leaves, same sibling pairs, boxes rounded
+// outwards the same way -- written into a page-locked buffer and
 // copied on `stream`.  Milliseconds of host time per build for scenes of this size; nothing is waited for.  The
 // depth-first `nodes` section of the blob (the A/B forms of the walk, LDS tables only) is left out.
-constexpr uint32_t kDeviceBuildMax = 16384;
+constexpr uint32_t kDeviceBuildMax = 8192;
 
 inline float host_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
 inline float host_up(float v) { return v + (fabsf(v) * 0x1p-22f + 1e-30f); }
-inline uint32_t host_spread(uint32_t v) {
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
 inline float bits_float(uint32_t u) {
     float f;
     memcpy(&f, &u, 4);
@@ -261,10 +301,10 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     float4 *hdr = blob, *slots = blob + 2 + 2 * (size_t)n_nodes;
     uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
     float4 *pairs = reinterpret_cast<float4 *>(index) + (n_slots + 3) / 4;
-    // split; box of the tree's centres; radius range
-    std::vector<uint64_t> keys;
-    keys.reserve(n_tree);
-    float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f }, rmin = 3.4e38f, rmax = 0.f;
+    // split; radius range
+    std::vector<uint32_t> order;
+    order.reserve(n_tree);
+    float rmin = 3.4e38f, rmax = 0.f;
     uint32_t na = 0;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = sph[i];
@@ -273,25 +313,43 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
             index[na] = i;
             na += 1;
         } else {
-            const float p[3] = { s.p.x, s.p.y, s.p.z };
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = fminf(lo[a], p[a]);
-                hi[a] = fmaxf(hi[a], p[a]);
-            }
+            order.push_back(i);
             rmin = fminf(rmin, fabsf(s.rad));
             rmax = fmaxf(rmax, fabsf(s.rad));
         }
     }
-    const float k[3] = { 1023.f / fmaxf(hi[0] - lo[0], 1e-30f), 1023.f / fmaxf(hi[1] - lo[1], 1e-30f), 1023.f / fmaxf(hi[2] - lo[2], 1e-30f) };
-    for (uint32_t i = 0; i < n_total; ++i) {
-        const rt_sphere &s = sph[i];
-        if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) continue;
-        const uint32_t qx = (uint32_t)fminf(fmaxf((s.p.x - lo[0]) * k[0], 0.f), 1023.f), qy = (uint32_t)fminf(fmaxf((s.p.y - lo[1]) * k[1], 0.f), 1023.f),
-                       qz = (uint32_t)fminf(fmaxf((s.p.z - lo[2]) * k[2], 0.f), 1023.f);
-        keys.push_back(((uint64_t)((host_spread(qx) << 2) | (host_spread(qy) << 1) | host_spread(qz)) << 32) | i);
+    if (na != n_always || order.size() != n_tree) return rt::fail(RT_ERR_STATE, "hierarchy: the split changed under the build");
+    // order: top-down, every node's spheres partitioned at the median along the longest axis of the box of their centres
+    // (the left child takes the first half of the node's leaves; ties go by scene index), as the device build does
+    {
+        auto coord = [&](uint32_t ix, int axis) { const rt_sphere &s = sph[ix]; return axis == 0 ? s.p.x : (axis == 1 ? s.p.y : s.p.z); };
+        struct Range { uint32_t a, b; };
+        std::vector<Range> todo{ { 0, n_leaves } };
+        while (!todo.empty()) {
+            const Range rg = todo.back();
+            todo.pop_back();
+            if (rg.b - rg.a <= 1) continue;
+            const size_t first = (size_t)rg.a * rt::kBvhLeaf, last = std::min((size_t)rg.b * rt::kBvhLeaf, (size_t)n_tree);
+            float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+            for (size_t j = first; j < last; ++j)
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    lo[a3] = fminf(lo[a3], coord(order[j], a3));
+                    hi[a3] = fmaxf(hi[a3], coord(order[j], a3));
+                }
+            const float ext[3] = { hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2] };
+            int axis = 0;
+            if (ext[1] > ext[axis]) axis = 1;
+            if (ext[2] > ext[axis]) axis = 2;
+            const uint32_t mid = (rg.a + rg.b) / 2;
+            const size_t cut = std::min((size_t)mid * rt::kBvhLeaf, last);
+            std::nth_element(order.begin() + first, order.begin() + cut, order.begin() + last, [&](uint32_t x, uint32_t y) {
+                const float cx = coord(x, axis), cy = coord(y, axis);
+                return cx < cy || (cx == cy && x < y);
+            });
+            todo.push_back({ rg.a, mid });
+            todo.push_back({ mid, rg.b });
+        }
     }
-    if (na != n_always || keys.size() != n_tree) return rt::fail(RT_ERR_STATE, "hierarchy: the split changed under the build");
-    std::sort(keys.begin(), keys.end());
     // records in leaf order, leaf boxes
     std::vector<HostBox> leaf(n_leaves);
     const float qnan = bits_float(0x7fc00000u);
@@ -304,7 +362,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
                 index[n_always + j] = 0xffffffffu;
                 continue;
             }
-            const uint32_t ix = (uint32_t)keys[j];
+            const uint32_t ix = order[j];
             const rt_sphere &s = sph[ix];
             slots[n_always + j] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
             index[n_always + j] = ix;
@@ -387,7 +445,9 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
     if (n_tree <= kDeviceBuildMax) {
         uint32_t n_pad = 2;
         while (n_pad < n_tree) n_pad *= 2;
-        const size_t lds = std::max((size_t)n_pad * 8, (size_t)n_leaves * 32);
+        uint32_t level_nodes = 1;
+        while (level_nodes < n_leaves) level_nodes *= 2;
+        const size_t lds = std::max((size_t)n_pad * 8 + (size_t)level_nodes * 28, (size_t)n_leaves * 32);
         hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
         HIP_TRY(hipGetLastError());
     } else {
