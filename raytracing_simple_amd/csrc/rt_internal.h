@@ -39,7 +39,8 @@ struct rt_ctx {
     hipEvent_t bvh_stage_ev = nullptr;
     bool bvh_stage_used = false;
     int bvh_min = 64;                   // scenes with at least this many spheres inside the tree use it (0 = never)
-    int bvh_lds_limit = 64 * 1024;      // ... while the instance's LDS stays below this
+    int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
+                                        // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
     int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
     int walk_form = 0;                  // 0 = measured choice (below); diagnostics: 1 = the walk-per-call form, 2 = the walk, unmeasured
     // hierarchy or plain sweep?  Decided per scene by measurement: the first launch of a new scene walks the

@@ -213,9 +213,9 @@ def census_walk(sph, cam, w, h, spp, steps=0, gate=0, mode=116):
             "node_steps_per_trip": round(c[0] / max(c[8], 1), 1), "clock_share_walk": round(c[6] / max(c[6] + c[7], 1), 3)}
 
 
-def timed(sph, cam, w, h, spp, bvh_min, reps=3, mode=api.RT_MODE_PARITY, walk=(0, 0, 0), ratio=0):
+def timed(sph, cam, w, h, spp, bvh_min, reps=3, mode=api.RT_MODE_PARITY, walk=(0, 0, 0), ratio=0, lds_limit=0):
     with api.RtContext(w, h, diag=True) as ctx:
-        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 0))
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, lds_limit))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, *walk))
         if ratio:
             ctx._check(ctx._lib.rt_debug_set_walk_round(ctx._h, ratio))

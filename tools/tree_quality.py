@@ -88,11 +88,16 @@ def build_sah(c, r, leaf=8, bins=16):
     root = rec(np.arange(len(c)))
     return inner / root, leafc / root
 
-for name, mk in (("random_1024", lambda: scenes.random_spheres(1024)), ("random_256", lambda: scenes.random_spheres(256)), ("mirror_box_256", lambda: scenes.mirror_box(256))):
-    sph = api.as_spheres(mk()[0])
-    r = np.abs(sph["rad"].astype(np.float64)); c = np.ascontiguousarray(sph["p"]).astype(np.float64)
-    med = np.median(r); keep = r <= 16 * med
-    c, r = c[keep], r[keep]
-    order, code = morton_order(c)
-    for label, res in (("morton+count", build_count(order, c, r)), ("median longest axis", build_median(c, r)), ("binned SAH", build_sah(c, r))):
-        print(name, label, "inner %.2f  leaf-sphere %.2f  (pair-step cost 50, sphere 20) -> %.0f" % (res[0], res[1], res[0]*50 + res[1]*20))
+def main():
+    for name, mk in (("random_1024", lambda: scenes.random_spheres(1024)), ("random_256", lambda: scenes.random_spheres(256)), ("mirror_box_256", lambda: scenes.mirror_box(256))):
+        sph = api.as_spheres(mk()[0])
+        r = np.abs(sph["rad"].astype(np.float64)); c = np.ascontiguousarray(sph["p"]).astype(np.float64)
+        med = np.median(r); keep = r <= 16 * med
+        c, r = c[keep], r[keep]
+        order, code = morton_order(c)
+        for label, res in (("morton+count", build_count(order, c, r)), ("median longest axis", build_median(c, r)), ("binned SAH", build_sah(c, r))):
+            print(name, label, "inner %.2f  leaf-sphere %.2f  (pair-step cost 50, sphere 20) -> %.0f" % (res[0], res[1], res[0]*50 + res[1]*20))
+
+
+if __name__ == "__main__":
+    main()
