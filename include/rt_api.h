@@ -130,7 +130,7 @@ RT_API void rt_destroy(rt_ctx *ctx);                              /* freeBuffer,
  * The 44-byte records go to the device as they are and a small kernel there builds the tables the
  * render kernel reads (centre | radius^2, emission | material, colour | radius, and the light list
  * SampleLights walks, with 4*pi*radius^2 -- all in binary32, the reference's own operations).
- * Scenes with 64 and more small spheres also get a hierarchy over them (a second kernel on the same stream; beyond
+ * Scenes with 56 and more small spheres also get a hierarchy over them (a second kernel on the same stream; beyond
  * 8192 such spheres it is built on the host from the records and copied): it changes which instance renders the scene,
  * never the result (rt_last_kernel, rt_scene_choice).  Up to RT_MAX_SPHERES spheres; tables that do not fit LDS are read
  * from HBM / L2.  Ordered after every launch issued on this context; no device-wide synchronisation.  A refused
@@ -223,7 +223,7 @@ RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
  * (12 and more: wave-ballot any-hit sharing), "..._pairs" (hundreds of small spheres: a hierarchy, where it measured
  * faster than the sweep on this scene), the same with "fast".  "" before the first launch.  Frames do not depend on it. */
 RT_API const char *rt_last_kernel(const rt_ctx *ctx);
-/* What the measurement on the current scene said (scenes with 64 and more small spheres whose sweep table fits LDS:
+/* What the measurement on the current scene said (scenes with 56 and more small spheres whose sweep table fits LDS:
  * the first pass walks the hierarchy, the second sweeps, the faster form renders the rest): returns 0 = not decided
  * (yet, or a scene that is not measured), 1 = hierarchy, 2 = plain sweep, and the two measured times per pass in
  * milliseconds (0 when not measured).  Never blocks; of a multi-device context, the first shard's. */

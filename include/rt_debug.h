@@ -36,7 +36,7 @@ RT_API int rt_debug_set_persist(rt_ctx *ctx, int on);
 RT_API int rt_debug_set_ncus(rt_ctx *ctx, int n);
 RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
 /* hierarchy over the small spheres of large scenes: smallest tree that is built and used (0 = never; library default
- * 64), largest LDS footprint it is used at (0 = keep; default 31 KiB = five workgroups per CU).  rt_debug_read_bvh: the tables as the kernels
+ * 56), largest LDS footprint it is used at (0 = keep; default 31 KiB = five workgroups per CU).  rt_debug_read_bvh: the tables as the kernels
  * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, nodes, slots }, all 0 without a hierarchy */
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
 RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int form);   /* node tests per lane per loop trip; ready lanes that make a wavefront shade; form 0 = hierarchy or plain sweep by measurement (default), 1 = always the walk-per-call form, 2 = always the walk */

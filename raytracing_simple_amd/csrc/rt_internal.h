@@ -38,7 +38,7 @@ struct rt_ctx {
     size_t bvh_stage_cap = 0;           // float4
     hipEvent_t bvh_stage_ev = nullptr;
     bool bvh_stage_used = false;
-    int bvh_min = 64;                   // scenes with at least this many spheres inside the tree use it (0 = never)
+    int bvh_min = 56;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
     int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
