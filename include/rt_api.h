@@ -223,7 +223,7 @@ RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
  * (12 and more: wave-ballot any-hit sharing), "..._pairs" (hundreds of small spheres: a hierarchy, where it measured
  * faster than the sweep on this scene), the same with "fast".  "" before the first launch.  Frames do not depend on it. */
 RT_API const char *rt_last_kernel(const rt_ctx *ctx);
-/* What the measurement on the current scene said (scenes with 56 and more small spheres whose sweep table fits LDS:
+/* What the measurement on the current scene said (scenes with 56 to 1500 small spheres:
  * the first pass walks the hierarchy, the second sweeps, the faster form renders the rest): returns 0 = not decided
  * (yet, or a scene that is not measured), 1 = hierarchy, 2 = plain sweep, and the two measured times per pass in
  * milliseconds (0 when not measured).  Never blocks; of a multi-device context, the first shard's. */

@@ -135,6 +135,14 @@ def test_measured_choice_changes_no_bit_and_probes_split_a_blocking_call():
     _same(many, want)
     small = _render(*((lambda s: (s[0], host.compute_camera(s[1], s[2], w, h)))(scenes.demo_plus(16))), w, h, 4, bvh_min=64, form=0)
     assert small["pick"] == 0 and small["stats"]["launches"] == 1      # no hierarchy below bvh_min: nothing to measure
+    big, orig, target = scenes.random_spheres(1700)                    # from 1500 spheres on the answer is known: no probe
+    bcam = host.compute_camera(orig, target, 48, 32)
+    with api.RtContext(48, 32, diag=True) as ctx:
+        ctx.set_scene(big)
+        ctx.set_camera(bcam)
+        px = ctx.render_pass(20)
+        assert ctx.stats()["launches"] == 1 and ctx.last_kernel.startswith("rt_trace_parity_pairs") and ctx.scene_choice()["picked"] is None
+        assert np.array_equal(px, O.render(big, bcam, 48, 32, 20)["pixels"])
 
 
 def test_moving_spheres_rebuild_the_hierarchy_on_the_stream():
