@@ -51,6 +51,7 @@
 #define RT_NS fast_pairs
 #define RT_KERNEL_NAME rt_trace_fast_pairs
 #define RT_OPT_BVH 6
+#define RT_OPT_MINWAVES 5            /* as many waves as workgroups of its LDS tables fit a CU */
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
@@ -58,6 +59,7 @@
 #define RT_KERNEL_NAME rt_trace_fast_pairs_g
 #define RT_OPT_BVH 6
 #define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_MINWAVES 4
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
