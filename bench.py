@@ -348,7 +348,7 @@ def main():
         frames_ok = {"frames_checked": frames_checked[0], "wrong_pixels": bad} if rank == 0 else None
 
     # ---- extras, N = 1, outside the headline's timed regions -------------------------------------------
-    other, target, in_library = None, None, None
+    other, target, in_library, large = None, None, None, None
     if world == 1 and not args.no_extras:
         # the other arithmetic mode on the same workload
         other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
@@ -380,7 +380,7 @@ def main():
             tf16 = FLOP_PER_SPHERE_TEST * st16["sphere_tests"] / (kms16 * 1e-3) / 1e12
             target = {"workload": "north-star target: Demo + 10 spheres (16), 1920x1080, 64 spp, default seed stream",
                       "asked_Mray_s": 10000.0, "steps": k16, "ms_per_step": round(el16 / k16 * 1e3, 4),
-                      "value": round(rays16 * k16 / el16 / 1e6, 1), "unit": "Mray/s", "kernel": "rt_trace_parity_coop", "kernel_ms": round(kms16, 4),
+                      "value": round(rays16 * k16 / el16 / 1e6, 1), "unit": "Mray/s", "kernel": c16[0].last_kernel, "kernel_ms": round(kms16, 4),
                       "roofline": {"bound": "valu-fp32", "achieved": round(tf16, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(tf16 / FP32_VECTOR_PEAK_TFLOPS, 5)},
                       "frames_in_flight": {"frames": F, "ms_per_step": round(el16F / k16 * 1e3, 4), "value": round(rays16 * k16 / el16F / 1e6, 1)}}
@@ -390,6 +390,30 @@ def main():
                 target["cpu_port_ms_per_frame"] = base16["ms_per_frame"]
             for c in c16:
                 c.close()
+        # a large scene (BASELINE configs[2]: 1024 random spheres, 1080p x 16 spp), blocking calls: the library builds a
+        # hierarchy for it, times it against the sweep on the first two frames and renders the rest with the faster form
+        if args.workload == "c2":
+            try:
+                sph3, o3, t3 = scenes.random_spheres(1024)
+                with api.RtContext(W, H, device=local_rank) as cl:
+                    cl.set_scene(sph3); cl.set_camera(host.compute_camera(o3, t3, W, H)); cl.set_mode(mode)
+                    for _ in range(3):
+                        cl.reset_async(); cl.render_pass(16, copy=False)
+                    k3 = max(5, args.steps // 2)
+                    t0 = time.perf_counter()
+                    for _ in range(k3):
+                        cl.reset_async(); cl.render_pass(16, copy=False)
+                    dt3 = time.perf_counter() - t0
+                    st3, ch3 = cl.stats(), cl.scene_choice()
+                    large = {"workload": "C3: 1024 random spheres, 1920x1080, 16 spp, default seed stream", "steps": k3,
+                             "ms_per_step": round(dt3 / k3 * 1e3, 4), "value": round((st3["samples"] + st3["shadow_rays"]) * k3 / dt3 / 1e6, 1),
+                             "unit": "Mray/s", "kernel": cl.last_kernel, "kernel_ms": round(st3["last_kernel_ms"], 4),
+                             "measured_choice": {"picked": ch3["picked"], "hierarchy_ms_per_pass": round(ch3["hierarchy_ms_per_pass"], 4),
+                                                 "sweep_ms_per_pass": round(ch3["sweep_ms_per_pass"], 4)},
+                             "note": "frames, seeds and counters are the same bits through either form (DESIGN.md section 5; "
+                                     "profiles/r02s_full_size_parity.jsonl); bench.py --workload c3 is the full record"}
+            except api.RtError as e:
+                large = {"error": str(e)}
         # the in-library multi-device context with a communicator of one: what the frame-end gather path costs
         # when it has nothing to move (the N-GPU figure comes from the N > 1 runs)
         try:
@@ -517,6 +541,8 @@ def main():
                                     "note": "the same K frames, F in flight on separate streams: throughput, not ms/frame"}
     if target is not None:
         line["north_star_target"] = target
+    if large is not None:
+        line["large_scene"] = large
     if other is not None:
         line["other_mode"] = other
     if in_library is not None:
