@@ -27,6 +27,7 @@ void HipConfig::allocateBuffer() {                       // OpenCLConfig.cpp:613
     // the per-pass readback into pPixels then runs at the PCIe rate (optional; failure is not fatal)
     (void)rt_pin_output(ctx, reinterpret_cast<uint32_t*>(pPixels), static_cast<size_t>(mWidth) * mHeight);
     if (const char* v = getenv("RT_READBACK_MS")) readbackMs = atof(v);
+    if (rt_throttle(ctx, 2, nullptr) != RT_OK) die("Failed to set up pacing");      // (the first call switches the bookkeeping on)
 }
 
 void HipConfig::freeBuffer() {                           // OpenCLConfig.cpp:684-717
@@ -76,43 +77,62 @@ unsigned* HipConfig::getPixels() {
         launchPending(true);
         if (rt_read_pixels(ctx, reinterpret_cast<uint32_t*>(pPixels)) != RT_OK) die("Failed to read the frame back");
         stale = false;
+        copyQueued = false;
+    } else if (copyQueued) {
+        if (rt_throttle(ctx, 0, nullptr) != RT_OK) die("Failed to wait for the frame copy");     // the display copy in flight lands first
+        copyQueued = false;
     }
     return pPixels;
 }
 
 void HipConfig::setArguments() {}                        // OpenCLConfig.cpp:517-611
 
-// One pass.  The reference reads the frame back after EVERY pass (OpenCLConfig.cpp:498-512) although
-// the window only looks at it when it redraws (SetupGL.cpp:59-63, unsynchronised).  A pass takes
-// 0.04-0.12 ms on an MI355X, the 8.3 MB readback of a 1080p frame three times that, and a launch of one pass
-// costs twice what the pass costs inside a longer launch (prologue, epilogue, the seed / colour round trip through
-// HBM).  So: the frame is copied when it is due for display -- on pass 0 and then every readbackMs (8 ms unless
-// RT_READBACK_MS says otherwise; 0 = after every pass, the reference's cadence) -- and the passes in between are
-// counted here and launched `batch` at a time, about a millisecond of work per launch (1080p: 11 900 passes/s one
-// per launch, 21 800 at 16).  The copy that is due launches what is pending and waits for everything queued, which
-// also bounds the queue to readbackMs of work.  Scene and camera changes and getPixels() launch what is pending first.
+// One pass.  The reference reads the frame back after EVERY pass (OpenCLConfig.cpp:498-512) although the window only
+// looks at it when it redraws (SetupGL.cpp:59-63, unsynchronised).  A pass takes 0.04-0.12 ms on an MI355X, the 8.3 MB
+// readback of a 1080p frame three times that, and a launch of one pass costs twice what the pass costs inside a longer
+// launch.  So passes are counted here and launched `batch` at a time (about a millisecond of work per launch, without
+// gamma and pixel store), and the frame is copied when it is due for display -- on pass 0 and then every readbackMs
+// (8 ms unless RT_READBACK_MS says otherwise; 0 = the reference's cadence: one blocking pass + copy per call).
+//
+// The caller times this function: Config::updateRendering (Config.cpp:73-91, not virtual) puts W*H / elapsed into the
+// window caption as "Sample/sec".  For that figure to stay TRUE with batching, a call must last what a pass costs the
+// device, not the microsecond it takes to count it:
+//   * the queue is bounded -- after a launch the call waits until at most two launches are unfinished (rt_throttle),
+//     which also returns the device time per pass of the launch that finished last;
+//   * every call then lasts at least 0.9 x that time (a short spin: this is the compute thread, which the reference
+//     blocks in clFinish), so the host runs at the device's pace, a fraction ahead; the launching call takes up the slack.
+// The frame that is due is copied asynchronously into pPixels (page-locked) behind the passes -- the window reads that
+// buffer unsynchronised in the reference too -- so a due pass costs a launch, not a drain of the queue.
 void HipConfig::execute() {                              // OpenCLConfig.cpp:407-515
     std::lock_guard<std::mutex> lock(guard);
-    const auto now = std::chrono::steady_clock::now();
-    const bool due = mCurrentSample == 0 || readbackMs <= 0.0 ||
-                     std::chrono::duration<double, std::milli>(now - lastReadback).count() >= readbackMs;
-    pending += 1;
-    if (due) {
-        const int n = pending;
-        pending = 0;
-        if (rt_set_pixel_write(ctx, 1) != RT_OK ||
-            rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), n) != RT_OK)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (readbackMs <= 0.0) {                             // the reference's own cadence
+        if (rt_set_pixel_write(ctx, 1) != RT_OK || rt_render_pass(ctx, reinterpret_cast<uint32_t*>(pPixels), 1) != RT_OK)
             die("Failed to render a pass");
         stale = false;
-        lastReadback = now;
-        rt_stats st;                                    // size the batches from the launch that just finished
-        if (n >= 4 && rt_get_stats(ctx, &st) == RT_OK && st.last_kernel_ms > 0.0) {
-            const double per_pass = st.last_kernel_ms / n;
-            const int want = static_cast<int>(1.0 / per_pass + 0.5);
+        return;
+    }
+    const bool due = mCurrentSample == 0 || std::chrono::duration<double, std::milli>(t0 - lastReadback).count() >= readbackMs;
+    pending += 1;
+    stale = true;
+    if (due || pending >= batch) {
+        launchPending(due);
+        if (due) {
+            if (rt_read_pixels_async(ctx, reinterpret_cast<uint32_t*>(pPixels), rt_stream(ctx)) != RT_OK) die("Failed to queue the frame copy");
+            copyQueued = true;
+            stale = false;                              // the copy in flight is the frame of every pass so far
+            lastReadback = t0;
+        }
+        double ms = 0.0;
+        if (rt_throttle(ctx, 2, &ms) != RT_OK) die("Failed to wait for the device");
+        if (ms > 0.0) {
+            passMs = ms;
+            const int want = static_cast<int>(1.0 / ms + 0.5);          // about a millisecond of work per launch
             batch = want < 1 ? 1 : (want > 64 ? 64 : want);
         }
-    } else {
-        stale = true;
-        if (pending >= batch) launchPending(false);     // passes nobody looks at skip the gamma + pixel store
+    }
+    if (passMs > 0.0) {
+        const auto until = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double, std::milli>(0.9 * passMs));
+        while (std::chrono::steady_clock::now() < until) { /* spin: tens of microseconds */ }
     }
 }

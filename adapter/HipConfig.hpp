@@ -45,6 +45,8 @@ private:
     bool stale = false;             // passes have run since pPixels was last brought up to date
     int pending = 0;                // passes execute() has counted and not launched yet
     int batch = 16;                 // launch them this many at a time (about a millisecond of work: set from the measured pass time)
+    double passMs = 0.0;            // device time per pass of the launch that finished last (0 = not known yet): what a call lasts
+    bool copyQueued = false;        // an asynchronous display copy into pPixels may still be in flight
     void launchPending(bool withPixels);
     std::mutex guard;               // execute() runs on the compute thread, getPixels() on the caller's (Main.cpp:96-106)
 };

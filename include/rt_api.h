@@ -56,7 +56,12 @@ typedef struct {
     uint64_t samples;        /* camera (primary) rays                                         */
     uint64_t closest_rays;   /* closest-hit queries, `Intersect` .cl:215 (primary+extension)  */
     uint64_t shadow_rays;    /* any-hit queries, `IntersectP` .cl:234                         */
-    uint64_t sphere_tests;   /* `SphereIntersect` .cl:173 evaluations                         */
+    uint64_t sphere_tests;   /* `SphereIntersect` .cl:173 evaluations OF THE REFERENCE'S ALGORITHM for these rays: every closest-hit
+                              * query counts all spheres, every shadow query the spheres up to and including its first blocker in
+                              * scene order (.cl:215-247).  The plain sweeps execute exactly these tests; the hierarchy of large
+                              * scenes (rt_last_kernel "..._pairs") reaches the same answers with far fewer, so there this is the
+                              * reference-equivalent count, equal to the oracle's, not the work done: what the walk executes is
+                              * counted by the census instance of the diagnostics library (bench.py `roofline.executed`).     */
     uint64_t rng_draws;      /* `GetRandom` .cl:143 calls                                     */
     uint64_t launches;       /* kernel launches                                               */
     double   last_kernel_ms; /* device time of the last rt_render_pass launch (HIP events)    */
@@ -76,8 +81,9 @@ enum rt_mode {
     RT_MODE_FAST   = 1       /* FMA contraction + hardware rcp/rsq/sin/cos/exp2/log2           */
 };
 
-#define RT_MAX_SPHERES 262144u /* (the hierarchy numbers its leaves of 8 spheres with 15 bits; up to ~9000 spheres
-                                 * the tables are staged in LDS, beyond that they are read from HBM / L2)        */
+#define RT_MAX_SPHERES 262144u /* (the hierarchy numbers its leaves of 8 spheres with 15 bits.  Its tables are staged in LDS while
+                                 * five workgroups of that size fit a CU -- 31 KiB, about 1 100 spheres -- and read from HBM / L2
+                                 * beyond; the plain sweep's table fits LDS up to about 9 700 spheres)                            */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -109,10 +115,18 @@ RT_API int rt_create(rt_ctx **out, int w, int h);
  * de-interleave kernel there and one copy to the host.  Every other call of this header works on
  * such a context as on a plain one and means the whole image: rt_render_pass returns all h rows,
  * rt_get_stats sums the devices, rt_read_colors / rt_read_seeds merge them.  Results are bit-identical
- * to a one-device context.  ngpus = 1 runs the same code (a communicator of one).
- * rt_create_multi_on with a device listed more than once is the one-GPU rehearsal of the same
- * path: RCCL refuses two ranks on one device, so the transfers into the root's receive slots are
- * device-to-device copies there; everything else (shards, slots, de-interleave) is unchanged.  */
+ * to a one-device context by construction (pixels are independent); ngpus = 1 runs the same code (a
+ * communicator of one).  One kernel instance renders the whole frame: the first shard measures hierarchy
+ * against sweep (rt_scene_choice) and the others follow it.
+ * STATUS of the n > 1 RCCL branch: exercised so far only as far as one GPU allows -- the communicator of one, and
+ * the rehearsal below, in which device-to-device copies stand in for ncclSend / ncclRecv.  The grouped send / receive
+ * across distinct devices has not run on hardware yet (tests/test_gpu_features.py holds the test, skipped below two
+ * devices); treat it as unverified until that test has passed on a multi-GPU node.
+ * rt_create_multi_on with ONE device listed ngpus times is that one-GPU rehearsal of the path: RCCL refuses two
+ * ranks on one device, so the transfers into the root's receive slots are device-to-device copies there; everything
+ * else (shards, slots, de-interleave) is unchanged.  A list that mixes repeated and distinct devices is refused
+ * (RT_ERR_ARG).  If a gather fails half-way (an RCCL error inside the group or at ncclGroupEnd) the context is marked
+ * unusable: every later call on it returns RT_ERR_STATE naming the failure, and only rt_destroy is meaningful.    */
 RT_API int rt_create_multi(rt_ctx **out, int w, int h, int ngpus);
 RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, int ngpus, int tile_rows);
 RT_API int rt_shard_count(const rt_ctx *ctx);                     /* 1 for a plain context        */
@@ -192,11 +206,30 @@ RT_API int rt_read_pixels(rt_ctx *ctx, uint32_t *out_host);
  * and no synchronisation: the caller orders later work on that stream.                       */
 RT_API int rt_render_async(rt_ctx *ctx, int n_samples, void *hip_stream);
 
+/* rt_read_pixels without the wait: the packed frame is brought up to date and its copy to `out_host` is queued on
+ * `hip_stream` behind everything issued on this context; the buffer holds the frame once that stream has drained (or
+ * rt_throttle(ctx, 0, ...) has returned).  `out_host` should be page-locked (rt_pin_output), or the runtime stages
+ * the copy and the call may block.  On a multi-device context this is rt_read_pixels (it blocks).               */
+RT_API int rt_read_pixels_async(rt_ctx *ctx, uint32_t *out_host, void *hip_stream);
+
+/* Pacing for hosts that queue passes with rt_render_async (the adapter's display loop): returns when at most
+ * `max_in_flight` of the rt_render_async launches issued on this context since the first rt_throttle call are still
+ * unfinished (0 = wait for all of them).  *ms_per_pass (may be NULL) receives the device time per pass of the most
+ * recent launch that has finished, 0 if none has.  The first call only switches the bookkeeping on (two events per
+ * launch from then on) and returns at once.  A multi-device context waits for everything when max_in_flight is 0
+ * and reports no time.                                                                                          */
+RT_API int rt_throttle(rt_ctx *ctx, int max_in_flight, double *ms_per_pass);
+
 /* The context's own non-blocking stream (a hipStream_t), the one rt_render_pass uses.  With
  * several contexts in flight, rt_render_async(ctx, n, rt_stream(ctx)) runs each on its own.
  * HIP gives a process GPU_MAX_HW_QUEUES hardware queues (default 4) and lets further streams
  * share them: two contexts on one queue do not overlap at all, so a host that keeps F contexts
- * in flight should start with GPU_MAX_HW_QUEUES >= the number of streams it uses (bench.py: 24). */
+ * in flight should start with GPU_MAX_HW_QUEUES >= the number of streams it uses (bench.py: 8).
+ * PLATFORM PRECONDITION (profiles/r02_stale_seed/): do not put more hardware queues on ONE GPU
+ * than its scheduler keeps resident -- one process per GPU is always fine; four processes of 8 queues each on one
+ * GPU were not: the scheduler then time-slices the queues, a dispatch can run XCD-share by XCD-share around a
+ * descheduling, and on this driver stack the early share occasionally loses its writes (no fence or store form the
+ * library could issue prevents it).  tools/gather_stress.py is the acceptance test for a deployment.            */
 RT_API void *rt_stream(rt_ctx *ctx);
 
 /* Device address and element count (uint32) of the local pixel buffer.                       */

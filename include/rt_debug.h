@@ -14,9 +14,18 @@
 extern "C" {
 #endif
 
-/* rt_set_mode() of the diagnostics library also accepts 100+k / 200+k: instance k of the parity /
- * fast kernel tables (csrc/rt_kernel_parity.hip, rt_kernel_fast.hip).                          */
+/* rt_set_mode() of the diagnostics library also accepts 100+k / 200+k: row k of the parity / fast
+ * instance tables (csrc/rt_kernel_parity.hip, rt_kernel_fast.hip; csrc/rt_device.h Instance).  Rows are
+ * found by kernel symbol, never by number: rt_debug_instance("rt_trace_parity_coop_census") returns the
+ * mode value (or RT_ERR_ARG), rt_debug_instance_name(fast, row) the symbol of a row ("" beyond the table). */
 RT_API int rt_debug_variant_count(int fast);
+RT_API int rt_debug_instance(const char *kernel_symbol);
+RT_API const char *rt_debug_instance_name(int fast, int row);
+/* the kernel instance the last launch of shard `shard` of a multi-device context used (rt_last_kernel names the first shard's) */
+RT_API const char *rt_debug_shard_kernel(rt_ctx *ctx, int shard);
+/* failure injection: puts a multi-device context into the state a failed gather (ncclGroupEnd) leaves it in and returns that
+ * failure's code; every later rendering / state call on the context must then return RT_ERR_STATE until it is destroyed */
+RT_API int rt_debug_break_gather(rt_ctx *ctx);
 
 /* Device-side evaluation of the scalar building blocks, for unit parity tests:
  * op 0: sinf, 1: cosf, 2: pow(x, 1/2.2f), 3: 1/x, 4: sqrt(x), 5: toInt(x) (result as float),
@@ -37,9 +46,9 @@ RT_API int rt_debug_set_ncus(rt_ctx *ctx, int n);
 RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
 /* hierarchy over the small spheres of large scenes: smallest tree that is built and used (0 = never; library default
  * 56), largest LDS footprint it is used at (0 = keep; default 31 KiB = five workgroups per CU).  rt_debug_read_bvh: the tables as the kernels
- * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, nodes, slots }, all 0 without a hierarchy */
+ * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, stack depth, slots }, all 0 without a hierarchy */
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
-RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int form);   /* node tests per lane per loop trip; ready lanes that make a wavefront shade; form 0 = hierarchy or plain sweep by measurement (default), 1 = always the walk-per-call form, 2 = always the walk */
+RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* pair steps per lane per loop trip; ready lanes that make a wavefront shade (0 = keep either); forced 0 = hierarchy or plain sweep by measurement (default), 1 = the hierarchy whenever the scene has one */
 RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a lane takes in a row before the leaf step of the lanes that hold a leaf (default 3; large = until every lane has one) */
 /* n_rays rays { o.xyz, t_max, d.xyz, shadow != 0 } (8 floats each; the last as a bit pattern) through the hierarchy walk
  * AND the plain sweep, one lane per ray; out4 (4 words per ray) = the walk's answer, then the sweep's -- closest hit:

@@ -2,16 +2,19 @@
 // backend.  TEST INFRASTRUCTURE (container build only; the binary is git-ignored and travels to the
 // GPU box like oracle/_ref/libref.so).
 //
-// Linked from the reference's sources where they lie (/root/reference/SimpleRT/src/{Config,Utility,
-// Vec,Scene}.cpp, unmodified) + adapter/HipConfig.cpp + librt_hip.so.  The flow below is the one
-// of SimpleRT/src/Main.cpp:68-102 without the freeglut window: scene from `readScene` or
-// `DemoSpheres`, `sceneSetup`, `updateCamera`, then N calls of `Config::updateRendering()` (the
-// reference's pass driver, Config.cpp:73-91, incl. its caption), and the frame `getPixels()`
-// returns, written as a PPM.  The reference's factory has no case for framework ID 2
-// (Config.cpp:63-65), so the object is constructed here the way INTEGRATION.md's factory edit
-// would construct it.
+// Linked from the reference's sources where they lie (/root/reference/SimpleRT/src/{Utility,Vec,Scene}.cpp
+// unmodified; Config.cpp with adapter/reference_factory.patch applied to a scratch copy, oracle/Makefile) +
+// adapter/HipConfig.cpp + librt_hip.so.  The flow below is the one of SimpleRT/src/Main.cpp:29-102 without the
+// freeglut window: the backend from the reference's own factory -- createConfig(w, h, selectType(2), ...), framework
+// ID 2 = the slot the patch fills (Config.cpp:13-68,99-110) --, the scene from `readScene` or `DemoSpheres`,
+// `sceneSetup`, `updateCamera`, then N calls of `Config::updateRendering()` (the reference's pass driver,
+// Config.cpp:73-91, incl. its caption), and the frame `getPixels()` returns, written as a PPM.
 //
-//   ref_host_hip <passes> <width> <height> <out.ppm> [scene.scn]        (RT_TEST_MOVE_CAMERA_AT=K: see below)
+//   ref_host_hip <passes> <width> <height> <out.ppm> [scene.scn]
+//   RT_TEST_MOVE_CAMERA_AT=K   see below
+//   RT_TEST_CAPTION_LOG=file   every pass's caption ("... Sample/sec %.1fK") appended to `file`, and a last line
+//                              "TRUE <samples per second over the whole loop, the drain included>"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -23,7 +26,6 @@
 #include "Utility.hpp"
 #include "Vec.hpp"
 
-#include "HipConfig.hpp"
 
 int main(int argc, char** argv) {
     if (argc < 5) {
@@ -31,7 +33,7 @@ int main(int argc, char** argv) {
         return 2;
     }
     const int passes = atoi(argv[1]), w = atoi(argv[2]), h = atoi(argv[3]);
-    std::unique_ptr<Config> config = std::make_unique<HipConfig>(w, h);   // = createConfig(w, h, selectType(2), true, MemType::Buffer) after INTEGRATION.md's edit
+    std::unique_ptr<Config> config = createConfig(w, h, selectType(2), true, MemType::Buffer);       // Main.cpp:29-66 with framework ID 2
 
     Vec orig, target;
     std::vector<Sphere> spheres;
@@ -51,6 +53,9 @@ int main(int argc, char** argv) {
     // passes the backend had only counted or queued at that point belong to the OLD camera
     const char* move_at = getenv("RT_TEST_MOVE_CAMERA_AT");
     const int k_move = move_at ? atoi(move_at) : -1;
+    const char* cap_path = getenv("RT_TEST_CAPTION_LOG");
+    FILE* cap = cap_path ? fopen(cap_path, "w") : nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     for (int i = 0; i < passes; ++i) {                                    // Main.cpp:96-102
         if (i == k_move) {
             orig = { orig.x + 5.f, orig.y + 3.f, orig.z - 4.f };
@@ -58,10 +63,16 @@ int main(int argc, char** argv) {
             config->updateCamera();
         }
         config->updateRendering();
+        if (cap) fputs(caption, cap);
     }
     fprintf(stderr, "%s", caption);
 
-    const unsigned* px = config->getPixels();                             // SetupGL.cpp:85
+    const unsigned* px = config->getPixels();                             // SetupGL.cpp:85 (waits for what is queued)
+    if (cap) {
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        fprintf(cap, "TRUE %.1f\n", (double)passes * w * h / sec);
+        fclose(cap);
+    }
     FILE* f = fopen(argv[4], "wb");
     if (!f) return 1;
     fprintf(f, "P6\n%d %d\n255\n", w, h);

@@ -17,12 +17,12 @@ DIFF, SPEC, REFR = 0, 1, 2
 SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_create_multi_on", "rt_shard_count", "rt_last_kernel", "rt_scene_choice",
            "rt_create_sharded", "rt_destroy", "rt_set_scene", "rt_update_spheres_async",
            "rt_set_camera", "rt_set_mode", "rt_reset", "rt_reset_async", "rt_render_pass", "rt_render_async",
-           "rt_pin_output", "rt_set_pixel_write", "rt_read_pixels", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream",
+           "rt_pin_output", "rt_set_pixel_write", "rt_read_pixels", "rt_read_pixels_async", "rt_throttle", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream",
            "rt_local_rows", "rt_current_sample", "rt_read_colors",
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_deinterleave_rows", "rt_compute_camera",
            "rt_default_seeds", "rt_demo_scene", "rt_read_scene"]
 # include/rt_debug.h: what librt_hip_diag.so exports on top of that
-DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
+DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_instance", "rt_debug_instance_name", "rt_debug_shard_kernel", "rt_debug_break_gather", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
                  "rt_debug_rcp_probe", "rt_debug_set_regen_gate", "rt_debug_set_mat_lds_limit", "rt_debug_set_persist",
                  "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_set_bvh", "rt_debug_set_walk", "rt_debug_set_walk_round", "rt_debug_bvh_pick", "rt_debug_walk_rays", "rt_debug_read_bvh", "rt_debug_set_tile_order", "rt_debug_read_tile_order", "rt_debug_set_wg_waves", "rt_debug_counters", "rt_debug_counters_raw",
                  "rt_debug_reset_by_copy", "rt_debug_probe_seeds", "rt_debug_sidelog_read", "rt_debug_timelog_enable", "rt_debug_timelog_tag",
@@ -79,6 +79,8 @@ def load_library(diag=False):
         "rt_scene_choice": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rt_update_spheres_async": (i32, [vp, u32, u32, vp, vp]),
         "rt_read_pixels": (i32, [vp, vp]),
+        "rt_read_pixels_async": (i32, [vp, vp, vp]),
+        "rt_throttle": (i32, [vp, i32, C.POINTER(C.c_double)]),
         "rt_deinterleave_rows": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "rt_create": (i32, [C.POINTER(vp), i32, i32]),
         "rt_create_sharded": (i32, [C.POINTER(vp), i32, i32, i32, i32, i32, i32]),
@@ -109,6 +111,10 @@ def load_library(diag=False):
     if diag:
         sig.update({
             "rt_debug_variant_count": (i32, [i32]),
+            "rt_debug_instance": (i32, [C.c_char_p]),
+            "rt_debug_instance_name": (C.c_char_p, [i32, i32]),
+            "rt_debug_shard_kernel": (C.c_char_p, [vp, i32]),
+            "rt_debug_break_gather": (i32, [vp]),
             "rt_debug_eval": (i32, [i32, vp, vp, sz]),
             "rt_debug_sqrt_mismatches": (C.c_longlong, []),
             "rt_debug_hitpost_mismatches": (C.c_longlong, []),
@@ -274,6 +280,17 @@ class RtContext:
         self._check(self._lib.rt_read_pixels(self._h, _ptr(out)))
         return out
 
+    def read_pixels_async(self, out, stream=None):
+        """rt_read_pixels_async: queue the copy of the up-to-date frame into `out` (page-lock it with pin_output)."""
+        self._check(self._lib.rt_read_pixels_async(self._h, _ptr(out), C.c_void_p(stream or 0)))
+
+    def throttle(self, max_in_flight):
+        """rt_throttle: wait until at most `max_in_flight` render_async launches are unfinished; returns the device
+        time per pass (ms) of the most recent finished one (0.0 if none)."""
+        ms = C.c_double()
+        self._check(self._lib.rt_throttle(self._h, max_in_flight, C.byref(ms)))
+        return ms.value
+
     def update_spheres(self, first, spheres, stream=None):
         """rt_update_spheres_async: replace spheres [first, first+len) of the current scene."""
         sph = as_spheres(spheres)
@@ -361,6 +378,22 @@ def deinterleave_rows(full_ptr, gathered_ptr, w, h, nranks, tile_rows, pad_rows,
     """rt_deinterleave_rows on raw device pointers (the gather root's frame assembly)."""
     _check(load_library().rt_deinterleave_rows(C.c_void_p(full_ptr), C.c_void_p(gathered_ptr), w, h, nranks, tile_rows,
                                                pad_rows, device, C.c_void_p(stream or 0)))
+
+
+def instance_mode(kernel_symbol):
+    """The rt_set_mode value of the diagnostics library that selects the instance with this kernel symbol
+    (rt_debug_instance: rows of the instance tables are found by name, never by number)."""
+    lib = load_library(diag=True)
+    mode = lib.rt_debug_instance(kernel_symbol.encode())
+    if mode < 0:
+        raise RtError(mode, lib.rt_last_error().decode(errors="replace"))
+    return mode
+
+
+def instance_names(fast=False):
+    """Kernel symbols of every instance of the diagnostics library's parity (or fast) table, in row order."""
+    lib = load_library(diag=True)
+    return [lib.rt_debug_instance_name(1 if fast else 0, k).decode() for k in range(lib.rt_debug_variant_count(1 if fast else 0))]
 
 
 def debug_eval(op, values):

@@ -297,15 +297,25 @@ rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
     return p;
 }
 
-// LDS of the instance that walks the hierarchy in the context's form (walk_form: 0 / 3 = sibling pairs with a stack,
-// 1 = walk per call, 2 = depth-first nodes as lane state)
-size_t bvh_lds(const rt_ctx *c, bool mat, int n_samples) {
-    if (c->walk_form == 1 || c->walk_form == 2)
-        return rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_nodes, c->bvh.n_slots, false, c->walk_form == 1);
-    return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
+constexpr size_t kLdsMax = 152 * 1024;     // what the kernels' dynamic-LDS attribute allows
+
+// ---- which instance, and what it needs (rt_device.h Instance; the rows live next to the instantiations) ----
+
+const rt::Instance *instances(bool fast, int *count) { return fast ? rt::fast_instances(count) : rt::parity_instances(count); }
+
+// the row with this role and workgroup shape (null: this library has none)
+const rt::Instance *find_role(bool fast, int role, int waves) {
+    int n = 0;
+    const rt::Instance *t = instances(fast, &n);
+    for (int k = 0; k < n; ++k)
+        if (t[k].role == role && t[k].waves == waves) return &t[k];
+    return nullptr;
 }
 
-constexpr size_t kLdsMax = 152 * 1024;     // what the kernels' dynamic-LDS attribute allows
+// LDS the hierarchy's staged tables take for this scene
+size_t pairs_lds(const rt_ctx *c, bool mat, int n_samples) {
+    return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
+}
 
 // the plain sweep's tables (geometry and lights) fit LDS for this launch
 bool tables_fit_lds(const rt_ctx *c, int n_samples) {
@@ -316,18 +326,49 @@ bool tables_fit_lds(const rt_ctx *c, int n_samples) {
 bool bvh_fits_lds(const rt_ctx *c, int n_samples) {
     const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
     const bool mat = lds_all <= (size_t)c->mat_lds_limit;
-    return bvh_lds(c, mat, n_samples) <= (size_t)c->bvh_lds_limit;
+    return pairs_lds(c, mat, n_samples) <= (size_t)c->bvh_lds_limit;
 }
 
-// the scene has a hierarchy and there is an instance that can walk it
-bool bvh_usable(const rt_ctx *c, int n_samples) {
-    if (!c->bvh_ok || c->wg_waves == 1 || c->persist != 0) return false;
-    if (c->walk_form == 1 || c->walk_form == 2) return bvh_fits_lds(c, n_samples);      // the A/B forms exist for LDS tables only
-    return true;
+// the scene has a hierarchy and the context may use it
+bool bvh_usable(const rt_ctx *c) { return c->bvh_ok && c->wg_waves != 1 && c->persist == 0; }
+
+// What the instance needs from the context, checked against what the context has: the ONE place that sizes the
+// dynamic LDS and hands out the hierarchy.  An instance whose tables the context lacks is refused (RT_ERR_STATE),
+// whatever route selected it -- the measured choice, a forced form, or a diagnostics mode.
+int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::LaunchParams &p, size_t *lds_out) {
+    const bool needs_bvh = inst.tables == rt::kTabPairsLds || inst.tables == rt::kTabPairsGlobal;
+    p.bvh = rt::BvhTables{};
+    if (needs_bvh) {
+        if (!c->bvh_ok || !c->bvh.blob)
+            return fail(RT_ERR_STATE, "%s walks a hierarchy and the scene has none (fewer than %d small spheres?)", inst.name, c->bvh_min);
+        p.bvh = c->bvh;
+    }
+    size_t lds = 0;
+    switch (inst.tables) {
+        case rt::kTabSweepLds:
+            lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
+            break;
+        case rt::kTabSweepGlobal:
+            p.mat_in_lds = 0;
+            lds = rt::lds_bytes(0, 0, false, n_samples);
+            break;
+        case rt::kTabPairsLds:
+            lds = pairs_lds(c, p.mat_in_lds != 0, n_samples);
+            break;
+        case rt::kTabPairsGlobal:
+            p.mat_in_lds = 0;
+            lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256);
+            break;
+        default:
+            return fail(RT_ERR_STATE, "%s: unknown table kind %d", inst.name, inst.tables);
+    }
+    if (lds > kLdsMax) return fail(RT_ERR_ARG, "%s needs %zu B of LDS for this scene (limit %zu)", inst.name, lds, kLdsMax);
+    *lds_out = lds;
+    return RT_OK;
 }
 
-// `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one that fits), 2 = the plain sweep
-int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
+// `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one), 2 = the plain sweep
+int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool natural_order = false) {
     if (!c->have_scene || !c->have_cam)
         return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
     if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
@@ -342,89 +383,52 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     // materials ride along in LDS only while that keeps at least 6 workgroups per CU resident
     // (160 KiB / 24 KiB); larger scenes read them from L2 once per hit
     p.mat_in_lds = lds_all <= (size_t)c->mat_lds_limit;
-    const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
+    const size_t lds_sweep = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
 
-    // which instance: arithmetic mode x any-hit form x workgroup shape.  Single-wavefront workgroups (8x8 tiles)
-    // keep the wave slots of a CU full (a 4-wavefront workgroup waits for four free slots at once) and give the
-    // heavy-first order a finer granule; each stages its own copy of the tables, so only while 24 copies fit a CU.
+    // which instance: arithmetic mode x role x workgroup shape.  Single-wavefront workgroups (8x8 tiles) keep the wave
+    // slots of a CU full (a 4-wavefront workgroup waits for four free slots at once) and give the heavy-first order a
+    // finer granule; each stages its own copy of the tables, so only while 24 copies fit a CU.
+    bool fast = c->mode == RT_MODE_FAST;
     const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
-    const bool fast = c->mode == RT_MODE_FAST;
-    const bool w1 = c->wg_waves == 1 || (c->wg_waves == 0 && lds + (coop ? 1536u : 256u) <= 6 * 1024);   // + the instance's static LDS
-    int variant = fast ? (coop ? (w1 ? rt::kFastCoopW1Variant : rt::kFastCoopVariant) : (w1 ? rt::kFastW1Variant : 0))
-                       : (coop ? (w1 ? rt::kParityCoopW1Variant : rt::kParityCoopVariant) : (w1 ? rt::kParityW1Variant : 0));
-    bool use_fast_table = fast;
-    bool persist = false;
-    // large scenes: the instance that walks the hierarchy, while its tables leave room for two workgroups per CU
-    size_t lds_use = lds;
-    const size_t lds_bvh = c->bvh_ok ? bvh_lds(c, p.mat_in_lds != 0, n_samples) : 0;
-    const bool in_lds = tables_fit_lds(c, n_samples);
-    if (form != 2 && bvh_usable(c, n_samples)) {
-        const bool per_call = c->walk_form == 1;
-        p.bvh = c->bvh;
-        if (per_call || c->walk_form == 2 || bvh_fits_lds(c, n_samples)) {
-            variant = per_call ? (fast ? rt::kFastBvhVariant : rt::kParityBvhVariant)
-                               : c->walk_form == 2 ? (fast ? rt::kFastWalkVariant : rt::kParityWalkVariant)
-                                                   : (fast ? rt::kFastPairsVariant : rt::kParityPairsVariant);
-            lds_use = lds_bvh;
-        } else {
-            // tables beyond the LDS budget: the same walk over pairs and slots where they lie; staged: header, stacks
-            variant = fast ? rt::kFastPairsGlobalVariant : rt::kParityPairsGlobalVariant;
-            p.mat_in_lds = 0;
-            lds_use = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256);
-        }
-        if (!per_call && c->regen_gate <= 0) p.regen_gate = c->walk_gate;
-    } else if (!in_lds) {
+    const bool w1 = c->wg_waves == 1 || (c->wg_waves == 0 && lds_sweep + (coop ? 1536u : 256u) <= 6 * 1024);   // + the instance's static LDS
+    int role = coop ? rt::kRoleCoop : rt::kRolePlain, waves = w1 ? 1 : 4;
+    if (form != 2 && bvh_usable(c)) {
+        // large scenes: the walk over the hierarchy, from LDS while its tables leave room for five workgroups per CU
+        role = bvh_fits_lds(c, n_samples) ? rt::kRolePairs : rt::kRolePairsGlobal;
+        waves = 4;
+        if (c->regen_gate <= 0) p.regen_gate = c->walk_gate;
+    } else if (!tables_fit_lds(c, n_samples)) {
         // no hierarchy (or it lost the measurement) and a table beyond LDS: the plain sweep over the table in HBM / L2
-        variant = fast ? rt::kFastGlobalVariant : rt::kParityGlobalVariant;
-        p.mat_in_lds = 0;
-        lds_use = rt::lds_bytes(0, 0, false, n_samples);
+        role = rt::kRoleSweepGlobal;
+        waves = 4;
     }
     p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
+    const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
-    persist = c->persist != 0 && (c->mode == RT_MODE_FAST || c->mode == RT_MODE_PARITY);
-    if (persist) variant = fast ? (coop ? rt::kFastPersistCoopVariant : rt::kFastPersistVariant)
-                                : (coop ? rt::kParityPersistCoopVariant : rt::kParityPersistVariant);
-    else if (c->mode >= 200) { variant = c->mode - 200; use_fast_table = true; }
-    else if (c->mode >= 100) { variant = c->mode - 100; use_fast_table = false; }
-    if (c->mode >= 100) {
-        const bool pairs_g = variant == (use_fast_table ? rt::kFastPairsGlobalVariant : rt::kParityPairsGlobalVariant);
-        const bool plain_g = variant == (use_fast_table ? rt::kFastGlobalVariant : rt::kParityGlobalVariant);
-        const bool wants_bvh = pairs_g || (use_fast_table ? (variant >= rt::kFastBvhVariant && variant <= rt::kFastPairsVariant)
-                                                          : (variant >= rt::kParityBvhVariant && variant <= rt::kParityPairsVariant + 1));
-        p.bvh = rt::BvhTables{};
-        lds_use = lds;
-        if (wants_bvh) {
-            if (!c->bvh_ok) return fail(RT_ERR_STATE, "mode %d needs a scene with a hierarchy (rt_debug_set_bvh)", c->mode);
-            const bool full = !use_fast_table && variant == rt::kParityBvhCheckVariant;
-            p.bvh = c->bvh;
-            const bool walk = use_fast_table ? variant == rt::kFastWalkVariant : variant >= rt::kParityWalkVariant;
-            const bool pairs = use_fast_table ? variant == rt::kFastPairsVariant : variant >= rt::kParityPairsVariant;
-            lds_use = pairs_g ? rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256)
-                      : pairs ? rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_leaves,
-                                                    c->bvh.n_slots, c->bvh.stack_depth, 256)
-                              : rt::lds_bytes_bvh(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples, c->bvh.n_nodes,
-                                                  c->bvh.n_slots, full, !walk);
-            if (lds_use > 152 * 1024) return fail(RT_ERR_ARG, "mode %d needs %zu B of LDS", c->mode, lds_use);
-        }
-        if (pairs_g || plain_g) p.mat_in_lds = 0;
-        if (plain_g) lds_use = rt::lds_bytes(0, 0, false, n_samples);
+    if (c->persist != 0 && c->mode < 100) {
+        role = coop ? rt::kRolePersistCoop : rt::kRolePersist;
+        waves = 4;
+    } else if (c->mode >= 100) {           // a row of the table by number (rt_set_mode checked the range)
+        fast = c->mode >= 200;
+        int n = 0;
+        const rt::Instance *t = instances(fast, &n);
+        inst = &t[c->mode - (fast ? 200 : 100)];
     }
 #endif
-    const int waves = use_fast_table ? rt::fast_variant_waves(variant) : rt::parity_variant_waves(variant);
-    const int tile_w = 8 * waves;
+    if (!inst) inst = find_role(fast, role, waves);
+    if (!inst) return fail(RT_ERR_STATE, "this library holds no %s instance of role %d with %d wavefronts per workgroup", fast ? "fast" : "parity", role, waves);
+    size_t lds_use = 0;
+    rc = bind_tables(c, *inst, n_samples, p, &lds_use);
+    if (rc != RT_OK) return rc;
+    const bool persist = (inst->flags & rt::kInstPersistent) != 0;
+
+    const int tile_w = 8 * inst->waves;
     dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
-    hipError_t e;
     // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
     // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)
     const uint32_t n_tiles = grid.x * grid.y;
-    bool instance_logs_cost = !persist;
-#if RT_DIAGNOSTICS
-    // A/B instances that predate the order (parity_r0) or have their own scheduling (stage-scheduled ones) neither
-    // read an order nor leave costs
-    if (!use_fast_table && (variant == 2 || variant == 3 || variant == 8)) instance_logs_cost = false;
-    if (use_fast_table && variant == 2) instance_logs_cost = false;
-#endif
+    const bool instance_logs_cost = (inst->flags & rt::kInstNoTileCost) == 0;
     if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
         if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
@@ -434,12 +438,11 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
             c->order_valid = true;
             c->order_age = 0;
         }
-        if (c->order_valid) p.order = c->d_order;
+        if (c->order_valid && !natural_order) p.order = c->d_order;
     }
-#if RT_DIAGNOSTICS
     if (persist) {
         // just enough workgroups to fill the machine; the tile queue (counters[30]) does the rest
-        size_t per_cu = lds > 0 ? (160 * 1024) / (lds + 6 * 1024) : 6;
+        size_t per_cu = lds_use > 0 ? (160 * 1024) / (lds_use + 6 * 1024) : 6;
         if (per_cu > 6) per_cu = 6;
         if (per_cu < 1) per_cu = 1;
         size_t blocks = (size_t)c->n_cus * per_cu;
@@ -448,20 +451,21 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
         grid = dim3((unsigned)blocks, 1, 1);
         HIP_TRY(hipMemsetAsync(c->d_counters + 30, 0, sizeof(unsigned long long), stream));
     }
-    if (c->mode == 100 + rt::kParityTimelogVariant && c->d_timelog && c->timelog_used < c->timelog_cap) {
+#if RT_DIAGNOSTICS
+    if (inst->role == rt::kRoleTimelog && c->d_timelog && c->timelog_used < c->timelog_cap) {
         p.timelog = c->d_timelog;
         p.seq = c->timelog_used++;
         p.tl_tag = c->timelog_tag;
         p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
     }
 #endif
-    e = use_fast_table ? rt::launch_fast(variant, p, grid, lds_use, stream) : rt::launch_parity(variant, p, grid, lds_use, stream);
+    const hipError_t e = rt::launch_instance(*inst, p, grid, lds_use, stream);
     if (e != hipSuccess)
-        return fail(RT_ERR_HIP, "kernel launch failed: %s (grid %ux%u, lds %zu B)",
-                    hipGetErrorString(e), grid.x, grid.y, lds_use);
+        return fail(RT_ERR_HIP, "kernel launch failed: %s (%s, grid %ux%u, lds %zu B)", hipGetErrorString(e), inst->name, grid.x, grid.y, lds_use);
     c->current_sample += n_samples;
     c->launches += 1;
-    c->last_kernel = use_fast_table ? rt::fast_variant_name(variant) : rt::parity_variant_name(variant);
+    c->last_kernel = inst->name;
+    c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal) ? 1 : 2;
     if (p.tile_cost && n_samples >= 4) {
         c->cost_valid = true;
         c->cost_tiles = n_tiles;
@@ -471,13 +475,18 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     return RT_OK;
 }
 
-// Hierarchy or plain sweep for this scene?  The walk wins by 3x on a thousand spheres scattered over a plane and
-// loses on a box packed with overlapping glass -- so it is measured: the first launch of a new scene walks the
-// hierarchy, the second sweeps, each between two events; when both have finished (asked without blocking), the
-// form that took less time per pass renders the rest.  A blocking call with enough passes splits off one pass for
-// each probe and waits for the verdict before it queues the rest (progressive passes equal one launch bit for bit).
+// Hierarchy or plain sweep for this scene?  The walk wins by 5x on a thousand spheres scattered over a plane and
+// loses on a box packed with overlapping glass -- so it is measured, once per scene: four launches in the same
+// (natural) tile order -- the hierarchy warm, the hierarchy timed, the sweep warm, the sweep timed, each timed one
+// between two events -- and when both timings have arrived (asked without blocking) the form that took less time per
+// pass renders the rest.  A blocking call with enough passes splits off 1 + 2 + 1 + 2 passes for the probes and waits
+// for the verdict before it queues the rest (progressive passes equal one launch bit for bit).  The verdict is kept
+// for the scene; device-resident updates keep it until the tree has changed size by a quarter or 256 updates have
+// gone by (rearm_probe_if_changed).  In a multi-device context only the first shard measures; the others follow it.
+constexpr int kProbeSteps = 4;          // hierarchy warm, hierarchy timed, sweep warm, sweep timed
+
 void probe_poll(rt_ctx *c, bool wait) {
-    if (c->bvh_pick != 0 || c->probe_state < 2) return;
+    if (c->bvh_pick != 0 || c->probe_state < kProbeSteps) return;
     if (wait) {
         if (hipEventSynchronize(c->probe_ev[3]) != hipSuccess) return;
     } else if (hipEventQuery(c->probe_ev[3]) != hipSuccess) {
@@ -492,39 +501,68 @@ void probe_poll(rt_ctx *c, bool wait) {
     const double ta = (double)a / c->probe_samples[0], tb = (double)b / c->probe_samples[1];
     c->probe_ms[0] = ta;
     c->probe_ms[1] = tb;
-    c->bvh_pick = ta <= 1.1 * tb ? 1 : 2;       // (the second probe may already run heavy tiles first)
+    c->bvh_pick = ta <= 1.05 * tb ? 1 : 2;      // (a dead band of 5 % towards the usual winner: no flipping on a tie)
+    c->probe_tree = c->bvh.n_slots - c->bvh.n_always;
+    c->probe_always = c->bvh.n_always;
+    c->probe_updates = 0;
 }
 
 int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
-    const int k = c->probe_state;               // 0: hierarchy, 1: plain sweep
+    const int k = c->probe_state;               // 0, 1: hierarchy (warm, timed); 2, 3: plain sweep (warm, timed)
+    const bool timed = (k & 1) != 0;
+    const int arm = k >> 1;
     int rc = chain(c, stream);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipEventRecord(c->probe_ev[2 * k], stream));
-    rc = launch_form(c, n_samples, stream, k == 0 ? 1 : 2);
+    if (timed) HIP_TRY(hipEventRecord(c->probe_ev[2 * arm], stream));
+    rc = launch_form(c, n_samples, stream, arm == 0 ? 1 : 2, true);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipEventRecord(c->probe_ev[2 * k + 1], stream));
-    c->probe_samples[k] = n_samples;
+    if (timed) {
+        HIP_TRY(hipEventRecord(c->probe_ev[2 * arm + 1], stream));
+        c->probe_samples[arm] = n_samples;
+    }
     c->probe_state = k + 1;
     return RT_OK;
 }
 
+void rearm_probe(rt_ctx *c) {
+    c->bvh_pick = 0;
+    c->probe_state = 0;
+    c->probe_ms[0] = c->probe_ms[1] = 0.0;
+    c->probe_updates = 0;
+}
+
+// after a device-resident update rebuilt the hierarchy: is the verdict still about this tree?
+void rearm_probe_if_changed(rt_ctx *c) {
+    if (c->bvh_pick == 0 && c->probe_state == 0) return;
+    if (!c->bvh_ok) {
+        rearm_probe(c);
+        return;
+    }
+    const uint32_t tree = c->bvh.n_slots - c->bvh.n_always, always = c->bvh.n_always;
+    auto moved = [](uint32_t now, uint32_t then) { return 4u * (now > then ? now - then : then - now) > then + 8u; };
+    if (moved(tree, c->probe_tree) || moved(always, c->probe_always) || ++c->probe_updates >= 256) rearm_probe(c);
+}
+
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false) {
-    const bool measured = c->walk_form == 0 && c->mode < 100;
-    if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c, n_samples))
+    const bool measured = c->walk_forced == 0 && c->mode < 100;
+    if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c))
         return launch_form(c, n_samples, stream, measured ? 2 : 0);
     // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
     // scene measured, open or packed, and one pass of the sweep at 1080p costs 2.6 ms at 1024 spheres,
     // 28 ms at 4096, 138 ms at 8192, seconds beyond LDS
     if (c->bvh.n_slots - c->bvh.n_always >= 1500u || !tables_fit_lds(c, n_samples)) return launch_form(c, n_samples, stream, 1);
+    if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
+        return launch_form(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);
     probe_poll(c, false);
     if (c->bvh_pick != 0) return launch_form(c, n_samples, stream, c->bvh_pick);
-    if (c->probe_state == 2) return launch_form(c, n_samples, stream, 1);    // both probes in flight: the usual winner meanwhile
+    if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 1);    // probes in flight: the usual winner meanwhile
     if (may_block && n_samples >= 16) {
         int done = 0;
-        while (c->probe_state < 2) {
-            const int rc = launch_probe(c, 1, stream);
+        while (c->probe_state < kProbeSteps) {
+            const int k = (c->probe_state & 1) ? 2 : 1;
+            const int rc = launch_probe(c, k, stream);
             if (rc != RT_OK) return rc;
-            done += 1;
+            done += k;
         }
         probe_poll(c, true);
         return launch_form(c, n_samples - done, stream, c->bvh_pick ? c->bvh_pick : 1);
@@ -748,6 +786,10 @@ RT_API void rt_destroy(rt_ctx *c) {
         if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
         for (int k = 0; k < 4; ++k)
             if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]);
+        for (auto &f : c->flight) {
+            if (f.start) (void)hipEventDestroy(f.start);
+            if (f.stop) (void)hipEventDestroy(f.stop);
+        }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -782,9 +824,7 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     c->is_light.assign(c->scene_cap, 0);
     c->h_spheres.assign(spheres, spheres + count);
     c->cost_valid = c->order_valid = false;
-    c->bvh_pick = 0;                    // a new scene: hierarchy or plain sweep is measured again
-    c->probe_state = 0;
-    c->probe_ms[0] = c->probe_ms[1] = 0.0;
+    rearm_probe(c);                     // a new scene: hierarchy or plain sweep is measured again
     rc = upload_spheres(c, 0, count, spheres, count, c->stream);
     if (rc != RT_OK) {
         c->have_scene = false;          // the tables are in an unknown state
@@ -807,7 +847,9 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     // the last frames' costs still predict this one (moving spheres): the order stays, and is sorted again from
     // fresh costs after a few changes
     if (++c->order_age >= 8) c->order_valid = false;
-    return upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
+    rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
+    if (rc == RT_OK) rearm_probe_if_changed(c);
+    return rc;
 }
 
 RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
@@ -826,7 +868,10 @@ RT_API int rt_set_mode(rt_ctx *c, int mode) {
     bool ok = mode == RT_MODE_PARITY || mode == RT_MODE_FAST;
 #if RT_DIAGNOSTICS
     // 100+k / 200+k: A/B instances of the parity / fast arithmetic (rt_debug.h; not part of the contract)
-    ok = ok || (mode >= 100 && mode < 100 + rt::parity_variant_count()) || (mode >= 200 && mode < 200 + rt::fast_variant_count());
+    int n_par = 0, n_fast = 0;
+    (void)rt::parity_instances(&n_par);
+    (void)rt::fast_instances(&n_fast);
+    ok = ok || (mode >= 100 && mode < 100 + n_par) || (mode >= 200 && mode < 200 + n_fast);
 #endif
     if (!ok) return fail(RT_ERR_ARG, "mode %d", mode);
     if (c->multi) return rt::multi_set_mode(c, mode);
@@ -870,7 +915,75 @@ RT_API int rt_render_async(rt_ctx *c, int n_samples, void *hip_stream) {
     if (c->multi) return rt::multi_render(c, nullptr, n_samples, false);
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
-    return launch(c, n_samples, (hipStream_t)hip_stream);
+    if (!c->throttle_on || n_samples <= 0) return launch(c, n_samples, (hipStream_t)hip_stream);
+    // rt_throttle's bookkeeping: this launch between two events of the ring (the oldest entry is waited for first)
+    hipStream_t stream = (hipStream_t)hip_stream;
+    rt_ctx::Flight &f = c->flight[c->flight_next];
+    if (f.pending) {
+        HIP_TRY(hipEventSynchronize(f.stop));
+        f.pending = false;
+    }
+    rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(f.start, stream));
+    rc = launch(c, n_samples, stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(f.stop, stream));
+    f.n_samples = n_samples;
+    f.pending = true;
+    c->flight_next = (c->flight_next + 1) % rt_ctx::kFlights;
+    return RT_OK;
+}
+
+RT_API int rt_throttle(rt_ctx *c, int max_in_flight, double *ms_per_pass) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    if (max_in_flight < 0) return fail(RT_ERR_ARG, "max_in_flight %d", max_in_flight);
+    if (ms_per_pass) *ms_per_pass = 0.0;
+    if (c->multi) {
+        if (max_in_flight > 0) return RT_OK;
+        const int n = rt::multi_shards(c);
+        for (int r = 0; r < n; ++r) {
+            rt_ctx *s = rt::multi_shard(c, r);
+            HIP_TRY(hipSetDevice(s->device));
+            HIP_TRY(hipStreamSynchronize(s->last_stream));
+        }
+        return RT_OK;
+    }
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    if (!c->throttle_on) {
+        for (auto &f : c->flight) {
+            HIP_TRY(hipEventCreate(&f.start));
+            HIP_TRY(hipEventCreate(&f.stop));
+        }
+        c->throttle_on = true;
+        if (max_in_flight == 0) return wait_all(c);
+        return RT_OK;
+    }
+    // oldest first: retire what has finished, wait for the oldest while too many are left
+    int pending = 0;
+    for (const auto &f : c->flight) pending += f.pending ? 1 : 0;
+    for (int k = 0; k < rt_ctx::kFlights && pending > 0; ++k) {
+        rt_ctx::Flight &f = c->flight[(c->flight_next + k) % rt_ctx::kFlights];
+        if (!f.pending) continue;
+        if (pending > max_in_flight) {
+            HIP_TRY(hipEventSynchronize(f.stop));
+        } else if (hipEventQuery(f.stop) != hipSuccess) {
+            (void)hipGetLastError();
+            break;                          // (launches of one context finish in issue order)
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, f.start, f.stop) == hipSuccess && f.n_samples > 0) c->flight_ms_per_pass = (double)ms / f.n_samples;
+        else (void)hipGetLastError();
+        f.pending = false;
+        pending -= 1;
+    }
+    if (max_in_flight == 0) {
+        rc = wait_all(c);                   // (launches from before the first rt_throttle call, copies)
+        if (rc != RT_OK) return rc;
+    }
+    if (ms_per_pass) *ms_per_pass = c->flight_ms_per_pass;
+    return RT_OK;
 }
 
 RT_API int rt_render_pass(rt_ctx *c, uint32_t *out_host, int n_samples) {
@@ -918,6 +1031,26 @@ RT_API int rt_read_pixels(rt_ctx *c, uint32_t *out_host) {
     HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels,
                            (size_t)c->local_rows * c->w * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+RT_API int rt_read_pixels_async(rt_ctx *c, uint32_t *out_host, void *hip_stream) {
+    if (!c || !out_host) return fail(RT_ERR_ARG, "null argument");
+    if (c->multi) return rt::multi_read_pixels(c, out_host);
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    if (c->local_rows == 0) return RT_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+    if (!c->pixels_current && c->current_sample > 0) {
+        rt::LaunchParams p = make_params(c, 0);
+        hipError_t e = (c->mode == RT_MODE_FAST || c->mode >= 200) ? rt::launch_pack_fast(p, stream) : rt::launch_pack_parity(p, stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "pack kernel launch failed: %s", hipGetErrorString(e));
+        c->pixels_current = true;
+    }
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels, (size_t)c->local_rows * c->w * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, stream));
     return RT_OK;
 }
 
@@ -1145,7 +1278,38 @@ RT_API int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out,
 #if RT_DIAGNOSTICS
 // =============================== diagnostics build only (rt_debug.h) ===========================
 
-RT_API int rt_debug_variant_count(int fast) { return fast ? rt::fast_variant_count() : rt::parity_variant_count(); }
+RT_API int rt_debug_variant_count(int fast) {
+    int n = 0;
+    (void)instances(fast != 0, &n);
+    return n;
+}
+// the rt_set_mode value that selects the instance with this kernel symbol (100 + row / 200 + row), or RT_ERR_ARG
+RT_API int rt_debug_instance(const char *name) {
+    if (!name) return fail(RT_ERR_ARG, "name is null");
+    for (int fast = 0; fast < 2; ++fast) {
+        int n = 0;
+        const rt::Instance *t = instances(fast != 0, &n);
+        for (int k = 0; k < n; ++k)
+            if (strcmp(t[k].name, name) == 0) return (fast ? 200 : 100) + k;
+    }
+    return fail(RT_ERR_ARG, "no instance named %s in this library", name);
+}
+// the kernel instance the last launch of shard `shard` of a multi-device context used ("" for a plain context or beyond the shards)
+RT_API const char *rt_debug_shard_kernel(rt_ctx *c, int shard) {
+    if (!c || !c->multi || shard < 0 || shard >= rt::multi_shards(c)) return "";
+    return rt::multi_shard(c, shard)->last_kernel;
+}
+// failure injection: the state a failed gather (ncclGroupEnd) leaves a multi-device context in -- every later call is refused
+RT_API int rt_debug_break_gather(rt_ctx *c) {
+    if (!c || !c->multi) return fail(RT_ERR_ARG, "not a multi-device context");
+    return rt::multi_debug_break(c);
+}
+// the kernel symbol of row `row` of the parity (fast = 0) or fast table, or "" beyond it
+RT_API const char *rt_debug_instance_name(int fast, int row) {
+    int n = 0;
+    const rt::Instance *t = instances(fast != 0, &n);
+    return (row >= 0 && row < n) ? t[row].name : "";
+}
 
 static int dbg_set_gate(rt_ctx *c, int v) { c->regen_gate = v; return RT_OK; }
 static int dbg_set_matlds(rt_ctx *c, int v) { c->mat_lds_limit = v; return RT_OK; }
@@ -1200,8 +1364,7 @@ RT_API int rt_debug_read_tile_order(rt_ctx *c, uint32_t *order_out, uint32_t *co
 static int dbg_set_bvh_lds(rt_ctx *c, int v) { if (v > 0) c->bvh_lds_limit = v; return RT_OK; }
 static int dbg_set_bvh_min(rt_ctx *c, int v) {
     c->bvh_min = v;
-    c->bvh_pick = 0;
-    c->probe_state = 0;
+    rearm_probe(c);
     if (!c->have_scene) return RT_OK;
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
@@ -1216,15 +1379,14 @@ RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     return dbg_apply(c, dbg_set_walk_round, steps);
 }
 
-static int dbg_set_walk_form(rt_ctx *c, int v) { c->walk_form = v; c->bvh_pick = 0; c->probe_state = 0; return RT_OK; }
-// rt_walk.inc.h: node tests per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
-// form: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = always the walk-per-call form,
-// 2 = always the walk
-RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int per_call) {
-    if (!c || steps < 0 || gate < 0 || gate > 64 || per_call < 0 || per_call > 3) return fail(RT_ERR_ARG, "steps %d, gate %d, form %d", steps, gate, per_call);
+static int dbg_set_walk_forced(rt_ctx *c, int v) { c->walk_forced = v ? 1 : 0; rearm_probe(c); return RT_OK; }
+// rt_walk.inc.h: pair steps per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
+// forced: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = the hierarchy whenever the scene has one
+RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int forced) {
+    if (!c || steps < 0 || gate < 0 || gate > 64 || forced < 0 || forced > 1) return fail(RT_ERR_ARG, "steps %d, gate %d, forced %d", steps, gate, forced);
     int rc = dbg_apply(c, dbg_set_walk_steps, steps);
     if (rc == RT_OK) rc = dbg_apply(c, dbg_set_walk_gate, gate);
-    return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_form, per_call);
+    return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_forced, forced);
 }
 // rays8[i] = { o.xyz, t_max, d.xyz, shadow != 0 } through the hierarchy walk and through the plain sweep (csrc/rt_walk.inc.h
 // rt_walk_rays kernel); out4[i] = the walk's answer, then the sweep's (closest: distance bits, scene index; shadow: first
@@ -1264,7 +1426,7 @@ RT_API int rt_debug_set_bvh(rt_ctx *c, int min_spheres, int lds_limit) {
     int rc = dbg_apply(c, dbg_set_bvh_lds, lds_limit);
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_bvh_min, min_spheres);
 }
-// the blob of rt_device.h BvhTables as it lies in HBM (float4 units), and its four counts {always, leaves, nodes, slots};
+// the blob of rt_device.h BvhTables as it lies in HBM (float4 units), and its four counts {always, leaves, stack depth, slots};
 // counts of 0 = the scene has no hierarchy
 RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, uint32_t *counts4) {
     if (!c || c->multi || !counts4) return fail(RT_ERR_ARG, "null / multi-device context");
@@ -1274,8 +1436,8 @@ RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, ui
     if (rc != RT_OK) return rc;
     counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
     if (!c->bvh_ok) return RT_OK;
-    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.n_nodes; counts4[3] = c->bvh.n_slots;
-    const size_t need = rt::bvh_blob_float4s(c->bvh.n_nodes, c->bvh.n_slots) + 4 * (size_t)(c->bvh.n_leaves - 1);   // ... | pairs
+    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.stack_depth; counts4[3] = c->bvh.n_slots;
+    const size_t need = rt::bvh_blob_float4s(c->bvh.n_leaves, c->bvh.n_slots);
     if (blob_out) {
         if (cap_float4 < need) return fail(RT_ERR_ARG, "blob needs %zu float4", need);
         HIP_TRY(hipMemcpy(blob_out, c->d_bvh, need * sizeof(float4), hipMemcpyDeviceToHost));

@@ -15,8 +15,7 @@ namespace {
 //   1. a sphere stays outside the tree ("always" list, scene order kept) unless its radius and centre are finite and
 //      |rad| <= r_cut (the host derives r_cut from the median radius: ground planes, walls and lights the size of
 //      the scene would blow up every box above them);
-//   2. the tree's shape is fixed: leaves of kBvhLeaf spheres, leaf ranges split in the middle, laid out depth-first
-//      (a node's first child is the next node, `skip` = node + size of its subtree) and as sibling pairs;
+//   2. the tree's shape is fixed: leaves of kBvhLeaf spheres, leaf ranges split in the middle, written as sibling pairs;
 //   3. who sits in which leaf is decided top-down: the spheres of a node are sorted along the longest axis of the box
 //      of their centres, the left child takes the first half of the node's leaves (a median split by count; one
 //      bitonic sort per level in LDS).  Against sorting once along a Morton curve this cuts the surface-area cost of
@@ -56,10 +55,9 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
     __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad;
     const unsigned tid = threadIdx.x, wave = tid >> 6;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
-    const uint32_t n_nodes = n_leaves ? 2 * n_leaves - 1 : 0;
     const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
-    float4 *hdr = blob, *nodes = blob + 2, *slots = nodes + 2 * (size_t)n_nodes;
-    uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
+    float4 *hdr = blob, *slots = blob + rt::bvh_slots_at();
+    uint32_t *index = reinterpret_cast<uint32_t *>(blob + rt::bvh_index_at(n_slots));
     if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; }
     for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
     __syncthreads();
@@ -198,44 +196,27 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
         s_leaf[2 * leaf + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
     }
     __syncthreads();
-    // ---- 4. one thread per node: leaves by number, inner nodes by the place where they split their range ----
-    for (uint32_t w = tid; w < n_nodes; w += 1024) {
-        const bool is_leaf = w < n_leaves;
-        const uint32_t want = is_leaf ? w : w - n_leaves + 1;       // leaf number, or split point in [1, n_leaves)
-        uint32_t a = 0, b = n_leaves, at = 0;
-        while (b - a > 1) {                                          // (a leaf's walk ends on a range of one)
-            const uint32_t mid = (a + b) / 2;
-            if (!is_leaf && mid == want) break;
-            if (want < mid) { at += 1; b = mid; }
-            else { at += 2 * (mid - a); a = mid; }
-        }
-        float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
-        uint32_t low = 0xffffffffu;
-        for (uint32_t l = a; l < b; ++l) {
-            const float4 A = s_leaf[2 * l], B = s_leaf[2 * l + 1];
-            lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
-            hi[0] = fmaxf(hi[0], B.x); hi[1] = fmaxf(hi[1], B.y); hi[2] = fmaxf(hi[2], B.z);
-            const uint32_t q = __float_as_uint(B.w);
-            low = q < low ? q : low;
-        }
-        const uint32_t skip = at + 2 * (b - a) - 1;
-        const uint32_t link = skip | (is_leaf ? (a + 1) << 16 : 0u);
-        nodes[2 * (size_t)at] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(link));
-        nodes[2 * (size_t)at + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
-        if (at == 0) {
+    // ---- 4. the header: root box (union of the leaf boxes) and radius range ----
+    if (tid == 0) {
+        if (n_leaves) {
+            float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+            for (uint32_t l = 0; l < n_leaves; ++l) {
+                const float4 A = s_leaf[2 * l], B = s_leaf[2 * l + 1];
+                lo[0] = fminf(lo[0], A.x); lo[1] = fminf(lo[1], A.y); lo[2] = fminf(lo[2], A.z);
+                hi[0] = fmaxf(hi[0], B.x); hi[1] = fmaxf(hi[1], B.y); hi[2] = fmaxf(hi[2], B.z);
+            }
             const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
             const float ex = hi[0] - cx, ey = hi[1] - cy, ez = hi[2] - cz;
             hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
             const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
             hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float(s_bad));
+        } else {
+            hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(s_bad));
         }
     }
-    if (n_nodes == 0 && tid == 0) {
-        hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(s_bad));
-    }
-    // ---- 5. the same tree as sibling pairs (rt_device.h BvhTables `pairs`): one thread per inner node ----
-    float4 *pairs = reinterpret_cast<float4 *>(index) + (n_slots + 3) / 4;
+    // ---- 5. the sibling pairs (rt_device.h BvhTables `pairs`): one thread per inner node ----
+    float4 *pairs = blob + rt::bvh_pairs_at(n_slots);
     for (uint32_t m = 1 + tid; m < n_leaves; m += 1024) {
         uint32_t a = 0, b = n_leaves, mid;
         for (;;) {
@@ -265,8 +246,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
 // Trees beyond what one workgroup sorts in LDS (more than 8192 spheres in the tree): the same tables from the host
 // mirror of the records -- same split, same top-down median ordering, same leaves, same sibling pairs, boxes rounded
 // outwards the same way -- written into a page-locked buffer and
-// copied on `stream`.  Milliseconds of host time per build for scenes of this size; nothing is waited for.  The
-// depth-first `nodes` section of the blob (the A/B forms of the walk, LDS tables only) is left out.
+// copied on `stream`.  Milliseconds of host time per build for scenes of this size; nothing is waited for.
 constexpr uint32_t kDeviceBuildMax = 8192;
 
 inline float host_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
@@ -285,8 +265,8 @@ struct HostBox {
 int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, uint32_t n_tree, hipStream_t stream) {
     const std::vector<rt_sphere> &sph = c->h_spheres;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
-    const uint32_t n_nodes = 2 * n_leaves - 1, n_slots = n_always + rt::kBvhLeaf * n_leaves;
-    const size_t total4 = rt::bvh_blob_float4s(n_nodes, n_slots) + 4 * (size_t)(n_leaves - 1);
+    const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
+    const size_t total4 = rt::bvh_blob_float4s(n_leaves, n_slots);
     if (c->bvh_stage_cap < total4) {
         if (c->bvh_stage_used) HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));
         if (c->h_bvh_stage) (void)hipHostFree(c->h_bvh_stage);
@@ -298,9 +278,9 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
         HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));       // the last build's copy still reads the buffer
     }
     float4 *blob = c->h_bvh_stage;
-    float4 *hdr = blob, *slots = blob + 2 + 2 * (size_t)n_nodes;
-    uint32_t *index = reinterpret_cast<uint32_t *>(slots + n_slots);
-    float4 *pairs = reinterpret_cast<float4 *>(index) + (n_slots + 3) / 4;
+    float4 *hdr = blob, *slots = blob + rt::bvh_slots_at();
+    uint32_t *index = reinterpret_cast<uint32_t *>(blob + rt::bvh_index_at(n_slots));
+    float4 *pairs = blob + rt::bvh_pairs_at(n_slots);
     // split; radius range
     std::vector<uint32_t> order;
     order.reserve(n_tree);
@@ -400,10 +380,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     const float ex = root.hi[0] - cx, ey = root.hi[1] - cy, ez = root.hi[2] - cz;
     hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
     hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
-    // one copy: header, then everything from the slots on (the depth-first nodes in between are not written)
-    HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, 2 * sizeof(float4), hipMemcpyHostToDevice, stream));
-    const size_t from = 2 + 2 * (size_t)n_nodes;
-    HIP_TRY(hipMemcpyAsync(c->d_bvh + from, blob + from, (total4 - from) * sizeof(float4), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, total4 * sizeof(float4), hipMemcpyHostToDevice, stream));
     if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
     HIP_TRY(hipEventRecord(c->bvh_stage_ev, stream));
     c->bvh_stage_used = true;
@@ -456,7 +433,7 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
     }
     uint32_t depth = 1;
     while ((1u << depth) < n_leaves) depth += 1;
-    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, 2 * n_leaves - 1, n_always + rt::kBvhLeaf * n_leaves, depth + 1 };
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1 };
     c->bvh_ok = true;
     return RT_OK;
 }

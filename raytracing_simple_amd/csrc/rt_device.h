@@ -34,31 +34,30 @@ struct SceneTables {
     uint32_t n_lights;
 };
 
-// Bounding-volume hierarchy over the small spheres of a large scene (rt_bvh_build_kernel in rt_api.hip;
-// traversal in rt_trace.inc.h, RT_OPT_BVH).  It only decides WHICH spheres a ray is tested against: every test
-// that is made is the reference's arithmetic, and the selection rule (smallest distance, lowest scene index among
-// equals; lowest blocking index for shadow rays) is the reference's loop order restated, so frames and counters do
-// not change.  One blob in HBM, staged into LDS by every workgroup:
+// Bounding-volume hierarchy over the small spheres of a large scene (built by rt_bvh.hip, walked by rt_walk.inc.h).
+// It only decides WHICH spheres a ray is tested against: every test that is made is the reference's arithmetic, and
+// the selection rule (smallest distance, lowest scene index among equals; lowest blocking index for shadow rays) is
+// the reference's loop order restated, so frames and counters do not change.  One blob in HBM:
 //   hdr[0] = { root box centre, half diagonal }   hdr[1] = { min |rad|, max |rad|, 1 / (2 min |rad|), - }
-//   nodes[2k], nodes[2k+1] = { lo.xyz, bits(skip | (leaf+1) << 16) }, { hi.xyz, bits(lowest scene index below) }
-//            in depth-first order: the first child of k is k+1, `skip` is the node after k's subtree
 //   slots[j] = { p, rad*rad } for j < n_always: the spheres that stay outside the tree (large or non-finite), in
-//            scene order, swept by every ray as before; then 4 per leaf, in leaf order (padded with NaN records)
-//   index[j] = scene index of slot j
+//            scene order, swept by every ray as before; then kBvhLeaf per leaf, in leaf order (padded with NaN records)
+//   index[j] = scene index of slot j (u32; read from HBM / L2 for accepted candidates only)
 //   pairs[4m .. 4m+3] = the two children of inner node m as { lo.xyz, bits(ref) }, { hi.xyz, bits(lowest scene index) }
-//            twice; ref = kBvhLeafRef | leaf number, or the number of the child's own pair.  The same tree as `nodes`,
-//            for a walk that takes the nearer child first and keeps the other on a per-lane stack (rt_walk.inc.h).
-//            Inner node m - 1 is the one that splits its range of leaves in front of leaf m; the root is pair
-//            n_leaves / 2 - 1 (a tree of one leaf has no pairs).
+//            twice; ref = kBvhLeafRef | leaf number, or the number of the child's own pair.  The walk takes the nearer
+//            child first and keeps the other on a per-lane stack.  Inner node m - 1 is the one that splits its range
+//            of leaves in front of leaf m; the root is pair n_leaves / 2 - 1 (a tree of one leaf has no pairs).
 constexpr int kBvhLeaf = 8;
 constexpr uint32_t kBvhLeafRef = 0x8000u;
 struct BvhTables {
-    const float4 *blob;     // hdr | nodes | slots | index | pairs
-    uint32_t n_always, n_leaves, n_nodes, n_slots;
+    const float4 *blob;     // hdr | slots | index | pairs
+    uint32_t n_always, n_leaves, n_slots;
     uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1)
 };
-inline size_t bvh_blob_float4s(uint32_t n_nodes, uint32_t n_slots) { return 2 + 2 * (size_t)n_nodes + n_slots + (n_slots + 3) / 4; }
-inline size_t bvh_pairs_offset(uint32_t n_nodes, uint32_t n_slots) { return bvh_blob_float4s(n_nodes, n_slots); }   // float4 units; 4 * (n_leaves - 1) follow
+// offsets into the blob, in float4 units
+__host__ __device__ inline uint32_t bvh_slots_at() { return 2u; }
+__host__ __device__ inline uint32_t bvh_index_at(uint32_t n_slots) { return 2u + n_slots; }
+__host__ __device__ inline uint32_t bvh_pairs_at(uint32_t n_slots) { return 2u + n_slots + (n_slots + 3u) / 4u; }
+inline size_t bvh_blob_float4s(uint32_t n_leaves, uint32_t n_slots) { return (size_t)bvh_pairs_at(n_slots) + 4 * (size_t)(n_leaves ? n_leaves - 1 : 0); }
 // LDS of the instance that walks the pairs: hdr | pairs | slots | per-lane stacks (u16) for `threads` lanes
 inline size_t lds_bytes_pairs(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples, uint32_t n_leaves,
                               uint32_t n_slots, uint32_t stack_depth, int threads) {
@@ -110,44 +109,50 @@ inline size_t lds_bytes(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, 
     return (b + 15) & ~(size_t)15;
 }
 
-// the same for the instances that walk the hierarchy (no full geometry table; the check instance carries both)
-inline size_t lds_bytes_bvh(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples, uint32_t n_nodes,
-                            uint32_t n_slots, bool with_full_table, bool with_index = true) {
-    size_t b = (bvh_blob_float4s(n_nodes, n_slots) - (with_index ? 0 : (n_slots + 3) / 4)) * 16 + (size_t)n_lights * 32;
-    if (with_full_table) b += (size_t)n_spheres * 16;
-    if (mat_in_lds) b += (size_t)n_spheres * 32;
-    if (n_samples <= kMaxK2Table) b += (size_t)(n_samples > 0 ? n_samples : 0) * 4;
-    return (b + 15) & ~(size_t)15;
-}
-
 // Final-frame pack kernels (rt_read_pixels): pixels[lrow*w + x] = toInt of the colour plane, with the
 // arithmetic of the mode that renders (.cl:34,594-596), for frames whose launches skipped the pixel store.
 hipError_t launch_pack_parity(const LaunchParams &p, hipStream_t stream);
 hipError_t launch_pack_fast(const LaunchParams &p, hipStream_t stream);
 
-// variant 0 = the shipped instance; higher indices are A/B shapes (mode 100+k / 200+k) that exist in
-// the diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1) only
-hipError_t launch_parity(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
-hipError_t launch_fast(int variant, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
-constexpr int kParityCoopVariant = 4;   // index of the cooperative-shadow instance in each table
-constexpr int kFastCoopVariant = 3;
-constexpr int kParityPersistVariant = 6, kParityPersistCoopVariant = 7;
-constexpr int kFastPersistVariant = 4, kFastPersistCoopVariant = 5;
-constexpr int kParityTimelogVariant = 9;
-constexpr int kParityW1Variant = 10, kParityCoopW1Variant = 11;   // single-wavefront workgroups (8x8 tiles)
-constexpr int kFastW1Variant = 6, kFastCoopW1Variant = 7;
-constexpr int kParityBvhVariant = 12, kParityBvhCheckVariant = 13;  // hierarchy over the small spheres (large scenes)
-constexpr int kFastBvhVariant = 8;
-constexpr int kParityWalkVariant = 15, kFastWalkVariant = 9;       // ... with the walk as lane state (rt_walk.inc.h)
-constexpr int kParityPairsVariant = 17, kFastPairsVariant = 10;    // ... nearer child first, over the sibling pairs
-constexpr int kParityPairsGlobalVariant = 19, kFastPairsGlobalVariant = 11;   // tables beyond LDS: read where they lie
-constexpr int kParityGlobalVariant = 20, kFastGlobalVariant = 12;
-int parity_variant_waves(int variant);   // wavefronts per workgroup of an instance: 4 (32x8 tile) or 1 (8x8 tile)
-int fast_variant_waves(int variant);
-int parity_variant_count();
-int fast_variant_count();
-const char *parity_variant_name(int variant);   // the kernel's symbol (what rocprofv3 lists), for rt_last_kernel
-const char *fast_variant_name(int variant);
+// ---- the kernel instances ------------------------------------------------------------------------------
+// One row per instance, written next to the instantiations in rt_kernel_parity.hip / rt_kernel_fast.hip: what the
+// instance is and what it needs.  rt_api.hip picks an instance by ROLE, sizes its LDS from `tables` and refuses a
+// launch whose instance needs a table the context does not have -- nothing in the host code depends on the order of
+// the rows.  The product library holds the shipped rows only; the diagnostics build (librt_hip_diag.so) adds the
+// A/B and verification instances (rt_set_mode 100 + row / 200 + row, or by name: rt_debug_instance).
+enum InstanceTables : uint8_t {
+    kTabSweepLds = 0,       // geometry + light tables staged in LDS (lds_bytes)
+    kTabSweepGlobal = 1,    // ... read where they lie in HBM / L2
+    kTabPairsLds = 2,       // the hierarchy (pairs, slots, stacks) staged in LDS (lds_bytes_pairs); needs BvhTables
+    kTabPairsGlobal = 3,    // ... pairs and slots read where they lie; staged: header and stacks; needs BvhTables
+};
+enum InstanceRole : uint8_t {
+    kRoleNone = 0,          // diagnostics: reachable by row / name only
+    kRolePlain,             // small scenes
+    kRoleCoop,              // 12 spheres and more: cooperative any-hit
+    kRolePairs,             // large scenes through the hierarchy
+    kRolePairsGlobal,       // ... tables beyond the LDS budget
+    kRoleSweepGlobal,       // no hierarchy (or it lost the measurement) and a table beyond LDS
+    kRolePersist,           // diagnostics: persistent wavefronts (rt_debug_set_persist)
+    kRolePersistCoop,
+    kRoleTimelog,           // diagnostics: the shipped shape + device wall-clock logging
+};
+enum InstanceFlags : uint8_t {
+    kInstPersistent = 1,    // the grid only fills the machine; tiles come from the queue at counters[30]
+    kInstNoTileCost = 2,    // neither reads the heavy-first order nor leaves per-tile costs
+    kInstStaticCoop = 4,    // carries the cooperative any-hit mailbox (1.5 KiB of static LDS per wavefront)
+};
+struct Instance {
+    void (*fn)(const LaunchParams);
+    const char *name;       // the kernel's symbol: what rocprofv3 lists and rt_last_kernel returns
+    uint8_t waves;          // wavefronts per workgroup: 4 (32x8 tile) or 1 (8x8 tile)
+    uint8_t tables;         // InstanceTables
+    uint8_t role;           // InstanceRole (with `waves`, what launch() selects by)
+    uint8_t flags;          // InstanceFlags
+};
+const Instance *parity_instances(int *count);
+const Instance *fast_instances(int *count);
+hipError_t launch_instance(const Instance &inst, const LaunchParams &p, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_walk_rays(const LaunchParams &p, const float4 *rays, uint32_t n_rays, uint4 *out, size_t lds, hipStream_t stream);   // diagnostics
 hipError_t launch_sqrt_check(unsigned long long *d_mismatches, hipStream_t stream, int which = 0);
 hipError_t launch_rcp_probe(unsigned long long *d_hist, hipStream_t stream);

@@ -42,11 +42,14 @@ struct rt_ctx {
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
     int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
-    int walk_form = 0;                  // 0 = measured choice (below); diagnostics: 1 = the walk-per-call form, 2 = the walk, unmeasured
-    // hierarchy or plain sweep?  Decided per scene by measurement: the first launch of a new scene walks the
-    // hierarchy, the second sweeps, both between events; whichever took less time per pass renders the rest
+    int walk_forced = 0;                // 0 = measured choice (below); diagnostics: 1 = the hierarchy whenever the scene has one
+    // hierarchy or plain sweep?  Decided per scene by measurement (rt_api.hip launch()): each form once warm and once
+    // timed between events, in the same tile order; whichever took less time per pass renders the rest
     int bvh_pick = 0;                   // 0 = not decided yet, 1 = hierarchy, 2 = plain sweep
-    int probe_state = 0;                // probes issued (0..2)
+    int probe_state = 0;                // probe launches issued (0..4)
+    uint32_t probe_tree = 0, probe_always = 0;   // the tree the verdict was measured on
+    int probe_updates = 0;              // device-resident updates since the verdict (it is measured again after 256)
+    rt_ctx *choice_leader = nullptr;    // a shard of a multi-device context: the shard whose verdict it follows (null: its own)
     int probe_samples[2] = { 0, 0 };
     double probe_ms[2] = { 0.0, 0.0 };  // measured time per pass: hierarchy, plain sweep (0 = not measured)
     hipEvent_t probe_ev[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -77,12 +80,24 @@ struct rt_ctx {
     int current_sample = 0;
     uint64_t launches = 0;
     const char *last_kernel = "";       // symbol of the instance the last launch used
+    int last_form = 0;                  // ... 1 = it walked the hierarchy, 2 = a plain sweep (0 = nothing launched yet)
     double last_ms = 0.0;
     unsigned long long debug_counters[24] = {};   // diagnostic instances only
     hipStream_t stream = nullptr;       // the context's own (non-blocking) stream
     hipStream_t last_stream = nullptr;  // stream of the most recent launch / update (what readers wait for)
     bool used_foreign_stream = false;   // some launch went to a caller's stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
+    // rt_throttle: the rt_render_async launches in flight, each between two events (a ring, oldest at flight_next)
+    struct Flight {
+        hipEvent_t start = nullptr, stop = nullptr;
+        int n_samples = 0;
+        bool pending = false;
+    };
+    static constexpr int kFlights = 8;
+    Flight flight[kFlights];
+    int flight_next = 0;
+    bool throttle_on = false;
+    double flight_ms_per_pass = 0.0;    // device time per pass of the most recent finished launch
     // diagnostics build: device wall-clock logs
     unsigned long long *d_timelog = nullptr, *d_wavelog = nullptr, *d_blocklog = nullptr;
     uint32_t *d_stalelog = nullptr;
@@ -126,6 +141,8 @@ void *multi_stream(rt_ctx *front);
 int multi_shards(const rt_ctx *front);
 const char *multi_last_kernel(const rt_ctx *front);
 rt_ctx *multi_first_shard(rt_ctx *front);
+rt_ctx *multi_shard(rt_ctx *front, int r);
 int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg);
+int multi_debug_break(rt_ctx *front);
 
 }  // namespace rt

@@ -91,6 +91,9 @@ struct rt_multi {
     uint32_t *d_gathered = nullptr;     // root: [n][pad_rows][w], rank r's block at r * pad_rows * w
     uint32_t *d_full = nullptr;         // root: [h][w], the assembled frame
     hipEvent_t ev_ready = nullptr;      // emulation: a shard's render done, on its device
+    hipEvent_t ev_copied = nullptr;     // emulation: the root has copied the shards' rows out of their pixel buffers
+    bool broken = false;                // a gather failed half-way: the communicators may hold an open or failed group
+    char broken_why[256] = "";
     uint32_t *pinned_out = nullptr;
     double last_ms = 0.0;
     uint64_t launches = 0;
@@ -105,21 +108,50 @@ int rows_of(int h, int rank, int n, int tile_rows) {
     return rows;
 }
 
+int refuse_if_broken(const rt_multi *m) {
+    if (m->broken) return fail(RT_ERR_STATE, "this multi-device context is unusable since a gather failed (%s): destroy it", m->broken_why);
+    return RT_OK;
+}
+
+int mark_broken(rt_multi *m, int code, const char *what, const char *detail) {
+    m->broken = true;
+    snprintf(m->broken_why, sizeof m->broken_why, "%s: %s", what, detail ? detail : "?");
+    return fail(code, "%s failed: %s -- the multi-device context is now unusable", what, detail ? detail : "?");
+}
+
 // the frame-end gather + assembly, queued behind the renders; root stream ends up holding everything
 int gather_and_assemble(rt_multi *m) {
+    int rc = refuse_if_broken(m);
+    if (rc != RT_OK) return rc;
     rt_ctx *root = m->shard[0];
     const size_t block = (size_t)m->pad_rows * (size_t)m->w;
+    // every transfer must fit the receive slot it lands in (slot r = pad_rows * w words at r * block)
+    for (int r = 1; r < m->n; ++r) {
+        const size_t count = (size_t)m->shard[r]->local_rows * (size_t)m->w;
+        if (count > block || m->shard[r]->w != m->w)
+            return fail(RT_ERR_STATE, "shard %d would send %zu words into a slot of %zu", r, count, block);
+    }
     if (m->n > 1 && !m->emulated) {
-        RCCL_TRY(g_rccl.GroupStart());
-        for (int r = 1; r < m->n; ++r) {
+        // One group: root posts n-1 receives, every other device one send.  A call that fails inside the group must
+        // not leave it open: the group is always ended, and any failure (there or in ncclGroupEnd) marks the context
+        // unusable -- later calls are refused instead of queueing behind a communicator in an unknown state.
+        int r0 = g_rccl.GroupStart();
+        if (r0 != 0) return mark_broken(m, RT_ERR_HIP, "ncclGroupStart", g_rccl.GetErrorString(r0));
+        int bad = 0;
+        const char *bad_what = "";
+        hipError_t bad_hip = hipSuccess;
+        for (int r = 1; r < m->n && !bad && bad_hip == hipSuccess; ++r) {
             const size_t count = (size_t)m->shard[r]->local_rows * (size_t)m->w;
             if (!count) continue;
-            HIP_TRY(hipSetDevice(m->devices[0]));
-            RCCL_TRY(g_rccl.Recv(m->d_gathered + (size_t)r * block, count, kRcclUint32, r, m->comm[0], root->stream));
-            HIP_TRY(hipSetDevice(m->devices[r]));
-            RCCL_TRY(g_rccl.Send(m->shard[r]->d_pixels, count, kRcclUint32, 0, m->comm[r], m->shard[r]->stream));
+            if ((bad_hip = hipSetDevice(m->devices[0])) != hipSuccess) break;
+            if ((bad = g_rccl.Recv(m->d_gathered + (size_t)r * block, count, kRcclUint32, r, m->comm[0], root->stream)) != 0) { bad_what = "ncclRecv"; break; }
+            if ((bad_hip = hipSetDevice(m->devices[r])) != hipSuccess) break;
+            if ((bad = g_rccl.Send(m->shard[r]->d_pixels, count, kRcclUint32, 0, m->comm[r], m->shard[r]->stream)) != 0) { bad_what = "ncclSend"; break; }
         }
-        RCCL_TRY(g_rccl.GroupEnd());
+        const int r1 = g_rccl.GroupEnd();
+        if (bad) return mark_broken(m, RT_ERR_HIP, bad_what, g_rccl.GetErrorString(bad));
+        if (bad_hip != hipSuccess) return mark_broken(m, RT_ERR_HIP, "hipSetDevice inside the gather", hipGetErrorString(bad_hip));
+        if (r1 != 0) return mark_broken(m, RT_ERR_HIP, "ncclGroupEnd", g_rccl.GetErrorString(r1));
     } else if (m->n > 1) {
         // one-GPU rehearsal: the receive slot is filled by a device-to-device copy on the ROOT's stream, which
         // first waits for the sending shard's render (what ncclRecv's pairing with ncclSend does on real links)
@@ -133,6 +165,11 @@ int gather_and_assemble(rt_multi *m) {
             HIP_TRY(hipMemcpyAsync(m->d_gathered + (size_t)r * block, m->shard[r]->d_pixels, count * sizeof(uint32_t),
                                    hipMemcpyDeviceToDevice, root->stream));
         }
+        // ... and a shard's NEXT render must not overwrite its pixel buffer before the root has copied it out (ncclSend
+        // sits on the shard's own stream and orders that by itself; the copy above sits on the root's)
+        HIP_TRY(hipEventRecord(m->ev_copied, root->stream));
+        for (int r = 1; r < m->n; ++r)
+            if (m->shard[r]->local_rows > 0) HIP_TRY(hipStreamWaitEvent(m->shard[r]->stream, m->ev_copied, 0));
     }
     HIP_TRY(hipSetDevice(m->devices[0]));
     return rt_deinterleave_rows(m->d_full, m->d_gathered, m->w, m->h, m->n, m->tile_rows, m->pad_rows, m->devices[0], root->stream);
@@ -149,6 +186,18 @@ RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, in
     if (ngpus < 1 || ngpus > 64 || !devices) return fail(RT_ERR_ARG, "ngpus %d", ngpus);
     if (tile_rows == 0) tile_rows = rt::kTileH;
     if (tile_rows < 0 || tile_rows % rt::kTileH != 0) return fail(RT_ERR_ARG, "tile_rows must be a positive multiple of %d", rt::kTileH);
+    // the list is either all distinct (one RCCL rank per device) or one device n times (the one-GPU rehearsal, whose
+    // transfers are device-to-device copies): RCCL refuses two ranks on a device, and a mixed list would need both
+    int n_same = 0, n_pairs = 0;
+    for (int i = 0; i < ngpus; ++i) {
+        if (devices[i] < 0) return fail(RT_ERR_ARG, "device %d", devices[i]);
+        for (int j = 0; j < i; ++j) {
+            n_pairs += 1;
+            n_same += devices[j] == devices[i] ? 1 : 0;
+        }
+    }
+    if (n_same != 0 && n_same != n_pairs)
+        return fail(RT_ERR_ARG, "the device list must name %d different devices, or one device %d times (the one-GPU rehearsal); a mixed list is refused", ngpus, ngpus);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
@@ -191,6 +240,8 @@ RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, in
             rt_ctx *s = nullptr;
             int rc = rt_create_sharded(&s, w, h, devices[r], r, ngpus, tile_rows);
             if (rc != RT_OK) return rc;
+            // ONE decision per context between the hierarchy and the plain sweep: the first shard measures, the others follow
+            if (r > 0) s->choice_leader = m->shard[0];
             m->shard.push_back(s);
         }
         HIP_TRY(hipSetDevice(devices[0]));
@@ -199,6 +250,7 @@ RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, in
         HIP_TRY(hipMemset(m->d_gathered, 0, (size_t)ngpus * m->pad_rows * w * sizeof(uint32_t)));
         HIP_TRY(hipMemset(m->d_full, 0, (size_t)w * h * sizeof(uint32_t)));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_copied, hipEventDisableTiming));
         // the root renders its own rows straight into its receive slot
         return rt_set_pixel_buffer(m->shard[0], m->d_gathered, (size_t)m->pad_rows * w);
     };
@@ -234,6 +286,7 @@ void multi_destroy(rt_ctx *front) {
         (void)hipFree(m->d_gathered);
         (void)hipFree(m->d_full);
         if (m->ev_ready) (void)hipEventDestroy(m->ev_ready);
+        if (m->ev_copied) (void)hipEventDestroy(m->ev_copied);
     }
     for (rcclComm c : m->comm)
         if (c) (void)g_rccl.CommDestroy(c);
@@ -243,10 +296,15 @@ void multi_destroy(rt_ctx *front) {
 
 int multi_shards(const rt_ctx *front) { return front->multi->n; }
 rt_ctx *multi_first_shard(rt_ctx *front) { return front->multi->shard.empty() ? front : front->multi->shard[0]; }
+rt_ctx *multi_shard(rt_ctx *front, int r) { return front->multi->shard[(size_t)r]; }
 const char *multi_last_kernel(const rt_ctx *front) { return front->multi->shard.empty() ? "" : front->multi->shard[0]->last_kernel; }
 
 #define EACH_SHARD(expr)                          \
     do {                                          \
+        {                                         \
+            int rb_ = refuse_if_broken(front->multi); \
+            if (rb_ != RT_OK) return rb_;         \
+        }                                         \
         for (rt_ctx * s : front->multi->shard) {  \
             int rc_ = (expr);                     \
             if (rc_ != RT_OK) return rc_;         \
@@ -262,6 +320,8 @@ int multi_set_camera(rt_ctx *front, const rt_camera *cam) { EACH_SHARD(rt_set_ca
 int multi_set_mode(rt_ctx *front, int mode) { EACH_SHARD(rt_set_mode(s, mode)); }
 int multi_set_pixel_write(rt_ctx *front, int enable) { EACH_SHARD(rt_set_pixel_write(s, enable)); }
 int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg) { EACH_SHARD(fn(s, arg)); }
+// diagnostics: put the context into the state a failed ncclGroupEnd leaves it in
+int multi_debug_break(rt_ctx *front) { return mark_broken(front->multi, RT_ERR_HIP, "ncclGroupEnd (injected by rt_debug_break_gather)", "unhandled system error"); }
 
 int multi_reset(rt_ctx *front, bool async) {
     rt_multi *m = front->multi;
@@ -276,6 +336,10 @@ void *multi_stream(rt_ctx *front) { return (void *)front->multi->shard[0]->strea
 int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking) {
     rt_multi *m = front->multi;
     if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
+    {
+        int rb = refuse_if_broken(m);
+        if (rb != RT_OK) return rb;
+    }
     // every device starts its rows before any is waited for
     for (int r = 0; r < m->n; ++r) {
         rt_ctx *s = m->shard[r];
@@ -313,6 +377,10 @@ int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking
 
 int multi_read_pixels(rt_ctx *front, uint32_t *out_host) {
     rt_multi *m = front->multi;
+    {
+        int rb = refuse_if_broken(m);
+        if (rb != RT_OK) return rb;
+    }
     rt_ctx *root = m->shard[0];
     const size_t block = (size_t)m->pad_rows * (size_t)m->w;
     // shards whose last launches skipped the pixel store pack their rows now; then the usual gather

@@ -28,27 +28,50 @@
 #ifndef RT_FAST
 #error "define RT_FAST to 0 or 1"
 #endif
-// Sweep shape (closest-hit / any-hit loops over the LDS geometry table):
-//   RT_OPT_UNROLL   spheres per loop trip (1, 2 or 4): independent tests interleave, LDS reads
-//                   are issued ahead of use, compare->select hazards get filled
-//   RT_OPT_SKIPNEG  skip the square-root half of a test when NO lane of the wavefront has a
-//                   non-negative discriminant (wave ballot): a miss then costs 16 VALU ops
-#ifndef RT_OPT_UNROLL
-#define RT_OPT_UNROLL 2
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
 #endif
-#ifndef RT_OPT_SKIPNEG
-#define RT_OPT_SKIPNEG 1
+// Per-instance options (rt_kernel_parity.hip / rt_kernel_fast.hip define them before each include; rt_opts_reset.h
+// forgets them).  The sweep shape itself is fixed: two spheres per loop trip (independent tests interleave, LDS reads
+// are issued ahead of use) and the square-root half of a test skipped when NO lane of the wavefront has a non-negative
+// discriminant (wave ballot).  What was measured against it and dropped is listed in DESIGN.md section 5 with the
+// commits that hold the code.
+//   RT_OPT_WG_WAVES       wavefronts per workgroup, 4 (a 32x8 tile) or 1 (an 8x8 tile).  A workgroup of four holds its
+//                         wave slots until the dispatcher finds room for four more at once; single-wavefront workgroups
+//                         refill slot by slot and give the heavy-first order an 8x8 granule.  Each workgroup stages its
+//                         own copy of the tables, so 1 is for scenes whose tables are small (rt_api.hip picks).
+//   RT_OPT_COOP           1: shadow rays of a wavefront share the idle lanes (coop_any; scenes of 12 spheres and more);
+//                         2: verification instance, the sequential sweep runs beside it (diagnostics)
+//   RT_OPT_WALK           1: large scenes -- the small spheres hang in a hierarchy that each lane walks for its own ray
+//                         (rt_walk.inc.h, its own kernel body); 2: the same with a census of its steps (diagnostics)
+//   RT_OPT_GLOBAL_TABLES  tables that do not fit LDS are read where they lie in HBM / L2
+//   RT_OPT_MINWAVES       launch bound: wavefronts per SIMD the register allocation must allow
+// Diagnostics build only:
+//   RT_OPT_PERSIST        persistent wavefronts: the grid only fills the machine, each wavefront pulls 8x8 pixel tiles
+//                         from a global queue and hands their pixels to its lanes one by one as lanes finish
+//   RT_OPT_STAMPS         section census (executions and active lanes per section, counters[8..19])
+//   RT_OPT_TIMELOG        device wall clock (s_memrealtime) of the launch and of every wavefront (P.timelog / P.wavelog)
+#ifndef RT_OPT_WG_WAVES
+#define RT_OPT_WG_WAVES 4
 #endif
-// RT_OPT_STAMPS: diagnostic instance only -- s_memtime at section boundaries, summed per
-// wavefront into counters[8..17] (never in a timed or shipped instance).
+#ifndef RT_OPT_COOP
+#define RT_OPT_COOP 0
+#endif
+#ifndef RT_OPT_WALK
+#define RT_OPT_WALK 0
+#endif
+#ifndef RT_OPT_GLOBAL_TABLES
+#define RT_OPT_GLOBAL_TABLES 0
+#endif
+#ifndef RT_OPT_MINWAVES
+#define RT_OPT_MINWAVES 1
+#endif
+#ifndef RT_OPT_PERSIST
+#define RT_OPT_PERSIST 0
+#endif
 #ifndef RT_OPT_STAMPS
 #define RT_OPT_STAMPS 0
 #endif
-#ifndef RT_OPT_WAVE_TILE_W
-#define RT_OPT_WAVE_TILE_W 8
-#endif
-// RT_OPT_TIMELOG: diagnostic instance only -- device wall-clock (s_memrealtime) of the launch's first
-// start and last end into P.timelog[P.seq], and of every wavefront into P.wavelog (when non-null)
 #ifndef RT_OPT_TIMELOG
 #define RT_OPT_TIMELOG 0
 #endif
@@ -57,74 +80,6 @@
 // descending order of that cost (P.order), so that the launch ends on cheap tiles (sky) instead of on a
 // few wavefronts of the most expensive ones (glass: up to 8 bounces x 64 samples, 1.7 ms against a mean of
 // 0.5 ms) that happened to start late.  Scheduling only: pixels do not depend on who renders them when.
-// RT_OPT_WG_WAVES: wavefronts per workgroup, 4 (a 32x8 tile) or 1 (an 8x8 tile).  A workgroup of four wavefronts
-// holds its wave slots until the dispatcher finds room for four more at once (measured: 95-96 % of the slots
-// filled on the plateau of a launch); single-wavefront workgroups refill slot by slot and give the heavy-first
-// order an 8x8 granule.  Each workgroup stages its own copy of the tables, so this is for scenes whose tables are
-// small (the host picks: rt_api.hip launch()).
-#ifndef RT_OPT_WG_WAVES
-#define RT_OPT_WG_WAVES 4
-#endif
-// RT_OPT_AB_OLD: the `parity_r0` A/B instance = the shipped shape minus its newest change (tools/ab_bench.py)
-#ifndef RT_OPT_AB_OLD
-#define RT_OPT_AB_OLD 0
-#endif
-#ifndef RT_DIAGNOSTICS
-#define RT_DIAGNOSTICS 0
-#endif
-// RT_OPT_COOP: shadow rays of a wavefront share the idle lanes (coop_any); for large scenes
-#ifndef RT_OPT_COOP
-#define RT_OPT_COOP 0
-#endif
-// RT_OPT_BVH: large scenes.  The small spheres hang in a bounding-volume hierarchy (rt_device.h BvhTables) that
-// each lane walks for its own ray; the few large ones are swept by every ray as before.  The hierarchy only
-// selects candidates -- every candidate goes through the reference's test, and the winner is chosen by the
-// reference's rule -- so frames and counters equal the plain sweep's.  2 = check instance: the plain sweep runs
-// beside the walk and disagreements are counted (counters[20..26]); 3 = census of the walk's steps; 4 = the shipped
-// form, in which a ray's walk is lane state that survives loop trips (rt_walk.inc.h).
-#ifndef RT_OPT_BVH
-#define RT_OPT_BVH 0
-#endif
-// RT_OPT_GLOBAL_TABLES: scenes whose tables do not fit LDS (more than ~9000 spheres, or thousands of lights): the
-// sweeps and the walk read geometry, lights and the hierarchy from HBM / L2 instead of a staged copy.  Same code, same
-// results; the tables are then read through the vector cache at whatever rate that gives.
-#ifndef RT_OPT_GLOBAL_TABLES
-#define RT_OPT_GLOBAL_TABLES 0
-#endif
-// RT_OPT_PERSIST: persistent wavefronts.  The grid only fills the machine; each wavefront pulls
-// 8x8 pixel tiles from a global queue and hands their pixels to its lanes one by one as lanes
-// finish (wave ballot + prefix count), so no lane idles at the end of its pixel while the others
-// of the wavefront still work, and no CU idles while others still hold unstarted tiles.
-#ifndef RT_OPT_PERSIST
-#define RT_OPT_PERSIST 0
-#endif
-// RT_OPT_LEAN_SQRT: parity instances use ieee_sqrt_lean instead of the compiler's sqrtf expansion
-#ifndef RT_OPT_LEAN_SQRT
-#define RT_OPT_LEAN_SQRT 0
-#endif
-// RT_OPT_LEAN_RCP: with LEAN_SQRT, normalisations use the lean reciprocal as well (sqrt_and_rcp)
-#ifndef RT_OPT_LEAN_RCP
-#define RT_OPT_LEAN_RCP 1
-#endif
-// RT_OPT_SHORT_ROOTS: the sweeps use hit_roots' short form of the root decision
-#ifndef RT_OPT_SHORT_ROOTS
-#define RT_OPT_SHORT_ROOTS 1
-#endif
-// RT_OPT_ANY_JOINT: the any-hit sweep decides per sphere pair (the earlier shape) instead of per sphere
-// RT_OPT_GLOSS_ID: the mirror/glass branch reuses n.d of the hit record instead of three more dot products
-#ifndef RT_OPT_GLOSS_ID
-#define RT_OPT_GLOSS_ID 1
-#endif
-#ifndef RT_OPT_ANY_JOINT
-#define RT_OPT_ANY_JOINT 0
-#endif
-#ifndef RT_OPT_JOINT_SKIP
-#define RT_OPT_JOINT_SKIP 0
-#endif
-// RT_OPT_SQRT_NOCHECK: no range check where the argument cannot need it (rt_sqrt_unit, rt_sqrt_det)
-#ifndef RT_OPT_SQRT_NOCHECK
-#define RT_OPT_SQRT_NOCHECK 1
-#endif
 
 
 #undef RT_STAMP
@@ -196,10 +151,8 @@ RT_DEV float ieee_sqrt_lean(float x) {
 RT_DEV float rt_sqrt(float x) {
 #if RT_FAST
     return __builtin_amdgcn_sqrtf(x);
-#elif RT_OPT_LEAN_SQRT
-    return ieee_sqrt_lean(x);
 #else
-    return sqrtf(x);       // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+    return ieee_sqrt_lean(x);
 #endif
 }
 // Square root of a value that is 0 or at least 2^-96 by construction (1 - z*z with z = 1 - 2k/2^23,
@@ -207,12 +160,8 @@ RT_DEV float rt_sqrt(float x) {
 RT_DEV float rt_sqrt_unit(float x) {
 #if RT_FAST
     return __builtin_amdgcn_sqrtf(x);
-#elif RT_OPT_LEAN_SQRT && RT_OPT_SQRT_NOCHECK
-    return ieee_sqrt_core(x);
-#elif RT_OPT_LEAN_SQRT
-    return ieee_sqrt_lean(x);
 #else
-    return sqrtf(x);
+    return ieee_sqrt_core(x);
 #endif
 }
 // Square root of a discriminant (hit_post).  No range check either: for 0 < det < 2^-96 the
@@ -223,12 +172,8 @@ RT_DEV float rt_sqrt_unit(float x) {
 RT_DEV float rt_sqrt_det(float x) {
 #if RT_FAST
     return __builtin_amdgcn_sqrtf(x);
-#elif RT_OPT_LEAN_SQRT && RT_OPT_SQRT_NOCHECK
-    return ieee_sqrt_core(x);
-#elif RT_OPT_LEAN_SQRT
-    return ieee_sqrt_lean(x);
 #else
-    return sqrtf(x);
+    return ieee_sqrt_core(x);
 #endif
 }
 RT_DEV float rt_rcp(float x) {
@@ -255,7 +200,7 @@ RT_DEV float sqrt_and_rcp(float dd, float &root) {
 #if RT_FAST
     root = __builtin_amdgcn_sqrtf(dd);
     return __builtin_amdgcn_rsqf(dd);
-#elif RT_OPT_LEAN_SQRT && RT_OPT_LEAN_RCP
+#else
     if (__builtin_amdgcn_ballot_w64(!(dd >= 0x1p-96f && dd <= 0x1.fffffep+127f)) != 0ull) {
         root = sqrtf(dd);
         return 1.f / root;
@@ -271,9 +216,6 @@ RT_DEV float sqrt_and_rcp(float dd, float &root) {
     const float r0 = __builtin_amdgcn_rcpf(s);
     const float e0 = __builtin_fmaf(-s, r0, 1.f);
     return __builtin_fmaf(e0, r0, r0);
-#else
-    root = rt_sqrt(dd);
-    return 1.f / root;
 #endif
 }
 RT_DEV V3 unit(V3 a) {                                                               // .cl:122-126
@@ -317,20 +259,7 @@ RT_DEV float next_random_z(uint32_t &s0, uint32_t &s1) {
     return 3.0f - __uint_as_float(next_random_word(s0, s1));
 }
 
-// .cl:173-201.  g = {centre, radius^2}.  A negative discriminant makes sq NaN and every
-// comparison below false, which yields the reference's 0.
-RT_DEV float hit_distance(float4 g, V3 o, V3 d) {
-    V3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);
-    float b = dot(op, d);
-    float det = b * b - dot(op, op) + g.w;
-    float sq = rt_sqrt(det);
-    float t1 = b - sq;
-    float t2 = b + sq;
-    float t = t1 > RT_EPS ? t1 : (t2 > RT_EPS ? t2 : 0.f);
-    return det < 0.f ? 0.f : t;
-}
-
-// The same test in two halves: discriminant first, roots second.
+// .cl:173-201 in two halves, g = {centre, radius^2}: discriminant first, roots second.
 struct HitPre {
     float b, det;
 };
@@ -356,84 +285,34 @@ struct HitRoots {
     bool hit;
 };
 RT_DEV HitRoots hit_roots(HitPre p) {
-#if !RT_OPT_SHORT_ROOTS
-    const float h = hit_post(p);
-    return HitRoots{ h, h != 0.f };
-#endif
     const float sq = rt_sqrt_det(p.det);
     const float t1 = p.b - sq;
     const float t2 = p.b + sq;
     return HitRoots{ t1 > RT_EPS ? t1 : t2, (p.det >= 0.f) && (t2 > RT_EPS) };
 }
 // true when some active lane needs the roots (NaN discriminants never hit: .cl:185-200)
-RT_DEV bool wave_any_nonneg(float det) {
-#if RT_OPT_SKIPNEG
-    return __builtin_amdgcn_ballot_w64(det >= 0.f) != 0ull;
-#else
-    (void)det;
-    return true;
-#endif
-}
-// Per-lane "the roots can matter".  Besides det < 0 a sphere is out when it lies behind the
-// ray: b < 0 and det <= fl(b*b) give sqrt_rn(det) <= sqrt_rn(fl(b*b)) = |b| (correctly rounded
-// sqrt is monotonic and returns |b| for a rounded square), so b - sq and b + sq are both <= 0
-// < EPSILON and the reference returns 0.
-RT_DEV float roots_matter(HitPre p) {
-#if RT_OPT_SKIPNEG >= 2
-    const float bb = p.b * p.b;
-    return (p.det >= 0.f && (p.b >= 0.f || p.det > bb)) ? 1.f : -1.f;
-#else
-    return p.det;
-#endif
-}
-
+RT_DEV bool wave_any_nonneg(float det) { return __builtin_amdgcn_ballot_w64(det >= 0.f) != 0ull; }
 // closest hit over spheres [0, n): .cl:215-232
 RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id,
                           unsigned long long &roots) {
     uint32_t i = 0;
-#if RT_OPT_UNROLL >= 4
-    for (; i + 4 <= n; i += 4) {
-        const float4 g0 = s_geom[i], g1 = s_geom[i + 1], g2 = s_geom[i + 2], g3 = s_geom[i + 3];
-        const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d), p2 = hit_pre(g2, o, d),
-                     p3 = hit_pre(g3, o, d);
-        if (wave_any_nonneg(fmaxf(fmaxf(roots_matter(p0), roots_matter(p1)), fmaxf(roots_matter(p2), roots_matter(p3))))) {
-            roots += 4;
-            const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1), h2 = hit_roots(p2), h3 = hit_roots(p3);
-            if (h0.hit && h0.t < t) { t = h0.t; id = i; }
-            if (h1.hit && h1.t < t) { t = h1.t; id = i + 1; }
-            if (h2.hit && h2.t < t) { t = h2.t; id = i + 2; }
-            if (h3.hit && h3.t < t) { t = h3.t; id = i + 3; }
-        }
-    }
-#endif
-#if RT_OPT_UNROLL >= 2
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
-#if RT_OPT_JOINT_SKIP
-        if (wave_any_nonneg(fmaxf(roots_matter(p0), roots_matter(p1)))) {
-            roots += 2;
-            const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1);
-            if (h0.hit && h0.t < t) { t = h0.t; id = i; }
-            if (h1.hit && h1.t < t) { t = h1.t; id = i + 1; }
-        }
-#else
-        if (wave_any_nonneg(roots_matter(p0))) {
+        if (wave_any_nonneg(p0.det)) {
             roots += 1;
             const HitRoots h0 = hit_roots(p0);
             if (h0.hit && h0.t < t) { t = h0.t; id = i; }
         }
-        if (wave_any_nonneg(roots_matter(p1))) {
+        if (wave_any_nonneg(p1.det)) {
             roots += 1;
             const HitRoots h1 = hit_roots(p1);
             if (h1.hit && h1.t < t) { t = h1.t; id = i + 1; }
         }
-#endif
     }
-#endif
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
-        if (wave_any_nonneg(roots_matter(p0))) {
+        if (wave_any_nonneg(p0.det)) {
             roots += 1;
             const HitRoots h0 = hit_roots(p0);
             if (h0.hit && h0.t < t) { t = h0.t; id = i; }
@@ -447,20 +326,9 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
                           unsigned long long &roots) {
     uint32_t first = n;
     uint32_t i = 0;
-#if RT_OPT_UNROLL >= 2
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
-#if RT_OPT_ANY_JOINT
-        if (wave_any_nonneg(fmaxf(roots_matter(p0), roots_matter(p1)))) {
-            roots += 2;
-            const HitRoots h0 = hit_roots(p0), h1 = hit_roots(p1);
-            const bool b0 = (h0.hit && h0.t < max_t), b1 = (h1.hit && h1.t < max_t);
-            const uint32_t cand = b0 ? i : (b1 ? i + 1 : n);
-            first = first < cand ? first : cand;
-            if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
-        }
-#else
         // a lane that already has its blocker asks for no more roots
         if (__builtin_amdgcn_ballot_w64(first == n && p0.det >= 0.f) != 0ull) {
             roots += 1;
@@ -473,9 +341,7 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
             if (first == n && h1.hit && h1.t < max_t) first = i + 1;
         }
         if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
-#endif
     }
-#endif
     for (; i < n; ++i) {
         const HitPre p0 = hit_pre(s_geom[i], o, d);
         if (__builtin_amdgcn_ballot_w64(first == n && p0.det >= 0.f) != 0ull) {
@@ -580,263 +446,6 @@ RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d
 }
 #endif
 
-#if RT_OPT_BVH
-// ---- walking the hierarchy ---------------------------------------------------------------------------
-// A sphere can only matter to a ray if the reference's test (hit_pre / hit_roots above, binary32, rounded after
-// every operation) returns a distance t for it, EPSILON < t <= t_max.  Where is X = o + t d then?  With op = fl(p - o),
-// OP = |op|, B = op.d exactly, b = B + db the computed dot product (|db| <= 3u OP, u = 2^-24), det = b^2 - OP^2 + r^2 + e
-// the computed discriminant (|e| <= 8u M^2, M^2 = OP^2 + r^2: one rounded square, a rounded three-term dot product,
-// the rounded r*r, two rounded sums), sq = sqrt(det)(1 + th), |th| <= u, and tau = b -+ sq before its own rounding:
-//     |X - p|^2 = tau^2 dd - 2 tau B + OP^2 = (sq^2 - b^2 + OP^2) + tau^2 (dd - 1) + 2 tau db
-//               = r^2 + e + 2 th det + tau^2 (dd - 1) + 2 tau db,      |tau| <= OP + |r|, tau^2 <= 2 M^2,
-// so |X - p|^2 <= r^2 + (19u + 2 |dd - 1|) M^2 <= r^2 + eps with eps := (64u + 4 |dd - 1|) M^2: X lies within
-// |r| + min(sqrt(eps), eps / 2|r|) of the centre -- inside the sphere's box grown by that `pad` -- at a ray parameter
-// in (0, t_max].  (The rounding of t itself and of p - o move X by at most 3u (OP + |o|); together with the slab
-// arithmetic's own rounding, bvh_misses below, that is an eighth of the linear term 64u (|o| + OP + |r|) of the pad.)  The walk therefore tests each node's box, grown by
-// `pad`, against the stretch [-pad, t_max + pad] of the ray, with OP bounded by the distance to the far side of the
-// root box and |r| by the largest radius in the tree; the slab arithmetic's own rounding is inside the pad's linear
-// term (bvh_misses below).  A lane whose direction is not a unit vector to within 10^-3, or not finite, gets an
-// infinite pad: it visits everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
-#undef RT_BVH_COUNT
-#if RT_OPT_BVH == 3
-struct BvhCount {                // census instance: [0] node steps of the wavefront, [1] node tests of this lane, [2]/[3] the same for leaves
-    uint32_t v[4];
-};
-#define RT_BVH_COUNT(C, k)                                                                        \
-    do {                                                                                         \
-        const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
-        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)act_) - 1)) (C).v[k] += 1u;      \
-        (C).v[(k) + 1] += 1u;                                                                    \
-    } while (0)
-#else
-struct BvhCount {};
-#define RT_BVH_COUNT(C, k)
-#endif
-struct BvhRay {
-    V3 clo, chi, inv;      // 1 / direction and -(origin +- pad) / direction: a slab distance is one fused multiply-add
-    float tback;           // how far behind the origin / beyond the current best a box still counts
-};
-RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
-    const float4 h0 = s_hdr[0], h1 = s_hdr[1];
-    const float u = 0x1p-24f, inf = __builtin_inff();
-    const float dd = d.x * d.x + d.y * d.y + d.z * d.z;
-    const V3 oc = sub(mk(h0.x, h0.y, h0.z), o);
-    const float far = (__builtin_amdgcn_sqrtf(dot(oc, oc)) + h0.w) * 1.01f;     // >= |p - o| of every sphere in the tree
-    const float skew = fabsf(dd - 1.f);
-    const float eps = (64.f * u + 4.f * skew) * (far * far + h1.y * h1.y);
-    float pad = fminf(__builtin_amdgcn_sqrtf(eps), eps * h1.z);                 // sqrt(r^2 + eps) - r, from above
-    pad = pad * 1.01f + 64.f * u * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far + h1.y);
-    float tback = pad + 1e-6f * far;
-    // (the products below must stay finite: origins and trees beyond 10^18 are walked in full as well)
-    const bool sane = (skew < 1e-3f) & (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far < 1e18f);    // false for NaN
-    pad = sane ? pad : inf;
-    tback = sane ? tback : inf;
-    BvhRay R;
-    // A direction component of (nearly) zero -- cosine-weighted bounces off an axis-aligned normal produce exact
-    // zeros a dozen times per frame -- is taken as +-10^-18: the ray then misses its true line by 10^-18 per unit of
-    // length, and 1 / d and the products with it stay finite (an infinite 1 / d would turn both slab distances of
-    // an axis into the same infinity, or into NaN, whichever side of the slab the origin is on).
-    const float tiny = 1e-18f;
-    R.inv = mk(__builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.x), tiny), d.x)),
-               __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.y), tiny), d.y)),
-               __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.z), tiny), d.z)));
-    R.clo = mk(-(o.x + pad) * R.inv.x, -(o.y + pad) * R.inv.y, -(o.z + pad) * R.inv.z);
-    R.chi = mk(-(o.x - pad) * R.inv.x, -(o.y - pad) * R.inv.y, -(o.z - pad) * R.inv.z);
-    R.tback = tback;
-    return R;
-}
-// True when the ray stretch [-tback, t_far + tback] misses the grown box for certain.  A slab distance is
-// fma(plane, 1/d, -(o +- pad)/d): the plane this computed distance really belongs to -- o +- pad + t d, exactly -- lies
-// within  4u |plane - o| + 2u |o|  of the box's (one ulp of v_rcp_f32, the rounded shifted origin, its rounded product,
-// the fused operation's own rounding), which the pad's linear term covers with the rest (above); so the point X of
-// the derivation above, which is inside the grown box by that margin, is between the computed planes on every axis and
-// its parameter inside [tn, tf].  Minimum and maximum drop NaN operands (a direction component of 0 against a plane
-// through the origin): that axis then does not constrain.
-RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far, float &t_near) {
-    const float x0 = __builtin_fmaf(A.x, R.inv.x, R.clo.x), x1 = __builtin_fmaf(B.x, R.inv.x, R.chi.x);
-    const float y0 = __builtin_fmaf(A.y, R.inv.y, R.clo.y), y1 = __builtin_fmaf(B.y, R.inv.y, R.chi.y);
-    const float z0 = __builtin_fmaf(A.z, R.inv.z, R.clo.z), z1 = __builtin_fmaf(B.z, R.inv.z, R.chi.z);
-    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -R.tback));
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
-    t_near = tn;                        // where the ray enters the grown box (an ordering hint, nothing more)
-    return tn > tf;
-}
-RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
-    float unused;
-    return bvh_misses(R, A, B, t_far, unused);
-}
-
-// ---- the walk over sibling pairs (rt_device.h BvhTables `pairs`), nearer child first ----
-// One step loads a pair (64 bytes), tests both boxes against the ray's stretch, goes on with the nearer of the
-// children that are hit and keeps the other on the lane's stack (16 bits per entry, [level][lane]); with neither hit
-// it takes the last kept one.  Which child comes first only decides how soon the bound shrinks: every sphere whose
-// chain of boxes the ray meets is still tested, so the result is the same set of candidates run through the same rule.
-// Shadow rays look for the LOWEST blocking scene index (that is what .cl:234-247 returns at): a subtree that only
-// holds higher indices than the best so far is skipped.  The walk's place (cur, sp) and its result so far (w_far,
-// w_idx, w_slot) are the caller's: `budget` pair steps at most per call, the rest next time.  At most `round_len`
-// pair steps are taken in a row before the leaf step of the lanes that hold a leaf -- a lane that is still looking
-// goes on looking in the next round instead of keeping the others waiting (the number of steps to the next leaf has
-// a long tail).  cen (census instances only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps.
-constexpr uint32_t kWalkDone = 0xffffffffu;
-RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
-                       uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
-                       int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen) {
-    const int lane_ = threadIdx.x & 63;
-    while (cur != kWalkDone && budget > 0) {
-        for (int round = round_len; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
-            budget -= 1;
-            if (cen) {
-                const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
-                if (lane_ == __ffsll((long long)act_) - 1) cen[0] += 1ull;
-                cen[1] += 1ull;
-            }
-            const float4 *pp = s_pairs + 4u * cur;
-            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
-            float tn0, tn1;
-            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
-            const bool m0 = out0 || (shadow && __float_as_uint(B0.w) > w_idx);
-            const bool m1 = out1 || (shadow && __float_as_uint(B1.w) > w_idx);
-            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
-            const bool both = !m0 & !m1, none = m0 & m1;
-            const bool second_first = both ? (tn1 < tn0) : m0;
-            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
-            if (both) {
-                my_stack[sp * stack_stride] = (uint16_t)far;
-                sp += 1;
-            }
-            if (none) {
-                sp -= 1;
-                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-                sp = sp < 0 ? 0 : sp;
-            } else {
-                cur = near;
-            }
-        }
-        if (cur != kWalkDone && cur >= kBvhLeafRef) {
-            if (cen) {
-                const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
-                if (lane_ == __ffsll((long long)act_) - 1) cen[2] += 1ull;
-                cen[3] += 1ull;
-            }
-            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-            HitPre p[kBvhLeaf];
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) {
-                if (p[k].det >= 0.f) {
-                    const HitRoots hr = hit_roots(p[k]);
-                    // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
-                    // shadow ray (.cl:234-247): the lowest scene index that blocks
-                    if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
-                        const uint32_t ix = index[sl + k];
-                        if (shadow) {
-                            w_idx = ix < w_idx ? ix : w_idx;
-                        } else if (hr.t < w_far || ix < w_idx) {
-                            w_far = hr.t;
-                            w_slot = sl + (uint32_t)k;
-                            w_idx = ix;
-                        }
-                    }
-                }
-            }
-            sp -= 1;
-            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-            sp = sp < 0 ? 0 : sp;
-        }
-    }
-}
-
-// closest hit among the spheres of the tree, .cl:215-232 restated: (t, idx) only ever moves to a smaller distance
-// or, at the same distance, to a lower scene index -- what the reference's `d < t` in index order ends with.
-RT_DEV void bvh_closest(const float4 *s_nodes, const float4 *s_slots, const uint32_t *s_index, uint32_t n_nodes,
-                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, float &t, uint32_t &slot, uint32_t &idx, BvhCount &cnt) {
-    uint32_t node = 0;
-    uint32_t guard = 2u * n_nodes + 8u;             // (a well-formed tree needs at most n_nodes trips)
-    while (node < n_nodes && guard != 0u) {
-        uint32_t leaf = 0xffffffffu;
-        bool more;
-        do {                                        // branch-free per step: one LDS round trip, selects
-            guard -= 1u;
-            RT_BVH_COUNT(cnt, 0);
-            const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
-            const uint32_t link = __float_as_uint(A.w);
-            const uint32_t next = max(link & 0xffffu, node + 1u);
-            const bool miss = bvh_misses(R, A, B, t);
-            const bool is_leaf = (link >> 16) != 0u;
-            const bool take = !miss & is_leaf;
-            leaf = take ? (link >> 16) - 1u : leaf;
-            node = (miss | is_leaf) ? next : node + 1u;
-            more = !take & (node < n_nodes) & (guard != 0u);
-        } while (more);
-        if (leaf != 0xffffffffu) {
-            RT_BVH_COUNT(cnt, 2);
-            const uint32_t s = n_always + (uint32_t)kBvhLeaf * leaf;
-            HitPre p[kBvhLeaf];
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[s + k], o, d);
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) {
-                if (p[k].det >= 0.f) {
-                    const HitRoots h = hit_roots(p[k]);
-                    if (h.hit && h.t <= t) {
-                        const uint32_t ix = s_index[s + k];
-                        if (h.t < t || ix < idx) {
-                            t = h.t;
-                            slot = s + (uint32_t)k;
-                            idx = ix;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// lowest scene index of a sphere of the tree that blocks the shadow ray (.cl:234-247 stops at the first blocker in
-// scene order), given the lowest one found so far (`first`, n = none): subtrees that only hold higher indices are skipped
-RT_DEV uint32_t bvh_any(const float4 *s_nodes, const float4 *s_slots, const uint32_t *s_index, uint32_t n_nodes,
-                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, float max_t, uint32_t first, BvhCount &cnt) {
-    uint32_t node = 0;
-    uint32_t guard = 2u * n_nodes + 8u;
-    while (node < n_nodes && guard != 0u) {
-        uint32_t leaf = 0xffffffffu;
-        bool more;
-        do {
-            guard -= 1u;
-            RT_BVH_COUNT(cnt, 0);
-            const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
-            const uint32_t link = __float_as_uint(A.w);
-            const uint32_t next = max(link & 0xffffu, node + 1u);
-            const bool outside = bvh_misses(R, A, B, max_t);
-            const bool miss = outside || __float_as_uint(B.w) > first;
-            const bool is_leaf = (link >> 16) != 0u;
-            const bool take = !miss & is_leaf;
-            leaf = take ? (link >> 16) - 1u : leaf;
-            node = (miss | is_leaf) ? next : node + 1u;
-            more = !take & (node < n_nodes) & (guard != 0u);
-        } while (more);
-        if (leaf != 0xffffffffu) {
-            RT_BVH_COUNT(cnt, 2);
-            const uint32_t s = n_always + (uint32_t)kBvhLeaf * leaf;
-            HitPre p[kBvhLeaf];
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[s + k], o, d);
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) {
-                if (p[k].det >= 0.f) {
-                    const HitRoots h = hit_roots(p[k]);
-                    if (h.hit && h.t < max_t) {
-                        const uint32_t ix = s_index[s + k];
-                        first = ix < first ? ix : first;
-                    }
-                }
-            }
-        }
-    }
-    return first;
-}
-#endif  // RT_OPT_BVH
 
 // .cl:34
 RT_DEV int to_int(float v) {
@@ -855,11 +464,8 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-#ifndef RT_OPT_MINWAVES
-#define RT_OPT_MINWAVES 1
-#endif
-#if RT_OPT_BVH >= 4
-#include "rt_walk.inc.h"       // large scenes: the walk as lane state (its own kernel body)
+#if RT_OPT_WALK
+#include "rt_walk.inc.h"       // large scenes: the walk of the hierarchy as lane state (its own kernel body)
 #else
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;      // (shadow the 4-wavefront constants of rt_device.h)
@@ -868,35 +474,15 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
-#if RT_OPT_BVH
-#if RT_OPT_COOP || RT_OPT_PERSIST
-#error "the hierarchy instances are plain (no cooperative any-hit, no persistent wavefronts)"
-#endif
-    // the blob of rt_device.h BvhTables, copied as it lies: hdr | nodes | slots | index
-    const uint32_t n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
-    float4 *s_hdr = lds;
-    float4 *s_nodes = s_hdr + 2;
-    float4 *s_slots = s_nodes + 2 * n_nodes;
-    uint32_t *s_index = reinterpret_cast<uint32_t *>(s_slots + n_slots);
-    const uint32_t blob_n = 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
-#if RT_OPT_BVH == 2
-    float4 *s_geom = lds + blob_n;           // check instance: the full table beside it
-    float4 *s_lightA = s_geom + n;
-#else
-    float4 *s_lightA = lds + blob_n;
-#endif
-#elif RT_OPT_GLOBAL_TABLES
+#if RT_OPT_GLOBAL_TABLES
     const float4 *s_geom = P.scene.geom;     // nothing staged but the reciprocals of the running average
     const float4 *s_lightA = P.scene.lightA;
-#else
-    float4 *s_geom = lds;
-    float4 *s_lightA = s_geom + n;           // {centre, radius}
-#endif
-#if RT_OPT_GLOBAL_TABLES
     const float4 *s_lightB = P.scene.lightB;
     float4 *s_emis = lds;                    // (never read: the host keeps mat_in_lds off)
     float4 *s_colr = lds;
 #else
+    float4 *s_geom = lds;
+    float4 *s_lightA = s_geom + n;           // {centre, radius}
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;             // {colour, radius}
@@ -912,13 +498,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     (void)s_tile_cost;
     if (tid < 5) s_stat[tid] = 0;
     if (tid == 5) s_tile_cost = 0u;
-#if RT_OPT_BVH
-    for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
-#endif
 #if !RT_OPT_GLOBAL_TABLES
-#if RT_OPT_BVH == 0 || RT_OPT_BVH == 2
     for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
-#endif
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
         s_lightA[i] = P.scene.lightA[i];
         s_lightB[i] = P.scene.lightB[i];
@@ -957,31 +538,15 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     int s = s_end;
     uint32_t cur_tile = 0, cur_used = 64;      // wave-uniform: current 8x8 tile, pixels handed out of it
     uint32_t c_samples = 0;
-    uint32_t dbg_trip = 0;
-    (void)dbg_trip;
 #else
     // which 32x8 tile this workgroup renders: its own index, or the next one of the heavy-first order
     const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
-#if RT_OPT_AB_OLD
-    const unsigned tile_id = block_linear;
-    (void)tile_id;
-    const int tile_bx = (int)blockIdx.x, tile_by = (int)blockIdx.y;
-#else
     const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;           // (wave-uniform: a scalar load)
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
     __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
     if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
-#endif
-#if RT_OPT_WAVE_TILE_W == 8
     const int x = tile_bx * kTileW + wave * 8 + (lane & 7);                 // 4 x 1 waves of 8x8
     const int lrow = tile_by * kTileH + (lane >> 3);
-#elif RT_OPT_WAVE_TILE_W == 16
-    const int x = tile_bx * kTileW + (wave & 1) * 16 + (lane & 15);         // 2 x 2 waves of 16x4
-    const int lrow = tile_by * kTileH + (wave >> 1) * 4 + (lane >> 4);
-#else
-    const int x = tile_bx * kTileW + (lane & 31);                           // 1 x 4 waves of 32x2
-    const int lrow = tile_by * kTileH + wave * 2 + (lane >> 5);
-#endif
     const int tile = lrow / P.tile_rows;
     const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
@@ -1018,11 +583,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     bool after_specular = true;
     bool need_ray = true;
 
-#if RT_OPT_BVH
-    BvhCount cnt_c{}, cnt_s{};                           // census instance only
-    (void)cnt_c;
-    (void)cnt_s;
-#endif
     unsigned long long st_roots_c = 0, st_roots_s = 0;   // wave-uniform; dead unless RT_OPT_STAMPS
     (void)st_roots_s;
 #if RT_OPT_COOP
@@ -1055,13 +615,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             const bool go = (__popcll(bw) >= P.regen_gate) || (ba == 0ull);
             const bool take = need_ray && go && s >= s_end;
             const unsigned long long F = __builtin_amdgcn_ballot_w64(take);
-#if RT_OPT_PERSIST == 2
-            dbg_trip += 1;
-            if (__builtin_amdgcn_ballot_w64(dbg_trip != (uint32_t)__builtin_amdgcn_readfirstlane((int)dbg_trip)) != 0ull)
-                atomicAdd(&P.counters[26], 1ull);        // lanes at different trip counts at the loop top
-            if (__builtin_amdgcn_ballot_w64(cur_used != (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_used)) != 0ull)
-                atomicAdd(&P.counters[27], 1ull);        // lanes disagree on the hand-out cursor
-#endif
             if (F != 0ull) {
                 if (take && has_pixel) {                                   // .cl:580-599 of the finished pixel
                     P.colors[3 * ci] = acc.x;
@@ -1074,9 +627,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     P.seeds[2 * gid + 1] = s1;
                     c_samples += (uint32_t)P.n_samples;
                     has_pixel = false;
-#if RT_OPT_PERSIST == 2
-                    atomicAdd(&P.counters[29], 1ull);   // debug: pixels finalized
-#endif
                 }
                 // hand out the next popcount(F) pixels of the wavefront's tile stream
                 const uint32_t n_take = (uint32_t)__popcll(F);
@@ -1114,9 +664,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                         if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
                         s = P.first_sample;
                         has_pixel = true;
-#if RT_OPT_PERSIST == 2
-                        atomicAdd(&P.counters[28], 1ull);   // debug: pixels handed out
-#endif
                     }
                 }
             }
@@ -1159,33 +706,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         uint32_t id = 0;
         RT_STAMP(1);
         st_roots_c = 0;
-#if RT_OPT_BVH
-        // the large spheres as before, then the tree; `slot` is where the winner's record lies, `id` its scene index
-        uint32_t slot = 0;
-        sweep_closest(s_slots, n_always, o, d, t, slot, st_roots_c);
-        id = (t < 1e20f) ? s_index[slot] : 0xffffffffu;
-        {
-            const BvhRay R = bvh_ray(s_hdr, o, d);
-            bvh_closest(s_nodes, s_slots, s_index, n_nodes, n_always, o, d, R, t, slot, id, cnt_c);
-        }
-#if RT_OPT_BVH == 2
-        {
-            float t_ref = 1e20f;
-            uint32_t id_ref = 0;
-            unsigned long long dummy = 0;
-            sweep_closest(s_geom, n, o, d, t_ref, id_ref, dummy);
-            atomicAdd(&P.counters[20], 1ull);
-            const bool hit_ref = t_ref < 1e20f, hit_bvh = t < 1e20f;
-            if (hit_ref != hit_bvh || (hit_ref && (__float_as_uint(t_ref) != __float_as_uint(t) || id_ref != id))) {
-                atomicAdd(&P.counters[21], 1ull);
-                P.counters[22] = ((unsigned long long)id << 32) | id_ref;
-                P.counters[23] = ((unsigned long long)__float_as_uint(t) << 32) | __float_as_uint(t_ref);
-            }
-        }
-#endif
-#else
         sweep_closest(s_geom, n, o, d, t, id, st_roots_c);
-#endif
         RT_STAMP_ROOTS(10, st_roots_c);
         c_closest += 1;
 
@@ -1199,11 +720,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             path_done = true;                                              // miss, .cl:327-330
         } else {
             RT_STAMP(2);
-#if RT_OPT_BVH
-            const float4 ge = s_slots[slot];
-#else
             const float4 ge = s_geom[id];
-#endif
             float4 em4, co4;
             if (P.mat_in_lds) {                 // wave-uniform: ds_read / global_load, not flat_load
                 em4 = s_emis[id];
@@ -1298,27 +815,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 c_shadow += 1;
                 RT_STAMP(4);
                 st_roots_s = 0;
-#if RT_OPT_BVH
-                const uint32_t first_large = sweep_any(s_slots, n_always, hp, sd, len - RT_EPS, st_roots_s);
-                uint32_t first = first_large < n_always ? s_index[first_large] : n;
-                {
-                    const BvhRay R = bvh_ray(s_hdr, hp, sd);
-                    first = bvh_any(s_nodes, s_slots, s_index, n_nodes, n_always, hp, sd, R, len - RT_EPS, first, cnt_s);
-                }
-#if RT_OPT_BVH == 2
-                {
-                    unsigned long long dummy = 0;
-                    const uint32_t first_ref = sweep_any(s_geom, n, hp, sd, len - RT_EPS, dummy);
-                    atomicAdd(&P.counters[24], 1ull);
-                    if (first_ref != first) {
-                        atomicAdd(&P.counters[25], 1ull);
-                        P.counters[26] = ((unsigned long long)first << 32) | first_ref;
-                    }
-                }
-#endif
-#else
                 const uint32_t first = sweep_any(s_geom, n, hp, sd, len - RT_EPS, st_roots_s);
-#endif
                 RT_STAMP_ROOTS(11, st_roots_s);
                 const bool blocked = first < n;
                 c_tests += blocked ? first + 1 : n;
@@ -1356,28 +853,19 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         } else if (is_gloss) {
             // reflection direction shared by SPEC and REFR, .cl:416-419 / 428-431
             RT_STAMP(7);
-#if RT_OPT_GLOSS_ID
             // n.d is the dp of the hit record; nl = n * m with m = -sign(dp), and for m = +-1 every
             // product and sum of (n.nl) and (d.nl) is the sign-flipped twin of the one in (n.n) and
             // (n.d) (rounding is sign-symmetric), so n.nl > 0 <=> dp < 0 and d.nl = m * dp = -|dp|.
             // dp = +-0 gives zeros of either sign, which the uses below do not tell apart; NaN stays NaN.
             const float n_dot_d = dp;
-#else
-            const float n_dot_d = dot(nrm, d);
-#endif
             V3 rfl = sub(d, scale(nrm, 2.f * n_dot_d));
             after_specular = true;
             if (refl == RT_SPEC) {                                         // .cl:413-424
                 thr = mul(thr, col);
                 d = rfl;
             } else {                                                       // .cl:425-489
-#if RT_OPT_GLOSS_ID
                 const bool into = dp < 0.f;
                 const float ddn = -fabsf(dp);
-#else
-                const bool into = dot(nrm, nl) > 0.f;
-                const float ddn = dot(d, nl);
-#endif
                 const float nc = 1.f, nt = 1.52f;
                 float nnt = into ? nc / nt : nt / nc;
                 float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
@@ -1430,14 +918,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // The arguments the epilogue needs are read from the kernel-argument segment AGAIN here (a fresh
     // scalar load behind an opaque pointer) instead of staying live in SGPRs through the loop: the loop
     // already fills the scalar file, and keeping them cost SGPR spills and with them a private segment.
-#if RT_OPT_AB_OLD
-    const LaunchParams &Q = P;
-#else
     const __attribute__((address_space(4))) LaunchParams *qp =
         (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("; epilogue arguments re-read" : "+s"(qp));
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
-#endif
     if (valid && Q.n_samples > 0) {
         int xe = x, ye = y, le = lrow;
         asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
@@ -1470,7 +954,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // one LDS add per wavefront, then one global add per workgroup into one of kStatReplicas
     // separate lines (162 000 same-address global atomics cost 1.8 ms per launch: one word takes
     // about 88 atomics per microsecond)
-#if !RT_OPT_PERSIST && !RT_OPT_AB_OLD
+#if !RT_OPT_PERSIST
     if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wave_t0[wave]));   // 10 ns ticks
 #endif
     if (lane == 0) {
@@ -1481,7 +965,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         atomicAdd(&s_stat[4], (unsigned long long)t_draws);
     }
     __syncthreads();
-#if !RT_OPT_PERSIST && !RT_OPT_AB_OLD
+#if !RT_OPT_PERSIST
     if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
 #endif
     if (tid < 5) {
@@ -1497,15 +981,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #if RT_OPT_STAMPS
     __syncthreads();
     if (tid < 12) atomicAdd(&P.counters[8 + tid], s_census[tid]);
-#endif
-#if RT_OPT_BVH == 3
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t a = wave_sum(cnt_c.v[k]), b = wave_sum(cnt_s.v[k]);
-        if (lane == 0) {
-            atomicAdd(&P.counters[20 + k], (unsigned long long)a);
-            atomicAdd(&P.counters[24 + k], (unsigned long long)b);
-        }
-    }
 #endif
 #if RT_OPT_TIMELOG
     {
@@ -1523,7 +998,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 #endif
 }
-#endif   // RT_OPT_BVH < 4
+#endif   // !RT_OPT_WALK
 
 #if !defined(RT_VARIANT_KERNEL)
 // The packed frame from the colour plane (.cl:34,594-596) with this mode's toInt, for frames whose

@@ -1,33 +1,181 @@
-// rt_walk.inc.h -- the path-trace kernel for large scenes (RT_OPT_BVH >= 4), included by rt_trace.inc.h in
-// place of its own kernel body; everything above it there (vector helpers, RNG, the sphere test, the sweeps,
-// sample_light, the hierarchy walk's ray set-up, slab test and pair walk) is shared.
+// rt_walk.inc.h -- the path-trace kernel for large scenes (RT_OPT_WALK), included by rt_trace.inc.h in place of its own
+// kernel body; everything above it there (vector helpers, RNG, the sphere test, the sweeps, sample_light) is shared.
 //
-// Same mapping (one lane = one pixel, the spp loop and the path state in registers), same arithmetic, same
-// order of random draws per pixel -- but the lanes of a wavefront are decoupled once more.  A census of the
-// walk-per-call form (RT_OPT_BVH 1: every lane walks the hierarchy to the end inside its closest-hit / shadow
-// call) showed 13 of 64 lanes busy per node step on closest-hit rays and 6 of 64 on shadow rays: the slowest of
-// a wavefront's rays takes five times the average, and everybody waits for it.  Here a ray's walk is lane state
-// (where it is in the tree, its stack, the bound, the best so far) that survives loop trips:
+// The small spheres hang in a bounding-volume hierarchy (rt_device.h BvhTables, built by rt_bvh.hip) that each lane walks
+// for its own ray; the few large ones are swept by every ray as before.  The hierarchy only selects candidates -- every
+// candidate goes through the reference's test, and the winner is chosen by the reference's rule -- so frames and counters
+// equal the plain sweep's.
 //
-//   T  every lane with a walk in flight takes up to P.walk_steps steps of it (walk_pairs in rt_trace.inc.h; closest-
-//      hit and shadow rays run the same loop, they differ in how a candidate updates the state);
+// Same mapping (one lane = one pixel, the spp loop and the path state in registers), same arithmetic, same order of random
+// draws per pixel -- but the lanes of a wavefront are decoupled once more: a ray's walk is lane state (where it is in the
+// tree, its stack, the bound, the best so far) that survives loop trips:
+//
+//   T  every lane with a walk in flight takes up to P.walk_steps steps of it (walk_pairs below; closest-hit and shadow
+//      rays run the same loop, they differ in how a candidate updates the state);
 //   S  lanes whose walk has ended (or that have no ray) do what comes next for them -- process the hit, sample
 //      the next light and start its shadow ray, add the light's contribution, bounce, finish the sample, start
 //      a camera ray -- once P.regen_gate of them are waiting or nobody is walking, and then join T again.
 //
 // Nothing here depends on which trip a lane does what: per pixel the sequence of operations and random draws is the
-// reference's.  What it buys and what is left (a third of the lane slots busy): DESIGN.md section 5.
-//
-// Forms: RT_OPT_BVH 6 = sibling pairs, nearer child first, a per-lane stack in LDS (shipped; with RT_OPT_GLOBAL_TABLES
-// the pairs and slots are read where they lie in HBM / L2); 4 = depth-first nodes with skip links (A/B); 5 / 7 = the
-// census instances of 4 / 6.
+// reference's.  RT_OPT_WALK 2 is the census instance of the diagnostics build (steps executed, lanes taking part, clock
+// shares: counters[20..28]); with RT_OPT_GLOBAL_TABLES the pairs and slots are read where they lie in HBM / L2.
+// Earlier forms (depth-first nodes with skip links, walked per call or as lane state) were measured and dropped:
+// DESIGN.md section 5 names the commits.
 
-#undef RT_OPT_WALK_PAIRS
-#undef RT_WALKING
-#undef RT_WALK_START
+// ---- walking the hierarchy ---------------------------------------------------------------------------
+// A sphere can only matter to a ray if the reference's test (hit_pre / hit_roots above, binary32, rounded after
+// every operation) returns a distance t for it, EPSILON < t <= t_max.  Where is X = o + t d then?  With op = fl(p - o),
+// OP = |op|, B = op.d exactly, b = B + db the computed dot product (|db| <= 3u OP, u = 2^-24), det = b^2 - OP^2 + r^2 + e
+// the computed discriminant (|e| <= 8u M^2, M^2 = OP^2 + r^2: one rounded square, a rounded three-term dot product,
+// the rounded r*r, two rounded sums), sq = sqrt(det)(1 + th), |th| <= u, and tau = b -+ sq before its own rounding:
+//     |X - p|^2 = tau^2 dd - 2 tau B + OP^2 = (sq^2 - b^2 + OP^2) + tau^2 (dd - 1) + 2 tau db
+//               = r^2 + e + 2 th det + tau^2 (dd - 1) + 2 tau db,      |tau| <= OP + |r|, tau^2 <= 2 M^2,
+// so |X - p|^2 <= r^2 + (19u + 2 |dd - 1|) M^2 <= r^2 + eps with eps := (64u + 4 |dd - 1|) M^2: X lies within
+// |r| + min(sqrt(eps), eps / 2|r|) of the centre -- inside the sphere's box grown by that `pad` -- at a ray parameter
+// in (0, t_max].  (The rounding of t itself and of p - o move X by at most 3u (OP + |o|); together with the slab
+// arithmetic's own rounding, bvh_misses below, that is an eighth of the linear term 64u (|o| + OP + |r|) of the pad.)  The walk therefore tests each node's box, grown by
+// `pad`, against the stretch [-pad, t_max + pad] of the ray, with OP bounded by the distance to the far side of the
+// root box and |r| by the largest radius in the tree; the slab arithmetic's own rounding is inside the pad's linear
+// term (bvh_misses below).  A lane whose direction is not a unit vector to within 10^-3, or not finite, gets an
+// infinite pad: it visits everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
+struct BvhRay {
+    V3 clo, chi, inv;      // 1 / direction and -(origin +- pad) / direction: a slab distance is one fused multiply-add
+    float tback;           // how far behind the origin / beyond the current best a box still counts
+};
+RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
+    const float4 h0 = s_hdr[0], h1 = s_hdr[1];
+    const float u = 0x1p-24f, inf = __builtin_inff();
+    const float dd = d.x * d.x + d.y * d.y + d.z * d.z;
+    const V3 oc = sub(mk(h0.x, h0.y, h0.z), o);
+    const float far = (__builtin_amdgcn_sqrtf(dot(oc, oc)) + h0.w) * 1.01f;     // >= |p - o| of every sphere in the tree
+    const float skew = fabsf(dd - 1.f);
+    const float eps = (64.f * u + 4.f * skew) * (far * far + h1.y * h1.y);
+    float pad = fminf(__builtin_amdgcn_sqrtf(eps), eps * h1.z);                 // sqrt(r^2 + eps) - r, from above
+    pad = pad * 1.01f + 64.f * u * (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far + h1.y);
+    float tback = pad + 1e-6f * far;
+    // (the products below must stay finite: origins and trees beyond 10^18 are walked in full as well)
+    const bool sane = (skew < 1e-3f) & (fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + far < 1e18f);    // false for NaN
+    pad = sane ? pad : inf;
+    tback = sane ? tback : inf;
+    BvhRay R;
+    // A direction component of (nearly) zero -- cosine-weighted bounces off an axis-aligned normal produce exact
+    // zeros a dozen times per frame -- is taken as +-10^-18: the ray then misses its true line by 10^-18 per unit of
+    // length, and 1 / d and the products with it stay finite (an infinite 1 / d would turn both slab distances of
+    // an axis into the same infinity, or into NaN, whichever side of the slab the origin is on).
+    const float tiny = 1e-18f;
+    R.inv = mk(__builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.x), tiny), d.x)),
+               __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.y), tiny), d.y)),
+               __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.z), tiny), d.z)));
+    R.clo = mk(-(o.x + pad) * R.inv.x, -(o.y + pad) * R.inv.y, -(o.z + pad) * R.inv.z);
+    R.chi = mk(-(o.x - pad) * R.inv.x, -(o.y - pad) * R.inv.y, -(o.z - pad) * R.inv.z);
+    R.tback = tback;
+    return R;
+}
+// True when the ray stretch [-tback, t_far + tback] misses the grown box for certain.  A slab distance is
+// fma(plane, 1/d, -(o +- pad)/d): the plane this computed distance really belongs to -- o +- pad + t d, exactly -- lies
+// within  4u |plane - o| + 2u |o|  of the box's (one ulp of v_rcp_f32, the rounded shifted origin, its rounded product,
+// the fused operation's own rounding), which the pad's linear term covers with the rest (above); so the point X of
+// the derivation above, which is inside the grown box by that margin, is between the computed planes on every axis and
+// its parameter inside [tn, tf].  Minimum and maximum drop NaN operands (a direction component of 0 against a plane
+// through the origin): that axis then does not constrain.
+RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far, float &t_near) {
+    const float x0 = __builtin_fmaf(A.x, R.inv.x, R.clo.x), x1 = __builtin_fmaf(B.x, R.inv.x, R.chi.x);
+    const float y0 = __builtin_fmaf(A.y, R.inv.y, R.clo.y), y1 = __builtin_fmaf(B.y, R.inv.y, R.chi.y);
+    const float z0 = __builtin_fmaf(A.z, R.inv.z, R.clo.z), z1 = __builtin_fmaf(B.z, R.inv.z, R.chi.z);
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -R.tback));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
+    t_near = tn;                        // where the ray enters the grown box (an ordering hint, nothing more)
+    return tn > tf;
+}
+RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
+    float unused;
+    return bvh_misses(R, A, B, t_far, unused);
+}
+
+// ---- the walk over sibling pairs (rt_device.h BvhTables `pairs`), nearer child first ----
+// One step loads a pair (64 bytes), tests both boxes against the ray's stretch, goes on with the nearer of the
+// children that are hit and keeps the other on the lane's stack (16 bits per entry, [level][lane]); with neither hit
+// it takes the last kept one.  Which child comes first only decides how soon the bound shrinks: every sphere whose
+// chain of boxes the ray meets is still tested, so the result is the same set of candidates run through the same rule.
+// Shadow rays look for the LOWEST blocking scene index (that is what .cl:234-247 returns at): a subtree that only
+// holds higher indices than the best so far is skipped.  The walk's place (cur, sp) and its result so far (w_far,
+// w_idx, w_slot) are the caller's: `budget` pair steps at most per call, the rest next time.  At most `round_len`
+// pair steps are taken in a row before the leaf step of the lanes that hold a leaf -- a lane that is still looking
+// goes on looking in the next round instead of keeping the others waiting (the number of steps to the next leaf has
+// a long tail).  cen (census instances only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps.
+constexpr uint32_t kWalkDone = 0xffffffffu;
+RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
+                       uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
+                       int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen) {
+    const int lane_ = threadIdx.x & 63;
+    while (cur != kWalkDone && budget > 0) {
+        for (int round = round_len; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
+            budget -= 1;
+            if (cen) {
+                const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
+                if (lane_ == __ffsll((long long)act_) - 1) cen[0] += 1ull;
+                cen[1] += 1ull;
+            }
+            const float4 *pp = s_pairs + 4u * cur;
+            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
+            float tn0, tn1;
+            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
+            const bool m0 = out0 || (shadow && __float_as_uint(B0.w) > w_idx);
+            const bool m1 = out1 || (shadow && __float_as_uint(B1.w) > w_idx);
+            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
+            const bool both = !m0 & !m1, none = m0 & m1;
+            const bool second_first = both ? (tn1 < tn0) : m0;
+            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
+            if (both) {
+                my_stack[sp * stack_stride] = (uint16_t)far;
+                sp += 1;
+            }
+            if (none) {
+                sp -= 1;
+                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+                sp = sp < 0 ? 0 : sp;
+            } else {
+                cur = near;
+            }
+        }
+        if (cur != kWalkDone && cur >= kBvhLeafRef) {
+            if (cen) {
+                const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
+                if (lane_ == __ffsll((long long)act_) - 1) cen[2] += 1ull;
+                cen[3] += 1ull;
+            }
+            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
+            HitPre p[kBvhLeaf];
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) {
+                if (p[k].det >= 0.f) {
+                    const HitRoots hr = hit_roots(p[k]);
+                    // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
+                    // shadow ray (.cl:234-247): the lowest scene index that blocks
+                    if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
+                        const uint32_t ix = index[sl + k];
+                        if (shadow) {
+                            w_idx = ix < w_idx ? ix : w_idx;
+                        } else if (hr.t < w_far || ix < w_idx) {
+                            w_far = hr.t;
+                            w_slot = sl + (uint32_t)k;
+                            w_idx = ix;
+                        }
+                    }
+                }
+            }
+            sp -= 1;
+            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+            sp = sp < 0 ? 0 : sp;
+        }
+    }
+}
+
+
 #undef RT_WALK_COUNT
 #undef RT_WALK_CLOCK
-#define RT_OPT_WALK_PAIRS (RT_OPT_BVH >= 6)
 
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
@@ -35,40 +183,28 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
-    const uint32_t n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
+    const uint32_t n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
     // (the scene index of a slot is only read for a candidate that passes the test: from HBM / L2, not staged)
-    const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + 2u + 2u * n_nodes + n_slots);
+    const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + bvh_index_at(n_slots));
     float4 *s_hdr = lds;
-#if RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES
-    // tables too large for LDS: pairs, slots and lights are read where they lie; staged: hdr | one stack per lane
     const uint32_t n_pairs = P.bvh.n_leaves - 1u;
-    const float4 *s_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
-    const float4 *s_slots = P.bvh.blob + 2u + 2u * n_nodes;
-    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_hdr + 2);
     const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
+    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
+    constexpr uint32_t kNone = kWalkDone;
+#if RT_OPT_GLOBAL_TABLES
+    // tables too large for LDS: pairs, slots and lights are read where they lie; staged: hdr | one stack per lane
+    const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
+    const float4 *s_slots = P.bvh.blob + bvh_slots_at();
+    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_hdr + 2);
     const float4 *s_lightA = P.scene.lightA, *s_lightB = P.scene.lightB;
     float4 *s_emis = s_hdr + 2 + stack_f4;        // (never read: the host keeps mat_in_lds off)
     float4 *s_colr = s_emis;
-    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
-    constexpr uint32_t kNone = kWalkDone;
-#elif RT_OPT_WALK_PAIRS
+#else
     // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane])
-    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     float4 *s_pairs = s_hdr + 2;
     float4 *s_slots = s_pairs + 4 * n_pairs;
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
-    const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
     float4 *s_lightA = s_slots + n_slots + stack_f4;     // {centre, radius}
-    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
-    constexpr uint32_t kNone = kWalkDone;
-#else
-    // staged: hdr | nodes | slots of rt_device.h BvhTables, as they lie
-    float4 *s_nodes = s_hdr + 2;
-    float4 *s_slots = s_nodes + 2 * n_nodes;
-    const uint32_t blob_n = 2u + 2u * n_nodes + n_slots;
-    float4 *s_lightA = lds + blob_n;              // {centre, radius}
-#endif
-#if !(RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES)
     float4 *s_lightB = s_lightA + n_lights;       // {emission, 4*pi*radius^2}
     float4 *s_emis = s_lightB + n_lights;         // {emission, bits(refl)}   (if mat_in_lds)
     float4 *s_colr = s_emis + n;                  // {colour, radius}
@@ -81,20 +217,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     __shared__ unsigned s_tile_cost;
     if (tid < 5) s_stat[tid] = 0;
     if (tid == 5) s_tile_cost = 0u;
-#if RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
-#elif RT_OPT_WALK_PAIRS
-    if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
+#if !RT_OPT_GLOBAL_TABLES
     {
-        const float4 *g_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
-        const float4 *g_slots = P.bvh.blob + 2u + 2u * n_nodes;
+        const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
+        const float4 *g_slots = P.bvh.blob + bvh_slots_at();
         for (uint32_t i = tid; i < 4u * n_pairs; i += kBlockThreads) s_pairs[i] = g_pairs[i];
         for (uint32_t i = tid; i < n_slots; i += kBlockThreads) s_slots[i] = g_slots[i];
     }
-#else
-    for (uint32_t i = tid; i < blob_n; i += kBlockThreads) lds[i] = P.bvh.blob[i];
-#endif
-#if !(RT_OPT_WALK_PAIRS && RT_OPT_GLOBAL_TABLES)
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
         s_lightA[i] = P.scene.lightA[i];
         s_lightB[i] = P.scene.lightB[i];
@@ -152,17 +282,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     int depth = 0;
     bool after_specular = true;
     // the walk: next node, distance bound, best sphere so far (scene index and slot)
-#if RT_OPT_WALK_PAIRS
     uint32_t cur = kNone;               // what the lane looks at next: a pair, kBvhLeafRef | leaf, or nothing (walk over)
     int sp = 0;                         // entries on its stack
     uint32_t w_idx = 0xffffffffu, w_slot = 0;
-#define RT_WALKING (cur != kNone)
-#define RT_WALK_START do { cur = root_ref; sp = 0; } while (0)
-#else
-    uint32_t node = n_nodes, w_idx = 0xffffffffu, w_slot = 0;
-#define RT_WALKING (node < n_nodes)
-#define RT_WALK_START do { node = 0; } while (0)
-#endif
     float w_far = 0.f;
     BvhRay R = bvh_ray(s_hdr, o, d);
     // a diffuse hit being lit: its normal, the light sum, the light in flight and what it adds if unblocked
@@ -170,9 +292,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     uint32_t lj = 0;
     float l_k = 0.f;
     unsigned long long unused_roots = 0;
-#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
+#if RT_OPT_WALK == 2
     // census instance: wave-level trips and lane participation of the two phases, and where the clock goes
-    unsigned long long cen[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // cen[0/1] pair steps (two box tests each) per wavefront / per lane, [2/3] leaf steps (kBvhLeaf sphere tests each),
+    // [4/5] shade phases, [6/7] clock ticks in the walk / in shading, [8] loop trips, [9] sphere tests of the always-list sweeps
+    unsigned long long cen[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #define RT_WALK_COUNT(k)                                                                         \
     do {                                                                                         \
         const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
@@ -192,16 +316,15 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
     for (;;) {
         if (st == kNew && s >= s_end) break;
-#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
+#if RT_OPT_WALK == 2
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
         const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
 #endif
 
         // ---- T: walk ----
-#if RT_OPT_WALK_PAIRS
-        // (walk_pairs in rt_trace.inc.h: up to P.walk_steps pair steps of this lane's walk, leaf steps in between)
+        // (walk_pairs above: up to P.walk_steps pair steps of this lane's walk, leaf steps in between)
         if (cur != kNone) {
-#if RT_OPT_BVH == 7
+#if RT_OPT_WALK == 2
             unsigned long long *cen_p = cen;
 #else
             unsigned long long *cen_p = nullptr;
@@ -209,63 +332,13 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             walk_pairs(s_pairs, s_slots, s_index, s_stack + tid, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_steps,
                        P.walk_round, cur, sp, w_far, w_idx, w_slot, cen_p);
         }
-#else
-        if (node < n_nodes) {
-            int budget = P.walk_steps;
-            const bool shadow = st == kShadow;
-            while (node < n_nodes && budget > 0) {
-                // node tests until a leaf's box is hit (branch-free per step: one LDS round trip, selects)
-                uint32_t leaf = 0xffffffffu;
-                bool more;
-                do {
-                    budget -= 1;
-                    RT_WALK_COUNT(0);
-                    const float4 A = s_nodes[2 * node], B = s_nodes[2 * node + 1];
-                    const uint32_t link = __float_as_uint(A.w);
-                    const uint32_t next = max(link & 0xffffu, node + 1u);          // (forward, whatever the table says)
-                    const bool prune = shadow & (__float_as_uint(B.w) > w_idx);     // only higher scene indices below
-                    const bool miss = prune | bvh_misses(R, A, B, w_far);
-                    const bool is_leaf = (link >> 16) != 0u;
-                    const bool take = !miss & is_leaf;
-                    leaf = take ? (link >> 16) - 1u : leaf;
-                    node = (miss | is_leaf) ? next : node + 1u;
-                    more = !take & (node < n_nodes) & (budget > 0);
-                } while (more);
-                if (leaf != 0xffffffffu) {
-                    RT_WALK_COUNT(2);
-                    const uint32_t sl = n_always + (uint32_t)kBvhLeaf * leaf;
-                    HitPre p[kBvhLeaf];
-#pragma unroll
-                    for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
-#pragma unroll
-                    for (int k = 0; k < kBvhLeaf; ++k) {
-                        if (p[k].det >= 0.f) {
-                            const HitRoots hr = hit_roots(p[k]);
-                            // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
-                            // shadow ray (.cl:234-247): the lowest scene index that blocks
-                            if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
-                                const uint32_t ix = s_index[sl + k];
-                                if (shadow) {
-                                    w_idx = ix < w_idx ? ix : w_idx;
-                                } else if (hr.t < w_far || ix < w_idx) {
-                                    w_far = hr.t;
-                                    w_slot = sl + (uint32_t)k;
-                                    w_idx = ix;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-#endif
 
-#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
+#if RT_OPT_WALK == 2
         RT_WALK_CLOCK(6, t_trip);
         const unsigned long long t_s = __builtin_amdgcn_s_memtime();
 #endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
-        const bool ready = !RT_WALKING;
+        const bool ready = cur == kNone;
         const unsigned long long br = __builtin_amdgcn_ballot_w64(ready);
         const unsigned long long bw = __builtin_amdgcn_ballot_w64(!ready);
         const bool go = (__popcll(br) >= P.regen_gate) || (bw == 0ull);
@@ -396,8 +469,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     w_far = len - RT_EPS;
                     const uint32_t first_large = sweep_any(s_slots, n_always, o, d, w_far, unused_roots);
                     w_idx = first_large < n_always ? s_index[first_large] : n;
+#if RT_OPT_WALK == 2
+                    cen[9] += first_large < n_always ? first_large + 1u : n_always;
+#endif
                     R = bvh_ray(s_hdr, o, d);
-                    RT_WALK_START;
+                    cur = root_ref;
+                    sp = 0;
                     st = kShadow;
                 }
             }
@@ -436,20 +513,24 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 float t = 1e20f;
                 uint32_t slot = 0;
                 sweep_closest(s_slots, n_always, o, d, t, slot, unused_roots);
+#if RT_OPT_WALK == 2
+                cen[9] += n_always;
+#endif
                 w_far = t;
                 w_slot = slot;
                 w_idx = (t < 1e20f) ? s_index[slot] : 0xffffffffu;
                 R = bvh_ray(s_hdr, o, d);
-                RT_WALK_START;
+                cur = root_ref;
+                sp = 0;
                 st = kClosest;
             }
         }
-#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
+#if RT_OPT_WALK == 2
         RT_WALK_CLOCK(7, t_s);
 #endif
     }
-#if RT_OPT_BVH == 5 || RT_OPT_BVH == 7
-    for (int k = 0; k < 9; ++k) {
+#if RT_OPT_WALK == 2
+    for (int k = 0; k < 10; ++k) {
         unsigned long long v = cen[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -497,7 +578,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
 
-#if RT_OPT_BVH == 6 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
+#if RT_OPT_WALK == 1 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
 // Diagnostics (rt_debug_walk_rays): arbitrary rays through the walk AND through the plain sweep over the full table,
 // one lane per ray -- the unit test of the one-sided culling with rays a path tracer produces once in 10^8 (exact
 // zeros and denormals in the direction, origins on box planes, far away, non-unit and non-finite directions).
@@ -508,8 +589,8 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
                                                                             uint4 *out) {
     constexpr int kThreads = 256;
     extern __shared__ float4 lds[];
-    const uint32_t n = P.scene.n_spheres, n_nodes = P.bvh.n_nodes, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
-    const uint32_t *g_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + 2u + 2u * n_nodes + n_slots);
+    const uint32_t n = P.scene.n_spheres, n_always = P.bvh.n_always, n_slots = P.bvh.n_slots;
+    const uint32_t *g_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + bvh_index_at(n_slots));
     float4 *s_hdr = lds;
     const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     float4 *s_pairs = s_hdr + 2;
@@ -519,8 +600,8 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
     const int tid = threadIdx.x;
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
     {
-        const float4 *g_pairs = P.bvh.blob + 2u + 2u * n_nodes + n_slots + (n_slots + 3u) / 4u;
-        const float4 *g_slots = P.bvh.blob + 2u + 2u * n_nodes;
+        const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
+        const float4 *g_slots = P.bvh.blob + bvh_slots_at();
         for (uint32_t i = tid; i < 4u * n_pairs; i += kThreads) s_pairs[i] = g_pairs[i];
         for (uint32_t i = tid; i < n_slots; i += kThreads) s_slots[i] = g_slots[i];
     }

@@ -85,6 +85,12 @@ def test_argument_validation_needs_no_device():
     assert lib.rt_create_multi(C.byref(h), 16, 16, 65) == -1
     assert lib.rt_create_multi_on(C.byref(h), 0, 16, (C.c_int * 1)(0), 1, 8) == -1
     assert lib.rt_create_multi_on(C.byref(h), 16, 16, None, 1, 8) == -1
+    # the device list of a multi-device context: all different, or one device n times (the rehearsal) -- never mixed
+    assert lib.rt_create_multi_on(C.byref(h), 16, 16, (C.c_int * 3)(0, 1, 0), 3, 8) == -1 and b"mixed" in lib.rt_last_error()
+    assert lib.rt_create_multi_on(C.byref(h), 16, 16, (C.c_int * 4)(2, 2, 3, 3), 4, 8) == -1
+    assert lib.rt_create_multi_on(C.byref(h), 16, 16, (C.c_int * 2)(0, -1), 2, 8) == -1
+    assert lib.rt_create_multi_on(C.byref(h), 16, 16, (C.c_int * 2)(0, 0), 2, 12) == -1 and b"tile_rows" in lib.rt_last_error()
+    assert lib.rt_throttle(None, 0, None) == -1 and lib.rt_read_pixels_async(None, None, None) == -1
     assert lib.rt_shard_count(None) == -1
     assert lib.rt_update_spheres_async(None, 0, 0, None, None) == -1
     assert lib.rt_read_pixels(None, None) == -1

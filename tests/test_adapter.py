@@ -18,6 +18,35 @@ def test_adapter_compiles_against_reference_headers():
                    check=True)
 
 
+REF_CONFIG_CPP = "/root/reference/SimpleRT/src/Config.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CONFIG_CPP), reason="needs the reference checkout (build container)")
+def test_factory_patch_applies_to_the_reference_and_compiles(tmp_path):
+    """adapter/reference_factory.patch is the edit INTEGRATION.md section 2a asks a maintainer to make
+    (SimpleRT/src/Config.cpp:13-68: the include and the `SupportType::Default` case).  Applied to a scratch copy of the
+    reference's file it must apply cleanly and compile with -DENABLE_HIP alone (neither OpenCL nor Cm enabled) against
+    the reference's headers and the adapter; without -DENABLE_HIP the patched file is the reference's translation unit
+    again (it compiles as before, given the two headers the OpenCL / Cm backends otherwise bring in).  oracle/Makefile
+    `refhost` links the same patched copy into oracle/_ref/ref_host_hip, whose main() goes through
+    createConfig(w, h, selectType(2), ...) -- the GPU tests below run it."""
+    work = tmp_path / "Config.cpp"
+    work.write_bytes(open(REF_CONFIG_CPP, "rb").read())
+    patch = os.path.join(ROOT, "adapter", "reference_factory.patch")
+    res = subprocess.run(["patch", "--fuzz=0", str(work)], stdin=open(patch), capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    text = work.read_text()
+    assert "make_unique<HipConfig>" in text and "SupportType::Default" in text
+    inc = ["-I" + REF_INC, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "adapter")]
+    subprocess.run(["g++", "-std=c++14", "-Wall", "-DENABLE_HIP", "-c", str(work), "-o", str(tmp_path / "with.o")] + inc, check=True)
+    subprocess.run(["g++", "-std=c++14", "-include", "stdexcept", "-include", "memory", "-c", str(work), "-o", str(tmp_path / "without.o")] + inc, check=True)
+    syms = subprocess.run(["nm", "-C", str(tmp_path / "with.o")], capture_output=True, text=True, check=True).stdout
+    assert "HipConfig::HipConfig(int, int)" in syms            # the factory constructs the backend
+    assert "HipConfig" not in subprocess.run(["nm", "-C", str(tmp_path / "without.o")], capture_output=True, text=True, check=True).stdout
+    main_src = open(os.path.join(ROOT, "oracle", "ref_host_main.cpp")).read()
+    assert "createConfig(w, h, selectType(2), true, MemType::Buffer)" in main_src and "make_unique<HipConfig>" not in main_src
+
+
 def test_rt_api_header_is_plain_c(tmp_path):
     src = tmp_path / "c_abi.c"
     src.write_text('#include "rt_api.h"\n'
@@ -217,6 +246,40 @@ def test_reference_host_code_drives_the_hip_backend(tmp_path, golden_dir):
     both = O.render(sph, O.camera((25.0, 103.0, 116.0), (0.0, 25.0, 0.0), w, h), w, h, passes - k, first_sample=k,
                     seeds_in=first["seeds"], colors_in=first["colors"])
     assert np.array_equal(frame(out, w, h), rgb(both["pixels"], w, h))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_HOST), reason="oracle/_ref/ref_host_hip is built in the container (make -C oracle refhost)")
+def test_reference_caption_is_true_under_the_adapter(tmp_path):
+    """The reference's only metric: Config::updateRendering (Config.cpp:73-91, not virtual) times execute() and writes
+    W*H / elapsed into the window caption as "Sample/sec".  The adapter launches passes in batches, so execute() paces
+    itself to the device (adapter/HipConfig.cpp): over 400 passes of the Demo scene at the default display cadence the
+    caption's rate must be the true rate -- samples rendered over wall time, the final drain included -- within a factor
+    of two for most passes and in the median, and the frame must still be the oracle's.  (Before: a counted pass
+    returned in a microsecond and the caption showed 10^9 K samples/s, the due pass a tenth of the true rate.)"""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    w, h, passes = 640, 360, 400
+    log = tmp_path / "captions.txt"
+    out = tmp_path / "f.ppm"
+    res = subprocess.run([REF_HOST, str(passes), str(w), str(h), str(out)], env=dict(os.environ, RT_TEST_CAPTION_LOG=str(log)),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    lines = log.read_text().splitlines()
+    true_rate = float(lines[-1].split()[1])
+    rates = np.array([float(re.search(r"Sample/sec\s+([0-9.eE+inf]+)K", ln).group(1)) * 1000.0 for ln in lines[:-1]])
+    assert len(rates) == passes and [int(re.search(r"pass (\d+)", ln).group(1)) for ln in lines[:-1]] == list(range(1, passes + 1))
+    steady = rates[40:]                                           # (the first passes include the backend's first launches)
+    ratio = steady / true_rate
+    assert 0.5 <= np.median(ratio) <= 2.0, (np.median(ratio), true_rate)
+    assert np.mean((ratio >= 0.5) & (ratio <= 2.0)) >= 0.8, np.percentile(ratio, [5, 25, 50, 75, 95])
+    raw = open(out, "rb").read()
+    head = b"P6\n%d %d\n255\n" % (w, h)
+    got = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)[::-1]
+    want = O.render(O.demo_spheres(), O.camera((20.0, 100.0, 120.0), (0.0, 25.0, 0.0), w, h), w, h, passes)
+    assert np.array_equal(got, np.ascontiguousarray(want["pixels"], dtype=np.uint32).view(np.uint8).reshape(h, w, 4)[:, :, :3])
 
 
 @pytest.mark.gpu

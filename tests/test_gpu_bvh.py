@@ -17,7 +17,7 @@ import bvh_check  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _render(sph, cam, w, h, spp, bvh_min=1, form=3, mode=api.RT_MODE_PARITY, passes=None):
+def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None):
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
@@ -62,22 +62,24 @@ def test_device_built_tables_are_a_valid_hierarchy(maker):
     (lambda: scenes.mirror_box(200), 48, 48, 3),
     (lambda: scenes.demo_plus(16), 96, 64, 4),
 ])
-def test_every_form_of_the_walk_equals_the_oracle(maker, w, h, spp):
-    """1 = walk per call, 2 = depth-first nodes as lane state, 3 = sibling pairs, nearer child first (the shipped form)"""
+def test_the_walk_equals_the_oracle(maker, w, h, spp):
+    """the hierarchy forced on scenes of every kind (open, boxed, too small to get one by default): frames, colour plane,
+    seeds and counters are the oracle's"""
     sph, orig, target = maker()
     cam = host.compute_camera(orig, target, w, h)
     want = O.render(sph, cam, w, h, spp)
-    for form in (1, 2, 3):
-        _same(_render(sph, cam, w, h, spp, form=form), want)
+    got = _render(sph, cam, w, h, spp)
+    _same(got, want)
 
 
 def test_walk_and_plain_sweep_agree_ray_by_ray():
-    """The check instance runs the plain sweep beside the walk for every ray and counts disagreements
-    (closest hit: distance bits and sphere index; shadow rays: first blocking index)."""
-    for maker, (w, h, spp) in ((lambda: scenes.random_spheres(1024), (128, 72, 3)), (lambda: scenes.mirror_box(96), (96, 64, 4))):
+    """Rays of the scene itself (camera rays, bounce rays off the spheres, rays towards the lights) through the walk and
+    through the plain sweep, one lane per ray: closest hit -- distance bits and sphere index; shadow rays -- first
+    blocking index."""
+    for maker, (w, h) in ((lambda: scenes.random_spheres(1024), (128, 72)), (lambda: scenes.mirror_box(96), (96, 64))):
         sph, orig, target = maker()
-        r = bvh_check.agreement(sph, host.compute_camera(orig, target, w, h), w, h, spp)
-        assert r is not None and r["closest_rays"] > 0 and r["shadow_rays"] > 0
+        r = bvh_check.agreement(sph, host.compute_camera(orig, target, w, h), w, h)
+        assert r is not None and r["closest_hits"] > 10000 and r["shadow_blocked"] > 1000, r
         assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
 
 
@@ -114,9 +116,8 @@ def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
     w, h, spp = 72, 48, 3
     cam = host.compute_camera(orig, target, w, h)
     want = O.render(sph, cam, w, h, spp)
-    _same(_render(sph, cam, w, h, spp, form=2), want)
-    _same(_render(sph, cam, w, h, spp, form=3), want)
-    r = bvh_check.agreement(sph, cam, w, h, spp)
+    _same(_render(sph, cam, w, h, spp), want)
+    r = bvh_check.agreement(sph, cam, w, h, 60000)
     assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
 
 
@@ -130,8 +131,8 @@ def test_measured_choice_changes_no_bit_and_probes_split_a_blocking_call():
     one = _render(sph, cam, w, h, spp, bvh_min=64, form=0)
     _same(one, want)
     assert one["pick"] in (1, 2)                     # a blocking call of >= 16 passes waits for the verdict
-    assert one["stats"]["launches"] == 3             # probe, probe, the rest
-    many = _render(sph, cam, w, h, spp, bvh_min=64, form=0, passes=[1, 1, 5, 13])
+    assert one["stats"]["launches"] == 5             # each form warm and timed, then the rest
+    many = _render(sph, cam, w, h, spp, bvh_min=64, form=0, passes=[1, 1, 2, 3, 13])
     _same(many, want)
     small = _render(*((lambda s: (s[0], host.compute_camera(s[1], s[2], w, h)))(scenes.demo_plus(16))), w, h, 4, bvh_min=64, form=0)
     assert small["pick"] == 0 and small["stats"]["launches"] == 1      # no hierarchy below bvh_min: nothing to measure
@@ -152,7 +153,7 @@ def test_moving_spheres_rebuild_the_hierarchy_on_the_stream():
     cam = host.compute_camera(orig, target, w, h)
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
-        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 3))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         for step in range(3):
@@ -173,14 +174,13 @@ def test_fast_mode_with_the_hierarchy_is_as_close_as_fast_mode_without():
     sph, orig, target = scenes.random_spheres(400)
     w, h, spp = 160, 96, 16
     cam = host.compute_camera(orig, target, w, h)
-    par = _render(sph, cam, w, h, spp, form=3)
+    par = _render(sph, cam, w, h, spp)
     plain = _render(sph, cam, w, h, spp, bvh_min=0, mode=api.RT_MODE_FAST)
     base = host.psnr(plain["pixels"], par["pixels"])
     assert base >= 30.0
-    for form in (1, 2, 3):
-        fast = _render(sph, cam, w, h, spp, form=form, mode=api.RT_MODE_FAST)
-        assert fast["stats"]["samples"] == par["stats"]["samples"]
-        assert host.psnr(fast["pixels"], par["pixels"]) >= min(50.0, base - 3.0)
+    fast = _render(sph, cam, w, h, spp, mode=api.RT_MODE_FAST)
+    assert fast["stats"]["samples"] == par["stats"]["samples"]
+    assert host.psnr(fast["pixels"], par["pixels"]) >= min(50.0, base - 3.0)
 
 
 def test_last_kernel_names_the_instance_the_scene_got():
@@ -204,9 +204,13 @@ def test_last_kernel_names_the_instance_the_scene_got():
         ctx.set_scene(sph)
         ctx.set_camera(host.compute_camera(orig, target, w, h))
         ctx.reset()
-        ctx.render_pass(1)                    # the first pass of a new large scene walks the hierarchy,
+        ctx.render_pass(1)                    # the first two launches of a new large scene walk the hierarchy (warm, timed),
         assert ctx.last_kernel == "rt_trace_parity_pairs"
-        ctx.render_pass(1)                    # the second sweeps; the faster form renders the rest
+        ctx.render_pass(1)
+        assert ctx.last_kernel == "rt_trace_parity_pairs"
+        ctx.render_pass(1)                    # the next two sweep; the faster form renders the rest
+        assert ctx.last_kernel == "rt_trace_parity_coop"
+        ctx.render_pass(1)
         assert ctx.last_kernel == "rt_trace_parity_coop"
         assert ctx.scene_choice()["picked"] in (None, "hierarchy", "sweep")   # (asked without blocking: may still be open)
         ctx.render_pass(40)
@@ -217,7 +221,8 @@ def test_last_kernel_names_the_instance_the_scene_got():
 
 
 def test_multi_device_context_with_a_large_scene():
-    """Every shard builds its own hierarchy and measures its own choice; the assembled frames are the oracle's."""
+    """Every shard builds its own hierarchy; the FIRST shard measures hierarchy against sweep and the others follow its
+    verdict, so one kernel instance renders the whole frame; the assembled frames are the oracle's."""
     sph, orig, target = scenes.random_spheres(300)
     w, h = 96, 72
     cam = host.compute_camera(orig, target, w, h)
@@ -225,7 +230,7 @@ def test_multi_device_context_with_a_large_scene():
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         done = 0
-        for n in (1, 1, 2, 20):                  # the first two passes are the shards' probes
+        for n in (1, 1, 2, 1, 20):               # the first four launches are the first shard's probes
             px = ctx.render_pass(n)
             done += n
             want = O.render(sph, cam, w, h, done)
@@ -346,7 +351,7 @@ def test_scenes_beyond_lds(n):
         assert ctx.last_kernel == "rt_trace_parity_pairs_g"
         _same(got, want)
         b = bvh_check.read_bvh(ctx)
-        assert bvh_check.check_structure(api.as_spheres(sph), b, dfs=n <= 8192) == []   # (host-built trees leave the depth-first nodes out)
+        assert bvh_check.check_structure(api.as_spheres(sph), b) == []
         # the plain sweep over the table in HBM / L2 (what a scene without a hierarchy gets)
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
         ctx.reset()

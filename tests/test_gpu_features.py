@@ -357,3 +357,112 @@ def test_convergence_tool_checkpoints_are_the_oracles_frames_and_converge(tmp_pa
         rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3)[::-1]
         want = O.render(sph, cam, w, h, spp)["pixels"].view(np.uint8).reshape(h, w, 4)[:, :, :3]
         assert np.array_equal(rgb, want), spp
+
+
+
+def test_one_kernel_instance_renders_every_shard():
+    """ONE decision per multi-device context: the first shard measures hierarchy against plain sweep, the others launch
+    the form it launched -- during the probes and after the verdict -- so rt_last_kernel is true for the whole frame
+    (a 64-sphere scene sits at the crossover, where shards deciding for themselves would disagree)."""
+    sph, orig, target = scenes.random_spheres(64)
+    w, h = 128, 96
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h, devices=[0, 0, 0], diag=True) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        done = 0
+        seen = []
+        for n in (1, 2, 1, 2, 3, 24, 7):
+            px = ctx.render_pass(n)
+            done += n
+            kernels = [ctx._lib.rt_debug_shard_kernel(ctx._h, r).decode() for r in range(3)]
+            assert len(set(kernels)) == 1 and kernels[0] == ctx.last_kernel, kernels
+            seen.append(kernels[0])
+            assert np.array_equal(px, O.render(sph, cam, w, h, done)["pixels"])
+        sweep = "rt_trace_parity_coop_w1"                                      # 64 spheres: small tables, single-wavefront workgroups
+        assert seen[:2] == ["rt_trace_parity_pairs"] * 2 and seen[2:4] == [sweep] * 2      # warm + timed, each form
+        ch = ctx.scene_choice()
+        assert ch["picked"] in ("hierarchy", "sweep")
+        assert seen[-1] == ("rt_trace_parity_pairs" if ch["picked"] == "hierarchy" else sweep)
+        st = ctx.stats()
+        want = O.render(sph, cam, w, h, done)
+        assert (st["samples"], st["sphere_tests"], st["rng_draws"]) == (want["stats"]["samples"], want["stats"]["sphere_tests"], want["stats"]["rng_draws"])
+
+
+def test_asynchronous_frames_through_the_rehearsal_gather_are_not_torn():
+    """rt_render_async on a multi-device context with pixel stores on: frame k's rows are copied out of a shard's pixel
+    buffer on the ROOT's stream, so the shard's frame k+1 must wait for that copy (a write-after-read hazard
+    on the non-blocking path).  40 progressive launches without a reset in between, the assembled frame read at the end
+    and at checkpoints, on a size whose frame takes long enough to copy."""
+    sph, orig, target = scenes.demo_plus(16)
+    w, h = 1024, 768
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h, devices=[0, 0]) as ctx:
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        done = 0
+        for k in range(40):
+            ctx.render_async(1)
+            done += 1
+            if k in (0, 17, 39):
+                assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, done)["pixels"]), k
+
+
+def test_a_failed_gather_leaves_the_context_in_a_defined_error_state():
+    """An RCCL failure inside the gather's group (or at ncclGroupEnd) must not leave later calls queueing behind a
+    communicator in an unknown state: the context is marked unusable, every later call is refused with RT_ERR_STATE and
+    the failure's name, and rt_destroy still works.  The failure is injected (rt_debug_break_gather)."""
+    sph, orig, target = scenes.demo_plus(16)
+    w, h = 96, 64
+    cam = host.compute_camera(orig, target, w, h)
+    ctx = api.RtContext(w, h, devices=[0, 0], diag=True)
+    ctx.set_scene(sph)
+    ctx.set_camera(cam)
+    assert np.array_equal(ctx.render_pass(2), O.render(sph, cam, w, h, 2)["pixels"])
+    assert ctx._lib.rt_debug_break_gather(ctx._h) == -3                       # RT_ERR_HIP: what the failing gather itself returns
+    for call in (lambda: ctx.render_pass(1), lambda: ctx.render_async(1), lambda: ctx.read_pixels(), lambda: ctx.set_scene(sph),
+                 lambda: ctx.set_camera(cam), lambda: ctx.reset(), lambda: ctx.set_mode(api.RT_MODE_FAST)):
+        with pytest.raises(api.RtError) as e:
+            call()
+        assert e.value.code == -5 and "unusable" in str(e.value) and "ncclGroupEnd" in str(e.value)
+    ctx.close()
+    with api.RtContext(w, h, devices=[0, 0]) as again:                          # a new context is unaffected
+        again.set_scene(sph)
+        again.set_camera(cam)
+        assert np.array_equal(again.render_pass(2), O.render(sph, cam, w, h, 2)["pixels"])
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="the RCCL send / receive across distinct devices needs at least two GPUs")
+def test_multi_device_context_on_distinct_devices_equals_the_one_device_frame():
+    """The REAL n > 1 path (ncclCommInitAll over distinct devices, the grouped ncclSend / ncclRecv, the de-interleave on
+    the root): never run so far -- every box this suite has seen had one GPU.  On a multi-GPU node the frame, the
+    colour plane, the seeds and the counters must equal the one-device context's and the oracle's."""
+    n = min(_device_count(), 8)
+    sph, orig, target = scenes.demo_plus(16)
+    w, h, spp = 320, 200, 6
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    for devices in ([0, 1], list(range(n))):
+        with api.RtContext(w, h, devices=devices) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+            ctx.reset()
+            for _ in range(spp):
+                ctx.render_async(1)
+            assert np.array_equal(ctx.read_pixels(), want["pixels"])
+        with api.RtContext(w, h, devices=devices[::-1]) as ctx:                 # the root need not be device 0
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            assert np.array_equal(ctx.render_pass(spp), want["pixels"])
+
+
+def test_mixed_device_lists_are_refused():
+    with pytest.raises(api.RtError) as e:
+        api.RtContext(64, 48, devices=[0, 1, 0])
+    assert e.value.code == -1 and "mixed" in str(e.value)

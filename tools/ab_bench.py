@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """In-process A/B of kernel instances (guide rule 24: interleaved rounds in ONE process).
 
-    python tools/ab_bench.py [--configs c2,c3,c5,c16] [--modes 0,100,101,...] [--rounds 5]
+    python tools/ab_bench.py [--configs c2,c3,c5,c16] [--modes 0,1,rt_trace_parity_persist,...] [--rounds 5]
 
-Each mode renders the same frame; parity-arithmetic instances (0, 100+k) must produce the same
-pixels as mode 0, fast ones (1, 200+k) are reported with their PSNR against mode 0."""
+Each mode renders the same frame (0 / 1 = what the library picks in parity / fast mode; a kernel symbol = that
+instance of the diagnostics library); parity-arithmetic instances must produce the same pixels as mode 0, fast ones
+are reported with their PSNR against mode 0."""
 import argparse
 import json
 import os
@@ -44,7 +45,7 @@ def main():
     ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
     ap.add_argument("--orders", default="", help="comma list of 0/1: natural tile order / heavy tiles first")
     args = ap.parse_args()
-    modes = [int(m) for m in args.modes.split(",")]
+    modes = [int(m) if m.lstrip("-").isdigit() else api.instance_mode(m) for m in args.modes.split(",")]
     gates = [int(g) for g in args.gates.split(",")] if args.gates else [None]
     persists = [int(g) for g in args.persist.split(",")] if args.persist else [None]
     orders = [int(g) for g in args.orders.split(",")] if args.orders else [None]

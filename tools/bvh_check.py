@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
-"""The hierarchy of large scenes (csrc/rt_device.h BvhTables), checked three ways on the GPU:
+"""The hierarchy of large scenes (csrc/rt_device.h BvhTables), checked on the GPU:
 
-  structure   the tables the device built, read back and walked on the host: every node's skip link
-              points forward, the leaves hold every tree sphere exactly once, every sphere lies inside
-              the boxes of its leaf and of all its ancestors, every node knows the lowest scene index
-              below it, the always list keeps scene order
-  agreement   the check instance (mode 113) renders with the walk AND the plain sweep per ray and counts
-              the rays on which they differ (closest hit: distance bits and sphere; shadow: first blocker)
+  structure   the tables the device (or, beyond 8192 tree spheres, the host) built, read back and walked on the host:
+              from the root pair every leaf is reached exactly once, the leaves hold every tree sphere exactly once,
+              every sphere lies inside the boxes of its leaf and of all its ancestors, every child knows the lowest
+              scene index below it, the always list keeps scene order
+  rays        rays through the walk AND the plain sweep, one lane per ray (rt_debug_walk_rays): camera rays and bounce
+              rays of the scene itself here; tests/test_gpu_bvh.py adds the adversarial ones
   parity      the shipped instance against the oracle, and timing with the hierarchy on / off
+  census      what the walk executes (instance rt_trace_parity_pairs_census): pair steps, leaf steps, lanes taking part
 
-    python tools/bvh_check.py [--quick]
+    python tools/bvh_check.py [--quick] [--census] [--timing-only]
 """
 import argparse
 import ctypes as C
@@ -30,29 +31,24 @@ from raytracing_simple_amd import api, host, scenes  # noqa: E402
 def read_bvh(ctx):
     counts = (C.c_uint32 * 4)()
     ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, None, 0, counts))
-    n_always, n_leaves, n_nodes, n_slots = list(counts)
-    if n_nodes == 0:
+    n_always, n_leaves, depth, n_slots = list(counts)
+    if n_leaves == 0:
         return None
-    n4_nodes = 2 + 2 * n_nodes + n_slots + (n_slots + 3) // 4
-    n4 = n4_nodes + 4 * (n_leaves - 1)
+    at_index = 2 + n_slots
+    at_pairs = at_index + (n_slots + 3) // 4
+    n4 = at_pairs + 4 * (n_leaves - 1)
     blob = np.zeros(4 * n4, np.float32)
     ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, blob.ctypes.data_as(C.c_void_p), n4, counts))
     b4 = blob.reshape(n4, 4)
-    nodes = b4[2:2 + 2 * n_nodes]
-    slots = b4[2 + 2 * n_nodes:2 + 2 * n_nodes + n_slots]
-    index = blob[4 * (2 + 2 * n_nodes + n_slots):].view(np.uint32)[:n_slots]
-    pairs = b4[n4_nodes:]
-    return {"pairs": pairs, "hdr": b4[:2], "lo": nodes[0::2, :3], "hi": nodes[1::2, :3], "link": nodes[0::2, 3].view(np.uint32),
-            "low": nodes[1::2, 3].view(np.uint32), "slots": slots, "index": index, "n_always": n_always,
-            "n_leaves": n_leaves, "n_nodes": n_nodes, "n_slots": n_slots}
+    return {"hdr": b4[:2], "slots": b4[2:at_index], "index": blob[4 * at_index:].view(np.uint32)[:n_slots], "pairs": b4[at_pairs:],
+            "n_always": n_always, "n_leaves": n_leaves, "stack_depth": depth, "n_slots": n_slots}
 
 
-def check_structure(sph, b, dfs=True):
-    """Host-side walk of the tables the library built; returns a list of complaints (empty = fine).
-    dfs=False: skip the depth-first `nodes` section (trees built on the host leave it out)."""
+def check_structure(sph, b):
+    """Host-side walk of the tables the library built; returns a list of complaints (empty = fine)."""
     bad = []
     n = len(sph)
-    na, nn, nl = b["n_always"], b["n_nodes"], b["n_leaves"]
+    na, nl = b["n_always"], b["n_leaves"]
     leaf_size = (b["n_slots"] - na) // max(nl, 1)
     idx = b["index"]
     # always list: scene order, records equal
@@ -74,44 +70,7 @@ def check_structure(sph, b, dfs=True):
         want = np.array([p[ix, 0], p[ix, 1], p[ix, 2], np.float32(rad[ix]) * np.float32(rad[ix])], np.float32)
         if not np.array_equal(want.view(np.uint32), b["slots"][j].view(np.uint32)):
             bad.append(f"slot {j} != record {ix}")
-    if dfs:
-        skip = b["link"] & 0xffff
-        leaf = (b["link"] >> 16).astype(np.int64) - 1
-        if not np.all(skip > np.arange(nn)):
-            bad.append("a skip link does not point forward")
-        if np.any(skip > nn):
-            bad.append("a skip link points past the end")
-        if sorted(leaf[leaf >= 0]) != list(range(nl)):
-            bad.append("leaf numbers are not 0..n_leaves-1, each once")
-        # subtree of node k = [k, skip[k]); every sphere below it inside its box, lowest index right
-        leaf_of_node = leaf
-        node_leaves = [[] for _ in range(nn)]
-        stack = []
-        for k in range(nn):
-            while stack and skip[stack[-1]] <= k:
-                stack.pop()
-            stack.append(k)
-            if leaf_of_node[k] >= 0:
-                for a in stack:
-                    node_leaves[a].append(int(leaf_of_node[k]))
-        for k in range(nn):
-            members = []
-            for lf in node_leaves[k]:
-                members += [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size] if i != 0xffffffff]
-            if not members:
-                bad.append(f"node {k} has no sphere below it")
-                continue
-            m = np.array(members)
-            ar = np.abs(rad[m]).astype(np.float64)
-            lo = (p[m].astype(np.float64) - ar[:, None]).min(0)
-            hi = (p[m].astype(np.float64) + ar[:, None]).max(0)
-            if np.any(b["lo"][k] > lo) or np.any(b["hi"][k] < hi):
-                bad.append(f"node {k}: box does not hold its spheres")
-            if b["low"][k] != m.min():
-                bad.append(f"node {k}: lowest index {b['low'][k]} != {m.min()}")
-        if leaf_of_node[0] < 0 and nn > 1 and len(node_leaves[0]) != nl:
-            bad.append("the root does not reach every leaf")
-    # the same tree as sibling pairs: from the root every leaf is reached exactly once, every child box holds the
+    # the sibling pairs: from the root every leaf is reached exactly once, every child box holds the
     # spheres below it and knows their lowest scene index
     LEAF = 0x8000
     pr = b["pairs"]
@@ -148,6 +107,11 @@ def check_structure(sph, b, dfs=True):
     _sys.setrecursionlimit(10000)
     root = (nl // 2 - 1) if nl > 1 else LEAF
     everything = below(root)
+    depth = 1
+    while (1 << depth) < nl:
+        depth += 1
+    if b["stack_depth"] != depth + 1:
+        bad.append(f"stack depth {b['stack_depth']} != tree depth + 1 = {depth + 1}")
     if sorted(seen_leaves) != list(range(nl)):
         bad.append("the pairs do not reach every leaf exactly once")
     if sorted(everything) != sorted(int(i) for i in real):
@@ -161,53 +125,87 @@ def counters_raw(ctx):
     return list(out)
 
 
-def agreement(sph, cam, w, h, spp, bvh_min=1):
-    with api.RtContext(w, h, diag=True) as ctx:
-        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
-        ctx.set_scene(sph)
-        ctx.set_camera(cam)
-        b = read_bvh(ctx)
-        if b is None:
-            return None
-        ctx.set_mode(113)
-        ctx.render_pass(spp)
-        c = counters_raw(ctx)
-        return {"closest_rays": c[20], "closest_differ": c[21], "shadow_rays": c[24], "shadow_differ": c[25],
-                "last_closest": [hex(c[22]), hex(c[23])], "last_shadow": hex(c[26]), "tree": [b["n_always"], b["n_leaves"], b["n_nodes"]]}
+def scene_rays(sph, cam, w, h, n, seed=1):
+    """Rays a render of this scene traces: camera rays through random pixels (closest hit) and, from random points on
+    the spheres' surfaces, cosine-ish bounce rays (closest hit) and rays towards the lights (shadow rays, bounded)."""
+    rng = np.random.default_rng(seed)
+    cam = np.asarray(cam, np.float32)
+    orig, cdir, cx, cy = cam[0:3], cam[6:9], cam[9:12], cam[12:15]
+    p = np.ascontiguousarray(sph["p"]).astype(np.float64)
+    r = np.abs(sph["rad"].astype(np.float64))
+    ok = np.isfinite(p).all(1) & np.isfinite(r) & (r > 0)
+    lights = np.nonzero(ok & ((sph["e"][:, 0] != 0) | (sph["e"][:, 2] != 0)))[0]
+    small = np.nonzero(ok & (r < 500))[0]
+    rays = np.zeros((n, 8), np.float32)
+    for i in range(n):
+        kind = i % 3
+        if kind == 0 or len(small) == 0:
+            kx, ky = rng.uniform(-0.5, 0.5, 2)
+            d = cx * kx + cy * ky + cdir
+            o = orig + 0.1 * d
+            d = d / np.linalg.norm(d)
+            tmax, shadow = 1e20, 0
+        else:
+            j = int(small[rng.integers(0, len(small))])
+            nrm = rng.normal(0, 1, 3); nrm /= np.linalg.norm(nrm)
+            o = p[j] + nrm * r[j]
+            if kind == 1 or len(lights) == 0:
+                d = nrm + rng.normal(0, 0.6, 3); d /= np.linalg.norm(d)
+                tmax, shadow = 1e20, 0
+            else:
+                k = int(lights[rng.integers(0, len(lights))])
+                u = rng.normal(0, 1, 3); u /= np.linalg.norm(u)
+                to = p[k] + u * r[k] - o
+                tmax = float(np.linalg.norm(to)) - 0.01
+                d = to / max(np.linalg.norm(to), 1e-30)
+                shadow = 1
+        rays[i, 0:3], rays[i, 3], rays[i, 4:7] = o, tmax, d
+        rays[i, 7:8].view(np.uint32)[0] = shadow
+    return rays
 
 
-def census(sph, cam, w, h, spp):
-    """mode 114: steps of the walk per wavefront and per lane (closest-hit and shadow rays)"""
-    with api.RtContext(w, h, diag=True) as ctx:
-        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
-        ctx.set_scene(sph)
-        ctx.set_camera(cam)
-        ctx.set_mode(114)
-        ctx.render_pass(spp)
-        c = counters_raw(ctx)
-        st = ctx.stats()
-    out = {}
-    for name, base, rays in (("closest", 20, st["closest_rays"]), ("shadow", 24, st["shadow_rays"])):
-        wn, ln, wl, ll = c[base:base + 4]
-        out[name] = {"rays": rays, "node_tests_per_ray": round(ln / max(rays, 1), 1), "leaf_visits_per_ray": round(ll / max(rays, 1), 2),
-                     "wave_node_steps": wn, "lanes_per_node_step": round(ln / max(wn, 1), 1),
-                     "wave_leaf_steps": wl, "lanes_per_leaf_step": round(ll / max(wl, 1), 1)}
+def walk_rays(ctx, rays):
+    """rt_debug_walk_rays: out[i] = the walk's answer (2 words), then the sweep's (2 words)"""
+    out = np.zeros((len(rays), 4), np.uint32)
+    with np.errstate(all="ignore"):
+        ctx._check(ctx._lib.rt_debug_walk_rays(ctx._h, rays.ctypes.data_as(C.c_void_p), len(rays), out.ctypes.data_as(C.c_void_p)))
     return out
 
 
-def census_walk(sph, cam, w, h, spp, steps=0, gate=0, mode=116):
-    """mode 116: the two phases of rt_walk.inc.h -- wave-level trips, lanes taking part, clock ticks"""
+def agreement(sph, cam, w, h, n_rays=120000, bvh_min=1):
+    """Rays of the scene itself through the walk and through the plain sweep: how many answers differ (must be 0)."""
+    sph = api.as_spheres(sph)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
+        ctx.set_scene(sph)
+        b = read_bvh(ctx)
+        if b is None:
+            return None
+        rays = scene_rays(sph, cam, w, h, n_rays)
+        out = walk_rays(ctx, rays)
+    shadow = rays[:, 7].view(np.uint32) != 0
+    differ = (out[:, 0] != out[:, 2]) | (out[:, 1] != out[:, 3])
+    return {"closest_rays": int((~shadow).sum()), "closest_differ": int((differ & ~shadow).sum()), "closest_hits": int(((out[:, 2] != 0xffffffff) & ~shadow).sum()),
+            "shadow_rays": int(shadow.sum()), "shadow_differ": int((differ & shadow).sum()), "shadow_blocked": int(((out[:, 2] < len(sph)) & shadow).sum()),
+            "tree": [b["n_always"], b["n_leaves"], b["stack_depth"]]}
+
+
+def census_walk(sph, cam, w, h, spp, steps=0, gate=0):
+    """instance rt_trace_parity_pairs_census: what the walk executes -- pair steps (two box tests each) and leaf steps
+    (kBvhLeaf sphere tests each) per wavefront and per lane, shade phases, loop trips, clock shares"""
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
-        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, steps, gate, 2))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, steps, gate, 1))
         ctx.set_scene(sph)
         ctx.set_camera(cam)
-        ctx.set_mode(mode)
+        ctx.set_mode(api.instance_mode("rt_trace_parity_pairs_census"))
         ctx.render_pass(spp)
         c = counters_raw(ctx)[20:29]
         st = ctx.stats()
+        b = read_bvh(ctx)
     rays = st["closest_rays"] + st["shadow_rays"]
-    return {"rays": rays, "node_tests_per_ray": round(c[1] / rays, 1), "lanes_per_node_step": round(c[1] / max(c[0], 1), 1),
+    return {"rays": rays, "pair_steps_lanes": c[1], "pair_steps_waves": c[0], "leaf_steps_lanes": c[3], "leaf_steps_waves": c[2],
+            "always_spheres": b["n_always"], "node_tests_per_ray": round(c[1] / rays, 1), "lanes_per_node_step": round(c[1] / max(c[0], 1), 1),
             "leaf_visits_per_ray": round(c[3] / rays, 2), "lanes_per_leaf_step": round(c[3] / max(c[2], 1), 1),
             "shade_phases": c[4], "lanes_per_shade_phase": round(c[5] / max(c[4], 1), 1), "loop_trips": c[8],
             "node_steps_per_trip": round(c[0] / max(c[8], 1), 1), "clock_share_walk": round(c[6] / max(c[6] + c[7], 1), 3)}
@@ -246,10 +244,8 @@ def main():
         for name, mk, (w, h, spp) in [("c3", lambda: scenes.random_spheres(1024), (480, 270, 16)),
                                       ("mirror_box_256", lambda: scenes.mirror_box(256), (480, 270, 16))]:
             sph, orig, target = mk()
-            print("census", name, json.dumps(census(sph, host.compute_camera(orig, target, w, h), w, h, spp)), flush=True)
             for steps, gate in ((64, 16), (16, 16)):
-                print("census_walk", name, steps, gate, json.dumps(census_walk(sph, host.compute_camera(orig, target, w, h), w, h, spp, steps, gate)), flush=True)
-                print("census_pairs", name, steps, gate, json.dumps(census_walk(sph, host.compute_camera(orig, target, w, h), w, h, spp, steps, gate, mode=118)), flush=True)
+                print("census_pairs", name, steps, gate, json.dumps(census_walk(sph, host.compute_camera(orig, target, w, h), w, h, spp, steps, gate)), flush=True)
         return 0
     if args.timing_only:
         return timing(args, report)
@@ -265,7 +261,7 @@ def main():
             ctx.set_scene(sph)
             b = read_bvh(ctx)
             bad = check_structure(sph, b) if b else ["no hierarchy"]
-            report["structure_" + name] = {"always": b["n_always"], "leaves": b["n_leaves"], "nodes": b["n_nodes"], "complaints": bad[:5],
+            report["structure_" + name] = {"always": b["n_always"], "leaves": b["n_leaves"], "stack_depth": b["stack_depth"], "complaints": bad[:5],
                                            "hdr": [float(v) for v in b["hdr"].ravel()[:7]]}
             print("structure", name, report["structure_" + name], flush=True)
             if bad:
@@ -278,7 +274,7 @@ def main():
                                   ("random_96", lambda: scenes.random_spheres(96), (128, 96, 8))]:
         sph, orig, target = mk()
         cam = host.compute_camera(orig, target, w, h)
-        r = agreement(sph, cam, w, h, spp)
+        r = agreement(sph, cam, w, h)
         report["agreement_" + name] = r
         print("agreement", name, r, flush=True)
         if r is None or r["closest_differ"] or r["shadow_differ"]:
@@ -291,7 +287,7 @@ def main():
         sph, orig, target = mk()
         cam = host.compute_camera(orig, target, w, h)
         want = O.render(sph, cam, w, h, spp)
-        for form in (2, 3):
+        for form in (1,):
           with api.RtContext(w, h, diag=True) as ctx:
             ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
             ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
@@ -326,17 +322,15 @@ def timing(args, report):
         sph, orig, target = mk()
         cam = host.compute_camera(orig, target, w, h)
         t_off, px_off, st_off = timed(sph, cam, w, h, spp, 0)
-        t_on, px_on, st_on = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 2))
-        t_call, px_call, st_call = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 1))
+        t_on, px_on, st_on = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 1))
         t_auto, px_auto, st_auto = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 0))
-        t_pairs, px_pairs, _ = timed(sph, cam, w, h, spp, 1, walk=(0, 0, 3))
         sweep = {}
         for steps, gate in ((32, 16), (64, 16), (128, 16), (64, 32)):
-            tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 3))
+            tt, pp, _ = timed(sph, cam, w, h, spp, 1, reps=2, walk=(steps, gate, 1))
             sweep[f"{steps}/{gate}"] = round(tt, 2) if np.array_equal(pp, px_off) else "FRAME DIFFERS"
         rays = st_on["samples"] + st_on["shadow_rays"]
-        report["timing_" + name] = {"plain_ms": round(t_off, 3), "hierarchy_ms": round(t_on, 3), "per_call_ms": round(t_call, 3), "pairs_ms": round(t_pairs, 3) if np.array_equal(px_pairs, px_off) else "FRAME DIFFERS", "measured_choice_ms": round(t_auto, 3), "measured_choice": st_auto.get("pick"),
-                                    "frames_equal": bool(np.array_equal(px_off, px_on) and np.array_equal(px_off, px_call) and np.array_equal(px_off, px_auto)), "steps/gate_ms": sweep,
+        report["timing_" + name] = {"plain_ms": round(t_off, 3), "hierarchy_ms": round(t_on, 3), "measured_choice_ms": round(t_auto, 3), "measured_choice": st_auto.get("pick"),
+                                    "frames_equal": bool(np.array_equal(px_off, px_on) and np.array_equal(px_off, px_auto)), "steps/gate_ms": sweep,
                                     "counters_equal": st_off["sphere_tests"] == st_on["sphere_tests"],
                                     "Mray_s_hierarchy": round(rays / t_on / 1e3, 1), "Mray_s_plain": round(rays / t_off / 1e3, 1)}
         print("timing", name, report["timing_" + name], flush=True)

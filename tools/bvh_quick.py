@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from raytracing_simple_amd import host, scenes
 import bvh_check
-form = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+form = int(sys.argv[1]) if len(sys.argv) > 1 else 1       # 1 = the hierarchy forced, 0 = the measured choice
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 gate = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rounds = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]

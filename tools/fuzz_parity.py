@@ -108,7 +108,7 @@ for seed in range(first, first + count):
     with api.RtContext(w, h, diag=bvh_form != 0) as ctx:
         if bvh_form:
             ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
-            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, bvh_form))
+            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))      # RT_FUZZ_BVH != 0: the hierarchy forced
         ctx.set_scene(sph); ctx.set_camera(cam)
         px = ctx.render_pass(spp); col = ctx.read_colors(); sd = ctx.read_seeds(); st = ctx.stats()
     o = want["stats"]

@@ -1,8 +1,8 @@
 #!/bin/bash
-# VALU instruction counts of kernel instances on one config: tools/pmc_ab.sh CONFIG MODES
+# VALU instruction counts of kernel instances on one config: tools/pmc_ab.sh CONFIG MODES   (MODES: 0, 1, or kernel symbols of the diagnostics library)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-CFG=${1:-c2}; MODES=${2:-0,108}
+CFG=${1:-c2}; MODES=${2:-0}
 OUT=$R/gpurun_out/pmc_ab
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp

@@ -6,11 +6,11 @@ sys.path.insert(0, ROOT)
 from raytracing_simple_amd import api, host
 from tools.ab_bench import CONFIGS
 cname = sys.argv[1]
-modes = [int(m) for m in sys.argv[2].split(",")]
+modes = [int(m) if m.lstrip("-").isdigit() else api.instance_mode(m) for m in sys.argv[2].split(",")]
 maker, w, h, spp = CONFIGS[cname]
 sph, orig, target = maker()
 cam = host.compute_camera(orig, target, w, h)
-with api.RtContext(w, h) as ctx:
+with api.RtContext(w, h, diag=any(m >= 100 for m in modes)) as ctx:
     ctx.set_scene(sph); ctx.set_camera(cam)
     for m in modes:
         ctx.set_mode(m); ctx.reset(); ctx.render_pass(spp, copy=False)

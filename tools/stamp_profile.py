@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Section shares of the render loop from the stamped diagnostic instance (mode 105)."""
+"""Section shares of the render loop from the census instances of the diagnostics library:
+
+    python tools/stamp_profile.py CONFIGS [KERNEL]     KERNEL = rt_trace_parity_census (default; scenes below 12 spheres),
+                                                       rt_trace_parity_coop_census (12 and more: the 16-sphere scene, C5)"""
 import ctypes as C
 import os
 import sys
@@ -19,7 +22,7 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
     with api.RtContext(w, h, diag=True) as ctx:
         ctx.set_scene(sph)
         ctx.set_camera(cam)
-        ctx.set_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 101)
+        ctx.set_mode(api.instance_mode(sys.argv[2] if len(sys.argv) > 2 else ("rt_trace_parity_coop_census" if len(sph) >= 12 else "rt_trace_parity_census")))
         ctx.render_pass(spp, copy=False)
         st = ctx.stats()
         buf = (C.c_ulonglong * 24)()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a launch's time goes at wavefront granularity: renders one frame with the wall-clock-logging instance
-(mode 109 of librt_hip_diag.so: the shipped kernel + one s_memrealtime pair per wavefront) and reports the
+(instance rt_trace_parity_tl of librt_hip_diag.so: the shipped kernel + one s_memrealtime pair per wavefront) and reports the
 resident-wavefront curve over the launch (ramp, plateau, tail), per-wavefront durations by image region and by
 XCD, and how much of the launch the last wavefronts account for.
     python tools/wave_timeline.py [c2|c16|c5] [out.json]"""
@@ -30,11 +30,11 @@ gx, gy = (w + 31) // 32, (h + 7) // 8
 n_waves = gx * gy * 4
 with api.RtContext(w, h, diag=True) as ctx:
     ctx.set_scene(sph); ctx.set_camera(cam)
-    ctx.set_mode(100 if len(sph) < 12 else 104)
+    ctx.set_mode(api.instance_mode("rt_trace_parity" if len(sph) < 12 else "rt_trace_parity_coop"))
     for _ in range(3):
         ctx.reset(); ctx.render_pass(spp)
     plain_ms = ctx.stats()["last_kernel_ms"]
-    ctx.set_mode(109)
+    ctx.set_mode(api.instance_mode("rt_trace_parity_tl"))
     api._check(lib.rt_debug_timelog_enable(ctx._h, 8, n_waves), lib)
     ctx.reset(); ctx.render_pass(spp)
     logged_ms = ctx.stats()["last_kernel_ms"]
