@@ -41,7 +41,88 @@ TILE_ROWS = 8
 FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0                # same table
 FLOP_PER_SPHERE_TEST = 20            # ray-sphere test
+FLOP_PER_BOX_TEST = 12               # the hierarchy's slab test: six fused multiply-adds (one per box plane)
 BYTES_PER_PIXEL_PER_LAUNCH = 32      # seeds 8 R + 8 W, colour 12 W, pixel 4 W
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def pmc_record(workload, mode):
+    """Counter-derived figures of the committed rocprofv3 profile of this workload's kernel (profiles/pmc_traffic.json,
+    written by tools/summarize_profile.py from separate --pmc passes of this file's own command): HBM bytes per launch,
+    VALU instructions, active lanes.  Constants of a committed profile, labelled with their source -- not measured in this
+    run.  None where no profile of the workload is committed."""
+    try:
+        data = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None
+    return (data.get(workload) or {}).get(mode)
+
+
+def walk_census(api, spheres, cam, w, h, spp):
+    """What the hierarchy walk EXECUTES for one frame of this scene: the census instance of the diagnostics library
+    (rt_trace_parity_pairs_census: the shipped walk + per-lane counters) renders the frame once, outside every timed
+    region -- pair steps (two box tests each), leaf steps (8 sphere tests each), sphere tests of the always-list sweeps."""
+    import ctypes as C
+    with api.RtContext(w, h, diag=True) as c:
+        c._check(c._lib.rt_debug_set_walk(c._h, 0, 0, 1))
+        c.set_scene(spheres)
+        c.set_camera(cam)
+        c.set_mode(api.instance_mode("rt_trace_parity_pairs_census"))
+        c.render_pass(spp, copy=False)
+        raw = (C.c_ulonglong * 32)()
+        c._check(c._lib.rt_debug_counters_raw(c._h, raw))
+        st = c.stats()
+    return {"box_tests": 2 * int(raw[21]), "leaf_sphere_tests": 8 * int(raw[23]), "always_sphere_tests": int(raw[29]),
+            "pair_steps": int(raw[21]), "leaf_steps": int(raw[23]), "lanes_per_pair_step": round(raw[21] / max(raw[20], 1), 1),
+            "lanes_per_leaf_step": round(raw[23] / max(raw[22], 1), 1), "reference_equivalent_sphere_tests": st["sphere_tests"]}
+
+
+def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workload, mode, census=None, choice=None):
+    """The `roofline` object of one kernel: algorithmic work per launch over its measured duration against the FP32 vector
+    peak, with the HBM view nested beside it.  Plain sweeps execute exactly the reference's tests, so there the algorithmic
+    figure (20 FLOP x counted sphere tests) is the executed one.  The hierarchy executes far fewer: its `achieved` / `frac`
+    come from what the walk executes (12 FLOP per box test, 20 per sphere test: `executed_work`, counted by the census
+    instance), and the reference-equivalent rate stands beside it as what it is -- a rate, not a fraction of a peak."""
+    sec = kernel_ms * 1e-3
+    ref_flops = FLOP_PER_SPHERE_TEST * sphere_tests
+    alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * n_pixels + 44 * n_spheres + 60
+    out = {"bound": "valu-fp32", "kernel": kernel, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": round(kernel_ms, 4)}
+    if census is not None:
+        flops = FLOP_PER_BOX_TEST * census["box_tests"] + FLOP_PER_SPHERE_TEST * (census["leaf_sphere_tests"] + census["always_sphere_tests"])
+        out.update({"achieved": round(flops / sec / 1e12, 3), "frac": round(flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
+                    "algorithmic_flops_per_launch": flops,
+                    "work_model": "EXECUTED work of the hierarchy walk: 12 FLOP x box tests (6 fused multiply-adds each) + 20 FLOP x sphere tests "
+                                  "(leaf visits and always-list sweeps), counted on this frame by the census instance rt_trace_parity_pairs_census",
+                    "executed_work": census,
+                    "reference_equivalent": {"sphere_tests": sphere_tests, "flops": ref_flops, "TFLOP_s": round(ref_flops / sec / 1e12, 2),
+                                             "note": "what the reference's sweep (every ray against every sphere in scene order, up to the first blocker for "
+                                                     "shadow rays) would execute for the same rays -- rt_stats.sphere_tests, equal to the oracle's; the walk "
+                                                     "reaches the same answers without executing them, so this is a rate, not a fraction of the peak"}})
+    else:
+        out.update({"achieved": round(ref_flops / sec / 1e12, 3), "frac": round(ref_flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
+                    "algorithmic_flops_per_launch": ref_flops,
+                    "work_model": "the reference's sweep, which this kernel executes test for test: every ray tests the spheres in scene order (all of them, "
+                                  "or up to its first blocker): 20 FLOP x rt_stats.sphere_tests"})
+    if choice is not None and choice.get("picked") is not None:
+        out["measured_choice"] = {"picked": choice["picked"], "hierarchy_ms_per_pass": round(choice["hierarchy_ms_per_pass"], 4),
+                                  "sweep_ms_per_pass": round(choice["sweep_ms_per_pass"], 4),
+                                  "note": "the library timed each form on this scene, warm, in the same tile order (rt_scene_choice); the sweep is the "
+                                          "wave-ballot any-hit instance (rt_trace_*_coop)"}
+    out["hbm"] = {"algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / sec / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 6)}
+    pm = pmc_record(workload, mode)
+    out["traffic"] = None
+    if pm and pm.get("kernel", kernel) == kernel:
+        out["traffic"] = pm.get("hbm_bytes_per_launch")
+        if pm.get("valu_insts_per_launch"):
+            # what the VALU actually issues (PMC of the committed profile, same command): the time its instructions
+            # need at full issue rate, and how much of this run's kernel time that is
+            floor_ms = pm["valu_busy_frac_single_stream"] * pm["profiled_kernel_ms"]
+            out["executed"] = {"valu_insts_per_launch": pm["valu_insts_per_launch"], "active_lane_frac": pm["active_lane_frac"],
+                               "valu_issue_floor_ms": round(floor_ms, 4), "valu_busy_frac": round(floor_ms / kernel_ms, 4),
+                               "l2_hit_rate": pm.get("l2_hit_rate"), "lds_bank_conflict_frac": pm.get("lds_bank_conflict_frac"),
+                               "source": pm.get("source", "profiles/pmc_traffic.json")}
+    return out
 
 
 def host_cores():
@@ -138,7 +219,9 @@ def inproc_child(args):
         st = ctx.stats()
     rays = st["samples"] + st["shadow_rays"]
     print(json.dumps({"n_gpus": n, "path": "rt_create_multi: one process, in-library gather"
-                      + (" (one-GPU rehearsal: D2D copies stand in for ncclSend/ncclRecv)" if len(set(devices)) < n else " (ncclSend/ncclRecv over xGMI)"),
+                      + (" (one-GPU rehearsal: D2D copies stand in for ncclSend/ncclRecv)" if len(set(devices)) < n
+                         else " (ncclSend/ncclRecv across distinct devices: before round 3's driver run this branch had executed nowhere -- "
+                              "frame_equals_single_device is its check)"),
                       "steps": args.steps, "ms_per_frame": round(dt / args.steps * 1e3, 4), "value": round(rays * args.steps / dt / 1e6, 1),
                       "unit": "Mray/s",
                       "slowest_shard_kernel_ms": round(st["last_kernel_ms"], 4),
@@ -226,6 +309,12 @@ def main():
 
     ctxs = make_contexts(spheres, cam, F)
     ctx = ctxs[0]
+    # scenes large enough for a hierarchy: the library measures hierarchy against sweep on a new scene's first launches
+    # (four of them; a blocking call of 16 passes or more holds them all) -- one untimed blocking frame per context settles
+    # that before any timed region, whatever --warmup says
+    for c in ctxs:
+        c.reset_async()
+        c.render_pass(max(SPP, 16), copy=False)
     side_streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
 
     gather, want_dev, mismatch = None, None, None
@@ -377,12 +466,10 @@ def main():
             el16F, _, _ = timed_region(c16, s16, F, k16, 2, with_events=False)
             st16 = frame_counters(c16[0])
             rays16 = st16["samples"] + st16["shadow_rays"]
-            tf16 = FLOP_PER_SPHERE_TEST * st16["sphere_tests"] / (kms16 * 1e-3) / 1e12
             target = {"workload": "north-star target: Demo + 10 spheres (16), 1920x1080, 64 spp, default seed stream",
                       "asked_Mray_s": 10000.0, "steps": k16, "ms_per_step": round(el16 / k16 * 1e3, 4),
                       "value": round(rays16 * k16 / el16 / 1e6, 1), "unit": "Mray/s", "kernel": c16[0].last_kernel, "kernel_ms": round(kms16, 4),
-                      "roofline": {"bound": "valu-fp32", "achieved": round(tf16, 3), "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(tf16 / FP32_VECTOR_PEAK_TFLOPS, 5)},
+                      "roofline": roofline_block(c16[0].last_kernel, kms16, st16["sphere_tests"], W * H, len(sph16), "c16", args.mode),
                       "frames_in_flight": {"frames": F, "ms_per_step": round(el16F / k16 * 1e3, 4), "value": round(rays16 * k16 / el16F / 1e6, 1)}}
             if not args.no_cpu and mode == api.RT_MODE_PARITY:
                 base16, cpu16 = cpu_baseline(sph16, cam16, W, H, SPP, reference_too=False)
@@ -395,8 +482,9 @@ def main():
         if args.workload == "c2":
             try:
                 sph3, o3, t3 = scenes.random_spheres(1024)
+                cam3 = host.compute_camera(o3, t3, W, H)
                 with api.RtContext(W, H, device=local_rank) as cl:
-                    cl.set_scene(sph3); cl.set_camera(host.compute_camera(o3, t3, W, H)); cl.set_mode(mode)
+                    cl.set_scene(sph3); cl.set_camera(cam3); cl.set_mode(mode)
                     for _ in range(3):
                         cl.reset_async(); cl.render_pass(16, copy=False)
                     k3 = max(5, args.steps // 2)
@@ -404,14 +492,14 @@ def main():
                     for _ in range(k3):
                         cl.reset_async(); cl.render_pass(16, copy=False)
                     dt3 = time.perf_counter() - t0
-                    st3, ch3 = cl.stats(), cl.scene_choice()
-                    large = {"workload": "C3: 1024 random spheres, 1920x1080, 16 spp, default seed stream", "steps": k3,
-                             "ms_per_step": round(dt3 / k3 * 1e3, 4), "value": round((st3["samples"] + st3["shadow_rays"]) * k3 / dt3 / 1e6, 1),
-                             "unit": "Mray/s", "kernel": cl.last_kernel, "kernel_ms": round(st3["last_kernel_ms"], 4),
-                             "measured_choice": {"picked": ch3["picked"], "hierarchy_ms_per_pass": round(ch3["hierarchy_ms_per_pass"], 4),
-                                                 "sweep_ms_per_pass": round(ch3["sweep_ms_per_pass"], 4)},
-                             "note": "frames, seeds and counters are the same bits through either form (DESIGN.md section 5; "
-                                     "profiles/r02s_full_size_parity.jsonl); bench.py --workload c3 is the full record"}
+                    st3, ch3, kern3 = cl.stats(), cl.scene_choice(), cl.last_kernel
+                cen3 = walk_census(api, sph3, cam3, W, H, 16) if "_pairs" in kern3 else None
+                large = {"workload": "C3: 1024 random spheres, 1920x1080, 16 spp, default seed stream", "steps": k3,
+                         "ms_per_step": round(dt3 / k3 * 1e3, 4), "value": round((st3["samples"] + st3["shadow_rays"]) * k3 / dt3 / 1e6, 1),
+                         "unit": "Mray/s", "kernel": kern3, "kernel_ms": round(st3["last_kernel_ms"], 4),
+                         "roofline": roofline_block(kern3, st3["last_kernel_ms"], st3["sphere_tests"], W * H, len(sph3), "c3", args.mode, census=cen3, choice=ch3),
+                         "note": "frames, seeds and counters are the same bits through either form (DESIGN.md section 5; "
+                                 "tests/test_gpu_parity.py test_baseline_configurations_at_full_size_bit_exact); bench.py --workload c3 is the full record"}
             except api.RtError as e:
                 large = {"error": str(e)}
         # the in-library multi-device context with a communicator of one: what the frame-end gather path costs
@@ -458,29 +546,13 @@ def main():
     value = rays * args.steps / el1_max / 1e6
     # roofline of the dominant (only) kernel, per launch, from this rank's launches in the headline region
     # (HIP events on the stream the kernel is launched on; launches do not overlap there)
-    my_tests = st["sphere_tests"]
-    flops = FLOP_PER_SPHERE_TEST * my_tests
-    achieved_tflops = flops / (kernel_ms * 1e-3) / 1e12
-    my_pixels = my_local_rows * W
-    alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * my_pixels + 44 * len(spheres) + 60
-    traffic, executed = None, None
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if world == 1 and args.workload == "c2" and os.path.exists(prof):
-        try:
-            pm = json.load(open(prof)).get(args.mode, {})
-            traffic = pm.get("hbm_bytes_per_launch")
-            if pm.get("valu_insts_per_launch"):
-                # what the VALU actually issues (PMC of the committed profile, same command): the
-                # time its instructions need at full issue rate, and how much of a step that is
-                floor_ms = pm["valu_busy_frac_single_stream"] * pm["profiled_kernel_ms"]
-                executed = {"valu_insts_per_launch": pm["valu_insts_per_launch"],
-                            "active_lane_frac": pm["active_lane_frac"],
-                            "valu_issue_floor_ms": round(floor_ms, 4),
-                            "valu_busy_frac": round(floor_ms / kernel_ms, 4),
-                            "l2_hit_rate": pm.get("l2_hit_rate"),
-                            "source": pm.get("source", "profiles/pmc_traffic.json (rocprofv3 --pmc passes, tools/profile_gpu.sh)")}
-        except (OSError, ValueError, KeyError):
-            traffic, executed = None, None
+    census = walk_census(api, spheres, cam, W, H, SPP) if (world == 1 and "_pairs" in kernel_name) else None
+    roofline = roofline_block(kernel_name, kernel_ms, st["sphere_tests"], my_local_rows * W, len(spheres), args.workload, args.mode,
+                              census=census, choice=choice)
+    if world > 1:
+        roofline["traffic"] = None          # the committed counters describe the unsharded launch
+        roofline.pop("executed", None)
+    roofline["kernel_ms_max_rank"] = round(kernel_ms_max, 4)
     line = {
         "metric": "Mray/s (primary+shadow) at 1080p 64spp" if args.workload == "c2"
                   else f"Mray/s (primary+shadow) at {W}x{H} {SPP}spp",
@@ -508,33 +580,8 @@ def main():
                    "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
                    "Mray_s_all_rays": round((closest + shadow) * args.steps / el1_max / 1e6, 1),
                    "Msample_s": round(samples * args.steps / el1_max / 1e6, 1)},
-        "roofline": {
-            "bound": "valu-fp32",
-            "kernel": kernel_name,
-            "achieved": round(achieved_tflops, 3),
-            "peak": FP32_VECTOR_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": round(achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, 5),
-            "traffic": traffic,
-            "kernel_ms": round(kernel_ms, 4),
-            "kernel_ms_max_rank": round(kernel_ms_max, 4),
-            "algorithmic_flops_per_launch": flops,
-            "measured_choice": None if choice["picked"] is None else
-            {"picked": choice["picked"], "hierarchy_ms_per_pass": round(choice["hierarchy_ms_per_pass"], 4),
-             "sweep_ms_per_pass": round(choice["sweep_ms_per_pass"], 4),
-             "note": "the library timed one launch of each form on this scene (rt_scene_choice); the sweep is the wave-ballot "
-                     "any-hit instance (rt_trace_*_coop)"},
-            "work_model": "the reference's sweep: every ray tests the spheres in scene order (all of them, or up to its first blocker)"
-                          + ("; this scene renders through the hierarchy (chosen by measurement), which returns the same frames and counters from "
-                             "far fewer executed tests: `achieved` is reference-equivalent work per second, not executed arithmetic"
-                             if kernel_name.endswith("_pairs") else ""),
-            "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
-                    "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
-        },
+        "roofline": roofline,
     }
-    if executed is not None:
-        line["roofline"]["executed"] = executed
     if elF_max is not None:
         line["frames_in_flight"] = {"frames": F, "ms_per_step": round(elF_max / args.steps * 1e3, 4),
                                     "value": round(rays * args.steps / elF_max / 1e6, 1), "unit": "Mray/s",

@@ -49,6 +49,7 @@ RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
  * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, stack depth, slots }, all 0 without a hierarchy */
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
 RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* pair steps per lane per loop trip; ready lanes that make a wavefront shade (0 = keep either); forced 0 = hierarchy or plain sweep by measurement (default), 1 = the hierarchy whenever the scene has one */
+RT_API int rt_debug_set_pool_rows(rt_ctx *ctx, int rows);   /* rows of 32 pixels a workgroup of the walk hands out to its lanes (a multiple of 8; 8 = one pixel per lane; default 32) */
 RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a lane takes in a row before the leaf step of the lanes that hold a leaf (default 3; large = until every lane has one) */
 /* n_rays rays { o.xyz, t_max, d.xyz, shadow != 0 } (8 floats each; the last as a bit pattern) through the hierarchy walk
  * AND the plain sweep, one lane per ray; out4 (4 words per ray) = the walk's answer, then the sweep's -- closest hit:

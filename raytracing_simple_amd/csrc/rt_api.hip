@@ -404,6 +404,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
     }
     p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
+    p.pool_rows = c->pool_rows;
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {
@@ -423,8 +424,11 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
     if (rc != RT_OK) return rc;
     const bool persist = (inst->flags & rt::kInstPersistent) != 0;
 
-    const int tile_w = 8 * inst->waves;
-    dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
+    // a workgroup's share of the image: 8 * waves x 8 pixels, one per lane -- or, for the instances that hand a pool of
+    // pixels to their lanes, 32 x pool_rows
+    const bool pool = (inst->flags & rt::kInstPixelPool) != 0;
+    const int tile_w = 8 * inst->waves, tile_h = pool ? c->pool_rows : rt::kTileH;
+    dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + tile_h - 1) / tile_h));
     // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
     // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)
     const uint32_t n_tiles = grid.x * grid.y;
@@ -459,9 +463,14 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
     }
 #endif
-    const hipError_t e = rt::launch_instance(*inst, p, grid, lds_use, stream);
+    hipError_t e = rt::launch_instance(*inst, p, grid, lds_use, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (%s, grid %ux%u, lds %zu B)", hipGetErrorString(e), inst->name, grid.x, grid.y, lds_use);
+    if (pool && !p.skip_pixels) {
+        // the pool instances leave the packed pixels to the pack kernel (.cl:34,594-596 with the mode's own toInt)
+        e = fast ? rt::launch_pack_fast(p, stream) : rt::launch_pack_parity(p, stream);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "pack kernel launch failed: %s", hipGetErrorString(e));
+    }
     c->current_sample += n_samples;
     c->launches += 1;
     c->last_kernel = inst->name;
@@ -671,7 +680,7 @@ void rt_host_set_error(const char *msg) { snprintf(g_err, sizeof g_err, "%s", ms
 RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, int nranks, int tile_rows) {
     if (!out) return fail(RT_ERR_ARG, "out is null");
     *out = nullptr;
-    if (w <= 0 || h <= 0) return fail(RT_ERR_ARG, "image size %dx%d", w, h);
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(RT_ERR_ARG, "image size %dx%d (1 .. 65535 in either direction)", w, h);
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(RT_ERR_ARG, "rank %d of %d", rank, nranks);
     if (tile_rows <= 0 || tile_rows % rt::kTileH != 0)
         return fail(RT_ERR_ARG, "tile_rows must be a positive multiple of %d", rt::kTileH);
@@ -1374,6 +1383,11 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
 static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
 static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v; return RT_OK; }
+static int dbg_set_pool_rows(rt_ctx *c, int v) { c->pool_rows = v; c->cost_valid = c->order_valid = false; return RT_OK; }
+RT_API int rt_debug_set_pool_rows(rt_ctx *c, int rows) {
+    if (!c || rows < 8 || rows % 8 != 0 || rows > 2048) return fail(RT_ERR_ARG, "rows %d", rows);
+    return dbg_apply(c, dbg_set_pool_rows, rows);
+}
 RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     if (!c || steps < 1) return fail(RT_ERR_ARG, "steps %d", steps);
     return dbg_apply(c, dbg_set_walk_round, steps);

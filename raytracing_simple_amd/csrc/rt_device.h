@@ -98,6 +98,7 @@ struct LaunchParams {
     // offsets, and with them their scalar loads and SGPR allocation, are what they were without it
     int walk_steps;         // rt_walk.inc.h: pair steps a lane may take per loop trip
     int walk_round;         // ... and in a row before the leaf step of the lanes that hold a leaf
+    int pool_rows;          // ... rows of 32 pixels a workgroup hands out to its lanes (a multiple of 8; 8 = one pixel per lane)
     BvhTables bvh;
 };
 
@@ -141,6 +142,7 @@ enum InstanceFlags : uint8_t {
     kInstPersistent = 1,    // the grid only fills the machine; tiles come from the queue at counters[30]
     kInstNoTileCost = 2,    // neither reads the heavy-first order nor leaves per-tile costs
     kInstStaticCoop = 4,    // carries the cooperative any-hit mailbox (1.5 KiB of static LDS per wavefront)
+    kInstPixelPool = 8,     // a workgroup hands a pool of 32 x pool_rows pixels to its lanes; the packed pixels come from the pack kernel behind it
 };
 struct Instance {
     void (*fn)(const LaunchParams);

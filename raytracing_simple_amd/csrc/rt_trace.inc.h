@@ -550,13 +550,16 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int tile = lrow / P.tile_rows;
     const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
+    // What stays in registers through the loop of the pixel's place: x | y << 16 in ONE register (the camera ray needs
+    // both per sample; the host refuses images beyond 65535 in either direction).  The local row, the validity and the
+    // 64-bit indices are formed again after the loop from the lane number and the tile.
+    const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
 
     uint32_t s0 = 0, s1 = 0;
     V3 acc = mk(0.f, 0.f, 0.f);
     int s = P.first_sample;
     const int s_end = valid ? P.first_sample + P.n_samples : P.first_sample;
     if (valid) {
-        // (the two 64-bit indices are formed again after the loop instead of staying live through it)
         const size_t gid = (size_t)y * (size_t)P.w + (size_t)x;             // .cl:560-563
         const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;  // .cl:579
         const uint2 sd = *reinterpret_cast<const uint2 *>(P.seeds_in + 2 * gid);
@@ -566,12 +569,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 #endif
 
-    const float inv_w = P.inv_w;                                             // .cl:503-504, divided on the host
-    const float inv_h = P.inv_h;
-    const V3 cam_o = mk(P.cam.orig.x, P.cam.orig.y, P.cam.orig.z);
-    const V3 cam_d = mk(P.cam.dir.x, P.cam.dir.y, P.cam.dir.z);
-    const V3 cam_x = mk(P.cam.x.x, P.cam.x.y, P.cam.x.z);
-    const V3 cam_y = mk(P.cam.y.x, P.cam.y.y, P.cam.y.z);
 
     uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
     unsigned long long c_tests = 0;   // shadow-ray tests (per-ray additions, never inside a sphere loop); closest-hit rays add n each, at the end
@@ -684,11 +681,28 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #endif
             RT_STAMP(0);
             // ---- camera ray, .cl:494-549 ----
+            // The camera (12 floats) and 1/w, 1/h are read from the kernel-argument segment HERE, once per sample, through
+            // the scalar cache, instead of occupying 14 scalar registers through the whole loop: the loop overfills the
+            // scalar file, its spills go to lanes of a vector register, and that register was the one the allocator then
+            // lacked (a private segment of 16 bytes in the cooperative instances).
+            const __attribute__((address_space(4))) LaunchParams *cp =
+                (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("; camera re-read" : "+s"(cp));
+            const float inv_w = cp->inv_w, inv_h = cp->inv_h;                // .cl:503-504, divided on the host
+            const V3 cam_o = mk(cp->cam.orig.x, cp->cam.orig.y, cp->cam.orig.z);
+            const V3 cam_d = mk(cp->cam.dir.x, cp->cam.dir.y, cp->cam.dir.z);
+            const V3 cam_x = mk(cp->cam.x.x, cp->cam.x.y, cp->cam.x.z);
+            const V3 cam_y = mk(cp->cam.y.x, cp->cam.y.y, cp->cam.y.z);
             float j1 = next_random_centred(s0, s1);
             float j2 = next_random_centred(s0, s1);
             c_draws += 2;
+#if RT_OPT_PERSIST
             float kcx = ((float)x + j1) * inv_w - 0.5f;
             float kcy = ((float)y + j2) * inv_h - 0.5f;
+#else
+            float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
+            float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
+#endif
             V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x,
                        cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
                        cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
@@ -922,9 +936,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("; epilogue arguments re-read" : "+s"(qp));
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
-    if (valid && Q.n_samples > 0) {
-        int xe = x, ye = y, le = lrow;
-        asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
+    // the lane's number from the execution mask (no register held for it): v_mbcnt of all ones
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
+    if (valid_e && Q.n_samples > 0) {
+        const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16), le = tile_by * kTileH + (lane_e >> 3);
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;           // .cl:560-563
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;   // .cl:579
         float *colors = Q.colors;
@@ -942,7 +958,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #if RT_OPT_PERSIST
     uint32_t n_done = c_samples;
 #else
-    uint32_t n_done = valid ? (uint32_t)Q.n_samples : 0u;
+    uint32_t n_done = valid_e ? (uint32_t)Q.n_samples : 0u;
 #endif
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);

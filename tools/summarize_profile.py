@@ -90,6 +90,30 @@ def main():
             f.write(f"| {k} | {avg[k]:.6g} |\n")
         f.write("\n## derived\n\n```\n" + json.dumps({k: v for k, v in summary.items()
                                                        if k not in ("pmc_per_launch_avg", "launch")}, indent=1) + "\n```\n")
+    # RT_PMC_KEY=c16 (the bench.py workload the profile is of): also the record bench.py reads for that workload's
+    # `roofline.traffic` / `roofline.executed` (profiles/pmc_traffic.json)
+    key = os.environ.get("RT_PMC_KEY")
+    if key and "valu_insts_per_launch" in summary and "avg_kernel_ns" in summary:
+        pmc_path = os.path.join(root, "profiles", "pmc_traffic.json")
+        try:
+            data = json.load(open(pmc_path))
+        except (OSError, ValueError):
+            data = {}
+        rec = {"kernel": kern, "valu_insts_per_launch": summary["valu_insts_per_launch"], "active_lane_frac": round(summary["active_lane_frac"], 4),
+               "profiled_kernel_ms": round(summary["avg_kernel_ns"] / 1e6, 4),
+               "source": f"profiles/{out_name}.{{md,json}} (rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --workload {key} --no-extras`, tools/profile_gpu.sh)"}
+        if "valu_busy_frac_single_stream" in summary:
+            rec["valu_busy_frac_single_stream"] = round(summary["valu_busy_frac_single_stream"], 4)
+        if "hbm_bytes_per_launch" in summary:
+            rec.update({"hbm_bytes_per_launch": int(summary["hbm_bytes_per_launch"]), "fetch_raw_bytes": round(summary["hbm_fetch_bytes_raw"], 1),
+                        "write_bytes": round(summary["hbm_write_bytes"], 1)})
+        if "l2_hit_rate" in summary:
+            rec["l2_hit_rate"] = round(summary["l2_hit_rate"], 4)
+        if avg.get("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_bank_conflict_frac"] = round(avg.get("SQ_LDS_BANK_CONFLICT", 0.0) / avg["SQ_LDS_IDX_ACTIVE"], 4)
+        data.setdefault(key, {})[mode] = rec
+        with open(pmc_path, "w") as f:
+            json.dump(data, f, indent=1)
     print(json.dumps(summary, indent=1))
 
 
