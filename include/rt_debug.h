@@ -49,7 +49,6 @@ RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
  * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, stack depth, slots }, all 0 without a hierarchy */
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
 RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* pair steps per lane per loop trip; ready lanes that make a wavefront shade (0 = keep either); forced 0 = hierarchy or plain sweep by measurement (default), 1 = the hierarchy whenever the scene has one */
-RT_API int rt_debug_set_pool_rows(rt_ctx *ctx, int rows);   /* rows of 32 pixels a workgroup of the walk hands out to its lanes (a multiple of 8; 8 = one pixel per lane; default 32) */
 RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a lane takes in a row before the leaf step of the lanes that hold a leaf (default 3; large = until every lane has one) */
 /* n_rays rays { o.xyz, t_max, d.xyz, shadow != 0 } (8 floats each; the last as a bit pattern) through the hierarchy walk
  * AND the plain sweep, one lane per ray; out4 (4 words per ray) = the walk's answer, then the sweep's -- closest hit:
@@ -61,6 +60,9 @@ RT_API int rt_debug_read_bvh(rt_ctx *ctx, float *blob_out, uint32_t cap_float4, 
 RT_API int rt_debug_set_wg_waves(rt_ctx *ctx, int waves);          /* 0 = automatic, 1 or 4 wavefronts per workgroup */
 RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order                */
 RT_API int rt_debug_read_tile_order(rt_ctx *ctx, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid);
+RT_API int rt_debug_set_pixel_deal(rt_ctx *ctx, int rows);         /* 0 = every wavefront renders its 8x8 square (no deal by cost); 8 / 16 / 32 = rows of a region of 32 x rows pixels */
+/* the deal in use -- per region 32 * rows positions dy * 32 + dx in rank order; *valid = rows of a region, 0 = no deal -- and the per-pixel costs of the last launch */
+RT_API int rt_debug_read_pixel_deal(rt_ctx *ctx, uint16_t *deal_out, size_t deal_cap, uint16_t *cost_out, size_t cost_cap, int *valid);
 
 /* raw diagnostic counters (section census of the stamped instances; valid after rt_get_stats) */
 RT_API int rt_debug_counters(rt_ctx *ctx, unsigned long long *out24);

@@ -145,6 +145,46 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
     }
 }
 
+// The deal of a region's pixels to its wavefronts (rt_device.h LaunchParams::deal): ONE workgroup per region of 32 x deal_rows
+// pixels sorts them by the cost the last launch left for them (rays traced; descending, ties by position) -- a bitonic sort
+// in LDS, one key per thread -- and writes their positions (dy * 32 + dx) in that order.  A region that is not wholly inside
+// the rendered rows keeps the 8x8 squares (its workgroups do not all exist: ranks must not move out of their square).
+__global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *__restrict__ cost, uint16_t *__restrict__ deal, int w, int rows,
+                                                              int regions_x, int deal_rows) {
+    __shared__ uint32_t s_key[rt::kRegionW * rt::kMaxDealRows];
+    const int tid = threadIdx.x, nt = blockDim.x, n = rt::kRegionW * deal_rows;       // n: a power of two, nt = min(n, 1024)
+    const int region = blockIdx.x, ry = region / regions_x, rx = region - ry * regions_x;
+    const int x0 = rx * rt::kRegionW, y0 = ry * deal_rows;
+    const bool whole = (x0 + rt::kRegionW <= w) && (y0 + deal_rows <= rows);
+    if (!whole) {
+        // identity: rank (band b, wavefront q, lane l) -> the pixel (q * 8 + (l & 7), b * 8 + (l >> 3)) of the wavefront's own square
+        for (int r = tid; r < n; r += nt) {
+            const int b = r >> 8, q = (r >> 6) & 3, l = r & 63;
+            deal[(size_t)region * n + r] = (uint16_t)(((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7)));
+        }
+        return;
+    }
+    for (int i = tid; i < n; i += nt) {
+        const int dx = i & 31, dy = i >> 5;
+        const uint32_t c_ = cost[(size_t)(y0 + dy) * (size_t)w + (size_t)(x0 + dx)];
+        s_key[i] = (c_ << 12) | (uint32_t)(4095 - i);       // descending sort of the key = heaviest first, then lowest position
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n; i += nt) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = s_key[i], b = s_key[l];
+                    if ((a < b) == ((i & k) == 0)) { s_key[i] = b; s_key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += nt) deal[(size_t)region * n + i] = (uint16_t)(4095u - (s_key[i] & 4095u));
+}
+
 // rt_deinterleave_rows: full[y] = row (t/n)*tile_rows + y%tile_rows of rank t%n's block, t = y/tile_rows.
 // One thread per 16 bytes where the row length allows it (w % 4 == 0 keeps every row 16-byte aligned).
 __global__ void __launch_bounds__(256) rt_deinterleave_kernel(uint32_t *__restrict__ full, const uint32_t *__restrict__ gathered, int w,
@@ -404,7 +444,6 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
     }
     p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
-    p.pool_rows = c->pool_rows;
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {
@@ -424,16 +463,32 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
     if (rc != RT_OK) return rc;
     const bool persist = (inst->flags & rt::kInstPersistent) != 0;
 
-    // a workgroup's share of the image: 8 * waves x 8 pixels, one per lane -- or, for the instances that hand a pool of
-    // pixels to their lanes, 32 x pool_rows
-    const bool pool = (inst->flags & rt::kInstPixelPool) != 0;
-    const int tile_w = 8 * inst->waves, tile_h = pool ? c->pool_rows : rt::kTileH;
-    dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + tile_h - 1) / tile_h));
+    const int tile_w = 8 * inst->waves;
+    dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
     // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
     // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)
     const uint32_t n_tiles = grid.x * grid.y;
     const bool instance_logs_cost = (inst->flags & rt::kInstNoTileCost) == 0;
     if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
+        // pixels dealt to wavefronts by cost: every launch leaves the rays it traced per pixel; once a long launch has,
+        // the 256 pixels of each 32x8 region are sorted by them (on the device, once per scene and camera) and later
+        // launches hand rank r of a region to wavefront r / 64, lane r % 64.  The tile costs measured under the old
+        // deal no longer describe the workgroups: the heavy-first order is sorted again from the next launch's.
+        if (c->use_deal && c->d_pixel_cost && !persist) {
+            p.pixel_cost = c->d_pixel_cost;
+            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 8) {
+                const int regions_x = (c->w + rt::kRegionW - 1) / rt::kRegionW, regions_y = (c->local_rows + c->deal_rows - 1) / c->deal_rows;
+                hipLaunchKernelGGL(rt_order_pixels_kernel, dim3((unsigned)(regions_x * regions_y)), dim3((unsigned)std::min(rt::kRegionW * c->deal_rows, 1024)), 0, stream,
+                                   c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows);
+                HIP_TRY(hipGetLastError());
+                c->deal_valid = true;
+                c->cost_valid = c->order_valid = false;
+            }
+            if (c->deal_valid) {
+                p.deal = c->d_deal;
+                p.deal_rows = c->deal_rows;
+            }
+        }
         if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
         if (c->cost_valid && !c->order_valid && n_samples >= 8) {
@@ -463,14 +518,9 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
     }
 #endif
-    hipError_t e = rt::launch_instance(*inst, p, grid, lds_use, stream);
+    const hipError_t e = rt::launch_instance(*inst, p, grid, lds_use, stream);
     if (e != hipSuccess)
         return fail(RT_ERR_HIP, "kernel launch failed: %s (%s, grid %ux%u, lds %zu B)", hipGetErrorString(e), inst->name, grid.x, grid.y, lds_use);
-    if (pool && !p.skip_pixels) {
-        // the pool instances leave the packed pixels to the pack kernel (.cl:34,594-596 with the mode's own toInt)
-        e = fast ? rt::launch_pack_fast(p, stream) : rt::launch_pack_parity(p, stream);
-        if (e != hipSuccess) return fail(RT_ERR_HIP, "pack kernel launch failed: %s", hipGetErrorString(e));
-    }
     c->current_sample += n_samples;
     c->launches += 1;
     c->last_kernel = inst->name;
@@ -479,6 +529,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         c->cost_valid = true;
         c->cost_tiles = n_tiles;
     }
+    if (p.pixel_cost && n_samples >= 4) c->pixel_cost_valid = true;
     c->seeds_default = false;           // this launch has written every seed pair the context renders
     c->pixels_current = c->pixel_write != 0;
     return RT_OK;
@@ -734,6 +785,10 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
         if (c->n_tiles) {
             HIP_TRY(hipMalloc(&c->d_tile_cost, (size_t)c->n_tiles * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&c->d_order, (size_t)c->n_tiles * sizeof(uint32_t)));
+            // (regions of 8 rows need the most entries: every region is padded to whole rows of 32 pixels)
+            const size_t deal_entries = (size_t)((w + rt::kRegionW - 1) / rt::kRegionW) * rt::kRegionW * (size_t)(((rows + 7) / 8) * 8 + rt::kMaxDealRows);
+            HIP_TRY(hipMalloc(&c->d_pixel_cost, ((size_t)rows * w + 4) * sizeof(uint16_t)));
+            HIP_TRY(hipMalloc(&c->d_deal, deal_entries * sizeof(uint16_t)));
         }
         // function attributes (dynamic-LDS limit) are per device, not per context
         static std::mutex mu;
@@ -780,6 +835,8 @@ RT_API void rt_destroy(rt_ctx *c) {
         (void)hipFree(c->d_stats);
         (void)hipFree(c->d_tile_cost);
         (void)hipFree(c->d_order);
+        (void)hipFree(c->d_pixel_cost);
+        (void)hipFree(c->d_deal);
         (void)hipFree(c->d_timelog);
         (void)hipFree(c->d_wavelog);
         (void)hipFree(c->d_blocklog);
@@ -833,6 +890,7 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     c->is_light.assign(c->scene_cap, 0);
     c->h_spheres.assign(spheres, spheres + count);
     c->cost_valid = c->order_valid = false;
+    c->pixel_cost_valid = c->deal_valid = false;
     rearm_probe(c);                     // a new scene: hierarchy or plain sweep is measured again
     rc = upload_spheres(c, 0, count, spheres, count, c->stream);
     if (rc != RT_OK) {
@@ -855,7 +913,7 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
     // the last frames' costs still predict this one (moving spheres): the order stays, and is sorted again from
     // fresh costs after a few changes
-    if (++c->order_age >= 8) c->order_valid = false;
+    if (++c->order_age >= 8) c->order_valid = c->deal_valid = false;
     rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
     if (rc == RT_OK) rearm_probe_if_changed(c);
     return rc;
@@ -865,7 +923,7 @@ RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
     if (c->multi) return rt::multi_set_camera(c, cam);
     if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) {
-        if (++c->order_age >= 8) c->order_valid = false;        // a moved camera: the order stays for a few frames, then is sorted again
+        if (++c->order_age >= 8) c->order_valid = c->deal_valid = false;        // a moved camera: order and deal stay for a few frames, then are sorted again
     }
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;
@@ -1327,6 +1385,13 @@ static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
 static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
+static int dbg_set_deal(rt_ctx *c, int v) {       // 0 = off; 8, 16, 32 = rows of a region
+    c->use_deal = v ? 1 : 0;
+    if (v) c->deal_rows = v;
+    c->deal_valid = false;
+    c->cost_valid = c->order_valid = false;
+    return RT_OK;
+}
 static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }
 
 // tuning knob (not part of the contract): 0 = automatic, 1 = free-running, n = gate of n lanes
@@ -1353,6 +1418,25 @@ RT_API int rt_debug_set_wg_waves(rt_ctx *c, int waves) {    // 0 = automatic, 1 
 RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour)
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     return dbg_apply(c, dbg_set_order, on);
+}
+RT_API int rt_debug_set_pixel_deal(rt_ctx *c, int rows) {     // 0: every wavefront renders its 8x8 square (the round-2 behaviour); 8 / 16 / 32: rows of a region
+    if (!c || (rows != 0 && rows != 8 && rows != 16 && rows != 32 && rows != 64 && rows != 128)) return fail(RT_ERR_ARG, "rows %d", rows);
+    return dbg_apply(c, dbg_set_deal, rows);
+}
+// the deal in use (valid = 0: none) -- per region 256 positions dy * 32 + dx in rank order -- and the per-pixel costs of the last launch
+RT_API int rt_debug_read_pixel_deal(rt_ctx *c, uint16_t *deal_out, size_t deal_cap, uint16_t *cost_out, size_t cost_cap, int *valid) {
+    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    const size_t regions = (size_t)((c->w + rt::kRegionW - 1) / rt::kRegionW) * (size_t)((c->local_rows + c->deal_rows - 1) / c->deal_rows);
+    const size_t per_region = (size_t)rt::kRegionW * c->deal_rows;
+    const size_t n_deal = regions * per_region < deal_cap ? regions * per_region : deal_cap, n_cost = (size_t)c->local_rows * c->w < cost_cap ? (size_t)c->local_rows * c->w : cost_cap;
+    if (deal_out && n_deal && c->d_deal) HIP_TRY(hipMemcpy(deal_out, c->d_deal, n_deal * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (cost_out && n_cost && c->d_pixel_cost) HIP_TRY(hipMemcpy(cost_out, c->d_pixel_cost, n_cost * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (valid) *valid = c->deal_valid ? c->deal_rows : 0;
+    return RT_OK;
 }
 // the tile order in use (valid = 0: none, tiles run in their natural order) and the per-tile costs of the last launch
 RT_API int rt_debug_read_tile_order(rt_ctx *c, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid) {
@@ -1383,11 +1467,7 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
 static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
 static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v; return RT_OK; }
-static int dbg_set_pool_rows(rt_ctx *c, int v) { c->pool_rows = v; c->cost_valid = c->order_valid = false; return RT_OK; }
-RT_API int rt_debug_set_pool_rows(rt_ctx *c, int rows) {
-    if (!c || rows < 8 || rows % 8 != 0 || rows > 2048) return fail(RT_ERR_ARG, "rows %d", rows);
-    return dbg_apply(c, dbg_set_pool_rows, rows);
-}
+
 RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     if (!c || steps < 1) return fail(RT_ERR_ARG, "steps %d", steps);
     return dbg_apply(c, dbg_set_walk_round, steps);

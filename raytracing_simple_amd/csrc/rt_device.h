@@ -15,6 +15,8 @@ constexpr int kTileH = 8;
 constexpr int kMaxDepth = 8;        // .cl:320 (depth > 7 ends the path)
 constexpr int kStatReplicas = 64;    // work counters are summed into 64 separate 64-byte lines
 constexpr int kMaxK2Table = 1024;   // running-average reciprocals kept in LDS up to this many passes per launch
+constexpr int kRegionW = 32;        // the pixels of a region of 32 x deal_rows pixels are dealt to its wavefronts by cost (LaunchParams::deal)
+constexpr int kMaxDealRows = 128;
 
 // Sphere tables in HBM, written once by rt_set_scene and staged into LDS by every workgroup.
 //   geom[i] = { p.x, p.y, p.z, rad*rad }      closest-hit / any-hit loops read only this
@@ -88,6 +90,13 @@ struct LaunchParams {
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
     const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order
     uint32_t *tile_cost;    // per tile: wall-clock ticks (10 ns) of its slowest wavefront, written by every launch (or null)
+    // Pixels dealt to wavefronts by cost (rt_order_pixels_kernel): the pixels of every region of 32 x deal_rows pixels, sorted
+    // by the rays the last launch traced for them, so that a wavefront renders 64 pixels of similar cost -- and of a similar
+    // kind: sky with sky, glass with glass -- instead of an 8x8 square that straddles them, and the four wavefronts of a
+    // workgroup finish together.  Rank r of a region goes to the region's 8-row band r / 256, wavefront (r / 64) % 4, lane r % 64.
+    const uint16_t *deal;   // [region][32 * deal_rows]: the region's pixels (dy * 32 + dx) in descending order of cost.  null = 8x8 squares
+    int deal_rows;          // rows of a region: 8, 16, 32, 64 or 128
+    uint16_t *pixel_cost;   // per local pixel (lrow * w + x): rays traced for it by this launch (closest-hit + shadow, saturated), or null
     // diagnostics build only (null in the product library): launch sequence number and the buffers the
     // instrumented instance logs device wall-clock intervals into (tools/gather_stress.py, tools/wave_timeline.py)
     unsigned long long *timelog;   // [seq][8]: min start, max end of the launch (s_memrealtime, 100 MHz), kind, tag, ...
@@ -98,7 +107,6 @@ struct LaunchParams {
     // offsets, and with them their scalar loads and SGPR allocation, are what they were without it
     int walk_steps;         // rt_walk.inc.h: pair steps a lane may take per loop trip
     int walk_round;         // ... and in a row before the leaf step of the lanes that hold a leaf
-    int pool_rows;          // ... rows of 32 pixels a workgroup hands out to its lanes (a multiple of 8; 8 = one pixel per lane)
     BvhTables bvh;
 };
 
@@ -142,7 +150,6 @@ enum InstanceFlags : uint8_t {
     kInstPersistent = 1,    // the grid only fills the machine; tiles come from the queue at counters[30]
     kInstNoTileCost = 2,    // neither reads the heavy-first order nor leaves per-tile costs
     kInstStaticCoop = 4,    // carries the cooperative any-hit mailbox (1.5 KiB of static LDS per wavefront)
-    kInstPixelPool = 8,     // a workgroup hands a pool of 32 x pool_rows pixels to its lanes; the packed pixels come from the pack kernel behind it
 };
 struct Instance {
     void (*fn)(const LaunchParams);

@@ -42,7 +42,6 @@ struct rt_ctx {
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
     int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
-    int pool_rows = 8;                  // ... rows of 32 pixels a workgroup of the walk hands out to its lanes (a multiple of 8)
     int walk_forced = 0;                // 0 = measured choice (below); diagnostics: 1 = the hierarchy whenever the scene has one
     // hierarchy or plain sweep?  Decided per scene by measurement (rt_api.hip launch()): each form once warm and once
     // timed between events, in the same tile order; whichever took less time per pass renders the rest
@@ -64,6 +63,11 @@ struct rt_ctx {
     bool cost_valid = false, order_valid = false;
     int order_age = 0;                  // scene / camera changes since the order was sorted (it is sorted again at 8)
     int use_order = 1;
+    // pixels dealt to wavefronts by cost (rt_device.h LaunchParams::deal): per-pixel rays of the last launch, the deal derived from them
+    uint16_t *d_pixel_cost = nullptr;
+    uint16_t *d_deal = nullptr;
+    bool pixel_cost_valid = false, deal_valid = false;
+    int use_deal = 1, deal_rows = 32;   // rows of a region (8, 16 or 32)
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
     uint32_t stage_cap = 0;             // records per slot
     int stage_next = 0;

@@ -81,8 +81,8 @@ static const Instance kFastInstances[] = {
     { fast_w1::rt_trace_fast_w1, "rt_trace_fast_w1", 1, kTabSweepLds, kRolePlain, 0 },
     { fast_coop::rt_trace_fast_coop, "rt_trace_fast_coop", 4, kTabSweepLds, kRoleCoop, kInstStaticCoop },
     { fast_coop_w1::rt_trace_fast_coop_w1, "rt_trace_fast_coop_w1", 1, kTabSweepLds, kRoleCoop, kInstStaticCoop },
-    { fast_pairs::rt_trace_fast_pairs, "rt_trace_fast_pairs", 4, kTabPairsLds, kRolePairs, kInstPixelPool },
-    { fast_pairs_g::rt_trace_fast_pairs_g, "rt_trace_fast_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, kInstPixelPool },
+    { fast_pairs::rt_trace_fast_pairs, "rt_trace_fast_pairs", 4, kTabPairsLds, kRolePairs, 0 },
+    { fast_pairs_g::rt_trace_fast_pairs_g, "rt_trace_fast_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, 0 },
     { fast_g::rt_trace_fast_g, "rt_trace_fast_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { fast::rt_sched_fast, "rt_sched_fast", 4, kTabSweepLds, kRoleNone, kInstNoTileCost },

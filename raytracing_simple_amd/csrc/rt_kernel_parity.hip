@@ -131,11 +131,11 @@ static const Instance kParityInstances[] = {
     { parity_w1::rt_trace_parity_w1, "rt_trace_parity_w1", 1, kTabSweepLds, kRolePlain, 0 },
     { parity_coop::rt_trace_parity_coop, "rt_trace_parity_coop", 4, kTabSweepLds, kRoleCoop, kInstStaticCoop },
     { parity_coop_w1::rt_trace_parity_coop_w1, "rt_trace_parity_coop_w1", 1, kTabSweepLds, kRoleCoop, kInstStaticCoop },
-    { parity_pairs::rt_trace_parity_pairs, "rt_trace_parity_pairs", 4, kTabPairsLds, kRolePairs, kInstPixelPool },
-    { parity_pairs_g::rt_trace_parity_pairs_g, "rt_trace_parity_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, kInstPixelPool },
+    { parity_pairs::rt_trace_parity_pairs, "rt_trace_parity_pairs", 4, kTabPairsLds, kRolePairs, 0 },
+    { parity_pairs_g::rt_trace_parity_pairs_g, "rt_trace_parity_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, 0 },
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
-    { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, kInstPixelPool },
+    { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },
     { parity_coop_census::rt_trace_parity_coop_census, "rt_trace_parity_coop_census", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

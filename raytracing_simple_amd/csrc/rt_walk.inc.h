@@ -215,8 +215,15 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int tid = threadIdx.x;
     __shared__ unsigned long long s_stat[5];
     __shared__ unsigned s_tile_cost;
+    __shared__ float4 s_cam[4];         // orig, dir | x, y | 1/w, 1/h
     if (tid < 5) s_stat[tid] = 0;
     if (tid == 5) s_tile_cost = 0u;
+    if (tid == 6) {
+        s_cam[0] = make_float4(P.cam.orig.x, P.cam.orig.y, P.cam.orig.z, P.cam.dir.x);
+        s_cam[1] = make_float4(P.cam.dir.y, P.cam.dir.z, P.cam.x.x, P.cam.x.y);
+        s_cam[2] = make_float4(P.cam.x.z, P.cam.y.x, P.cam.y.y, P.cam.y.z);
+        s_cam[3] = make_float4(0.f, 0.f, P.inv_w, P.inv_h);
+    }
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
 #if !RT_OPT_GLOBAL_TABLES
     {
@@ -240,39 +247,44 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         for (int i = tid; i < P.n_samples; i += kBlockThreads) s_k2[i] = rt_rcp((float)(P.first_sample + i) + 1.f);
     __syncthreads();
 
-    // ---- the workgroup's pool of pixels -----------------------------------------------------
-    // A workgroup owns 32 x P.pool_rows pixels (P.pool_rows / 8 rows of four 8x8 sub-tiles) and hands them to its lanes one
-    // by one, sub-tile after sub-tile, as lanes finish (an LDS counter; ballot + prefix count per wavefront): a lane whose
-    // pixel is done after 16 rays (sky) takes the next pixel instead of idling while its neighbours trace 60 (ground,
-    // glass) -- with one pixel per lane a third of the lane slots of this kernel belonged to finished pixels.  Which lane
-    // renders which pixel is invisible: a pixel's samples, draws and arithmetic are its own.  The packed pixels are written
-    // by the pack kernel behind this launch (rt_pack_*: the gamma conversion is three pow per pixel, too dear to run for
-    // a lane or two at a time inside the loop).
+    // ---- pixel of this lane (as in rt_trace.inc.h) ------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
     const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
     const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
     __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
-    __shared__ unsigned s_next;                 // pixels of the pool handed out so far
     if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
-    const int pool_x0 = tile_bx * kTileW, pool_row0 = tile_by * P.pool_rows;
-    if (tid == 0) s_next = 0u;
-    __syncthreads();
+    // the lane's pixel: its wavefront's 8x8 square, or the pixel of this workgroup's rank in the order by cost of the region
+    // (32 x P.deal_rows pixels) its tile lies in (P.deal; rt_trace.inc.h)
+    int x = tile_bx * kTileW + wave * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
+    if (P.deal) {
+        const int bands = P.deal_rows >> 3, region_y = tile_by / bands, band = tile_by - region_y * bands;
+        const unsigned id = P.deal[(size_t)(region_y * (int)gridDim.x + tile_bx) * (size_t)(kRegionW * P.deal_rows) + (unsigned)(band * 256 + tid)];
+        x = tile_bx * kTileW + (int)(id & 31u);
+        lrow = region_y * P.deal_rows + (int)(id >> 5);
+    }
+    const int rtile = lrow / P.tile_rows;
+    const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
+    const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
 
-    // the pixel in hand (none yet: the first shade phase hands every wavefront a sub-tile)
-    bool has_pixel = false;
-    float fx = 0.f, fy = 0.f;                   // its image coordinates, as the camera ray uses them (.cl:520-521)
-    uint32_t q = 0;                             // its number in the pool
     uint32_t s0 = 0, s1 = 0;
     V3 acc = mk(0.f, 0.f, 0.f);
-    int s = P.first_sample, s_end = P.first_sample;
-    uint32_t c_samples = 0;
+    int s = P.first_sample;
+    const int s_end = valid ? P.first_sample + P.n_samples : P.first_sample;
+    if (valid) {
+        const size_t gid = (size_t)y * (size_t)P.w + (size_t)x;             // .cl:560-563
+        const size_t ci = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x;  // .cl:579
+        const uint2 sd = *reinterpret_cast<const uint2 *>(P.seeds_in + 2 * gid);
+        s0 = sd.x;
+        s1 = sd.y;
+        if (P.first_sample > 0) acc = mk(P.colors[3 * ci], P.colors[3 * ci + 1], P.colors[3 * ci + 2]);
+    }
 
     uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
     unsigned long long c_tests = 0;
 
     // ---- lane state ---------------------------------------------------------------------------
-    enum { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3, kDone = 4 };
+    enum { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3 };
     int st = kNew;
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);     // the ray in flight: the path's, or the shadow ray (o = hit point)
     V3 thr = mk(1.f, 1.f, 1.f), rad = mk(0.f, 0.f, 0.f);
@@ -312,7 +324,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #endif
 
     for (;;) {
-        if (st == kDone) break;
+        if (st == kNew && s >= s_end) break;
 #if RT_OPT_WALK == 2
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
         const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
@@ -488,71 +500,19 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 st = kNew;
                 start_closest = false;
             }
-            if (st == kNew && !start_closest && s >= s_end) {
-                // ---- the pixel in hand is complete (or there is none yet): .cl:580-599 for it, then the next one of the pool ----
-                // (the arguments only this block needs are read from the kernel-argument segment here, through the scalar cache,
-                // instead of living in scalar registers through the loop)
-                const __attribute__((address_space(4))) LaunchParams *G =
-                    (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-                asm volatile("; pool arguments re-read" : "+s"(G));
-                const int tr = G->tile_rows;
-                if (has_pixel) {
-                    const int sub = (int)(q >> 6), i = (int)(q & 63u);
-                    const int x = pool_x0 + (sub & 3) * 8 + (i & 7), lrow = pool_row0 + (sub >> 2) * 8 + (i >> 3);
-                    const int rtile = lrow / tr, y = (rtile * G->nranks + G->rank) * tr + (lrow - rtile * tr);
-                    const size_t gid = (size_t)y * (size_t)G->w + (size_t)x;
-                    const size_t ci = (size_t)(G->h - y - 1) * (size_t)G->w + (size_t)x;
-                    G->colors[3 * ci] = acc.x;
-                    G->colors[3 * ci + 1] = acc.y;
-                    G->colors[3 * ci + 2] = acc.z;
-                    *reinterpret_cast<uint2 *>(G->seeds + 2 * gid) = make_uint2(s0, s1);
-                    c_samples += (uint32_t)G->n_samples;
-                    has_pixel = false;
-                }
-                const unsigned long long takers = __builtin_amdgcn_ballot_w64(true);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(takers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)takers, 0u));
-                uint32_t base = 0;
-                if (rank == 0) base = atomicAdd(&s_next, (unsigned)__popcll(takers));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);          // (rank 0 is the first active lane)
-                q = base + rank;
-                if (q >= (uint32_t)(kTileW * G->pool_rows)) {
-                    st = kDone;                         // the pool is handed out: this lane retires
-                } else {
-                    const int sub = (int)(q >> 6), i = (int)(q & 63u);
-                    const int x = pool_x0 + (sub & 3) * 8 + (i & 7), lrow = pool_row0 + (sub >> 2) * 8 + (i >> 3);
-                    const int rtile = lrow / tr, y = (rtile * G->nranks + G->rank) * tr + (lrow - rtile * tr);
-                    s = G->first_sample;
-                    s_end = s;                          // (a pixel of the pool beyond the image: nothing to render, the next phase takes another)
-                    if ((x < G->w) && (lrow < G->local_rows) && (y < G->h)) {
-                        const size_t gid = (size_t)y * (size_t)G->w + (size_t)x;             // .cl:560-563
-                        const size_t ci = (size_t)(G->h - y - 1) * (size_t)G->w + (size_t)x;  // .cl:579
-                        const uint2 sd = *reinterpret_cast<const uint2 *>(G->seeds_in + 2 * gid);
-                        s0 = sd.x;
-                        s1 = sd.y;
-                        acc = mk(0.f, 0.f, 0.f);
-                        if (G->first_sample > 0) acc = mk(G->colors[3 * ci], G->colors[3 * ci + 1], G->colors[3 * ci + 2]);
-                        fx = (float)x;
-                        fy = (float)y;
-                        s_end = G->first_sample + G->n_samples;
-                        has_pixel = true;
-                    }
-                }
-            }
             if (st == kNew && !start_closest && s < s_end) {
-                // ---- camera ray, .cl:494-549 (camera and 1/w, 1/h re-read from the kernel-argument segment: rt_trace.inc.h) ----
-                const __attribute__((address_space(4))) LaunchParams *cp =
-                    (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
-                asm volatile("; camera re-read" : "+s"(cp));
-                const float inv_w = cp->inv_w, inv_h = cp->inv_h;
-                const V3 cam_o = mk(cp->cam.orig.x, cp->cam.orig.y, cp->cam.orig.z);
-                const V3 cam_d = mk(cp->cam.dir.x, cp->cam.dir.y, cp->cam.dir.z);
-                const V3 cam_x = mk(cp->cam.x.x, cp->cam.x.y, cp->cam.x.z);
-                const V3 cam_y = mk(cp->cam.y.x, cp->cam.y.y, cp->cam.y.z);
+                // ---- camera ray, .cl:494-549.  The camera (12 floats) and 1/w, 1/h come from LDS here, once per sample
+                // (broadcast reads), instead of occupying 14 scalar registers through the loop: the loop overfills the scalar
+                // file and its spills go to lanes of a vector register the allocator then lacks ----
+                const float4 c0 = s_cam[0], c1 = s_cam[1], c2 = s_cam[2], c3 = s_cam[3];
+                const float inv_w = c3.z, inv_h = c3.w;
+                const V3 cam_o = mk(c0.x, c0.y, c0.z), cam_d = mk(c0.w, c1.x, c1.y);
+                const V3 cam_x = mk(c1.z, c1.w, c2.x), cam_y = mk(c2.y, c2.z, c2.w);
                 float j1 = next_random_centred(s0, s1);
                 float j2 = next_random_centred(s0, s1);
                 c_draws += 2;
-                float kcx = (fx + j1) * inv_w - 0.5f;
-                float kcy = (fy + j2) * inv_h - 0.5f;
+                float kcx = ((float)x + j1) * inv_w - 0.5f;
+                float kcy = ((float)y + j2) * inv_h - 0.5f;
                 V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
                            cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
                 o = add(scale(rd, 0.1f), cam_o);
@@ -593,12 +553,31 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 #endif
 
-    // ---- epilogue: the work counters (every pixel was written when it was finished) ----
+    // ---- epilogue: as in rt_trace.inc.h ----
     const __attribute__((address_space(4))) LaunchParams *qp =
         (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("; epilogue arguments re-read" : "+s"(qp));
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
-    uint32_t n_done = c_samples;
+    if (valid && Q.n_samples > 0) {
+        int xe = x, ye = y, le = lrow;
+        asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
+        const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;
+        const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;
+        float *colors = Q.colors;
+        colors[3 * ci] = acc.x;
+        colors[3 * ci + 1] = acc.y;
+        colors[3 * ci + 2] = acc.z;
+        if (!Q.skip_pixels)
+            Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =
+                (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
+        *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);
+        uint16_t *pc = Q.pixel_cost;
+        if (pc) {
+            const uint32_t rays = c_closest + c_shadow;
+            pc[(size_t)le * (size_t)Q.w + (size_t)xe] = (uint16_t)(rays < 65535u ? rays : 65535u);
+        }
+    }
+    uint32_t n_done = valid ? (uint32_t)Q.n_samples : 0u;
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);

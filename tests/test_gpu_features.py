@@ -265,9 +265,10 @@ def test_rt_render_second_call_costs_little_more_than_its_kernel():
 
 # ---- heavy tiles first -------------------------------------------------------------------------------------
 def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_bit():
-    """The second long launch of one scene and camera walks the 32x8 tiles in descending order of the cost the
-    first one measured.  Scheduling only: pixels, colour plane, seeds and counters equal the oracle either way;
-    a new camera or scene drops the order until costs exist again."""
+    """Long launches of one scene and camera walk the tiles in descending order of the cost the launch before measured (the
+    third one on: the second deals the pixels of every region to its wavefronts by cost, which changes what a tile is).
+    Scheduling only: pixels, colour plane, seeds and counters equal the oracle either way; a new scene drops the order until
+    costs exist again."""
     lib = api.load_library(diag=True)
     w, h, spp = 200, 120, 8
     sph, orig, target = scenes.demo_plus(16)
@@ -288,9 +289,12 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         order, cost, valid = order_state(ctx)
         n8 = ((w + 7) // 8) * ((h + 7) // 8)                                   # 16 spheres: single-wavefront workgroups, 8x8 tiles
         assert not valid and len(cost) == n8 and cost[:n8].min() > 0
-        for _ in range(2):
-            ctx.reset()
-            _assert_same(_state(ctx, ctx.render_pass(spp)), want)              # heavy first
+        ctx.reset()
+        _assert_same(_state(ctx, ctx.render_pass(spp)), want)                  # pixels dealt by cost from now on: tile costs are measured afresh
+        _, cost, valid = order_state(ctx)
+        assert not valid and cost[:n8].min() > 0
+        ctx.reset()
+        _assert_same(_state(ctx, ctx.render_pass(spp)), want)                  # heavy first
         order, cost2, valid = order_state(ctx)
         assert valid and sorted(order.tolist()) == list(range(len(order)))
         capped = np.minimum(cost, 0x1FFFFF).astype(np.uint64)
@@ -466,3 +470,88 @@ def test_mixed_device_lists_are_refused():
     with pytest.raises(api.RtError) as e:
         api.RtContext(64, 48, devices=[0, 1, 0])
     assert e.value.code == -1 and "mixed" in str(e.value)
+
+
+def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
+    """Every launch leaves the rays it traced per pixel; the next long launch sorts the pixels of each region (32 x 8, 16 or 32
+    rows) by them and hands rank r to the region's band r / 256, wavefront (r / 64) % 4, lane r % 64 (rt_order_pixels_kernel).
+    The deal is a permutation of every whole region in descending order of cost, regions that hang over the image edge keep
+    their 8x8 squares, and frames, colour plane, seeds and counters are the oracle's with it and without -- for both
+    workgroup shapes, the hierarchy walk, ragged images and a sharded context."""
+    lib = api.load_library(diag=True)
+
+    def deal_state(ctx, w, rows, deal_rows):
+        regions = ((w + 31) // 32) * ((rows + deal_rows - 1) // deal_rows)
+        deal = np.zeros(regions * 32 * deal_rows, np.uint16)
+        cost = np.zeros(rows * w, np.uint16)
+        valid = C.c_int()
+        api._check(lib.rt_debug_read_pixel_deal(ctx._h, deal.ctypes.data_as(C.c_void_p), deal.size, cost.ctypes.data_as(C.c_void_p), cost.size,
+                                                C.byref(valid)), lib)
+        return deal.reshape(regions, 32 * deal_rows), cost.reshape(rows, w), valid.value
+
+    def identity(deal_rows):
+        r = np.arange(32 * deal_rows)
+        b, q, l = r >> 8, (r >> 6) & 3, r & 63
+        return (((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7))).astype(np.uint16)
+
+    cases = [(lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32),                # single-wavefront workgroups, ragged: 200 = 6 * 32 + 8, 120 = 3 * 32 + 24
+             (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 8),
+             (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 256, 64, 8, {"wg": 4}, 16),    # four-wavefront workgroups
+             (lambda: scenes.random_spheres(300), 160, 96, 8, {"walk": 1}, 32),  # the hierarchy walk
+             (lambda: scenes.mirror_box(64), 96, 72, 8, {}, 32)]                 # cooperative any-hit
+    for maker, w, h, spp, knobs, deal_rows in cases:
+        sph, orig, target = maker()
+        cam = host.compute_camera(orig, target, w, h)
+        want = O.render(sph, cam, w, h, spp)
+        with api.RtContext(w, h, diag=True) as ctx:
+            if "wg" in knobs:
+                lib.rt_debug_set_wg_waves(ctx._h, knobs["wg"])
+            if "walk" in knobs:
+                ctx._check(lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+                ctx._check(lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
+            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, deal_rows))
+            ctx.set_scene(sph); ctx.set_camera(cam)
+            _assert_same(_state(ctx, ctx.render_pass(spp)), want)              # 8x8 squares; leaves the cost of every pixel
+            deal, cost, valid = deal_state(ctx, w, h, deal_rows)
+            st = ctx.stats()
+            assert not valid and int(cost.astype(np.int64).sum()) == st["closest_rays"] + st["shadow_rays"]
+            for _ in range(3):
+                ctx.reset()
+                _assert_same(_state(ctx, ctx.render_pass(spp)), want)          # dealt by cost (the same frame costs the same again)
+            deal, cost2, valid = deal_state(ctx, w, h, deal_rows)
+            assert valid == deal_rows and np.array_equal(cost2, cost)
+            regions_x = (w + 31) // 32
+            whole = 0
+            for r in range(deal.shape[0]):
+                ry, rx = divmod(r, regions_x)
+                if rx * 32 + 32 <= w and ry * deal_rows + deal_rows <= h:
+                    whole += 1
+                    assert sorted(deal[r].tolist()) == list(range(32 * deal_rows)), r
+                    c = cost[ry * deal_rows + (deal[r] >> 5).astype(int), rx * 32 + (deal[r] & 31).astype(int)].astype(int)
+                    assert np.all(np.diff(c) <= 0), r                          # heaviest pixel first
+                else:
+                    assert np.array_equal(deal[r], identity(deal_rows)), r     # a region over the edge keeps its squares
+            assert whole > 0
+            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, 0))                  # knob: squares again
+            ctx.reset()
+            _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+            # progressive passes on a dealt context, and a pass count that changes the launch shape
+            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, deal_rows))
+            ctx.reset(); ctx.render_pass(spp); ctx.reset()
+            ctx.render_pass(3); ctx.render_pass(9); ctx.render_pass(4)
+            _assert_same(_state(ctx, ctx.read_pixels()), O.render(sph, cam, w, h, 16))
+    # sharded contexts deal their own rows
+    sph, orig, target = scenes.demo_plus(16)
+    w, h, spp = 200, 120, 8
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    parts = []
+    for r in range(3):
+        with api.RtContext(w, h, rank=r, nranks=3, diag=True) as ctx:
+            ctx.set_scene(sph); ctx.set_camera(cam)
+            for _ in range(3):
+                ctx.reset(); px = ctx.render_pass(spp)
+            assert deal_state(ctx, w, ctx.local_rows, 32)[2] == 32
+            parts.append(px)
+    from raytracing_simple_amd import dist as rdist
+    assert np.array_equal(rdist.assemble_numpy(parts, h, w, 3, 8), want["pixels"])

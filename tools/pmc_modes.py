@@ -11,8 +11,6 @@ maker, w, h, spp = CONFIGS[cname]
 sph, orig, target = maker()
 cam = host.compute_camera(orig, target, w, h)
 with api.RtContext(w, h, diag=any(m >= 100 for m in modes)) as ctx:
-    if os.environ.get("RT_POOL_ROWS"):             # the walk kernel's pixel pool (diagnostics library: give a kernel symbol as mode)
-        ctx._check(ctx._lib.rt_debug_set_pool_rows(ctx._h, int(os.environ["RT_POOL_ROWS"])))
     ctx.set_scene(sph); ctx.set_camera(cam)
     for m in modes:
         ctx.set_mode(m); ctx.reset(); ctx.render_pass(spp, copy=False)
