@@ -181,6 +181,12 @@ def self_launch(args):
     import socket
     import torch                      # device_count() does not initialise the GPU on this image
     have = torch.cuda.device_count()
+    if os.environ.get("RT_BENCH_SINGLE_DEVICE") == "1" and args.gpus > 3 and os.environ.get("RT_REHEARSAL_OVERSUBSCRIBE") != "1":
+        # the platform precondition of DESIGN.md section 3: more processes' hardware queues on ONE GPU than its scheduler keeps
+        # resident (four ranks of this bench) and a dispatch can lose its writes -- a wrong frame there is not a library bug
+        raise SystemExit(f"bench.py --gpus {args.gpus} with RT_BENCH_SINGLE_DEVICE=1: at most 3 ranks are rehearsed on one device (queue "
+                         "oversubscription loses writes on this driver stack: DESIGN.md section 3, profiles/r02_stale_seed/); "
+                         "RT_REHEARSAL_OVERSUBSCRIBE=1 overrides, for studying exactly that")
     if have < args.gpus and os.environ.get("RT_BENCH_SINGLE_DEVICE") != "1":
         raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} HIP device(s); nothing is measured on fewer "
                          "GPUs than asked for (RT_BENCH_SINGLE_DEVICE=1 rehearses the ranks on one device, with gloo)")

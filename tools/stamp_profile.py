@@ -15,20 +15,27 @@ from tools.ab_bench import CONFIGS  # noqa: E402
 NAMES = ["camera ray", "closest sweep", "hit point/normal", "light sample", "shadow sweep", "light contrib",
          "diffuse bounce", "spec/refr", "loop trip", "accumulate", "closest roots", "shadow roots"]
 
-for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2").split(","):
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+for cname in (args[0] if args else "c2").split(","):
     maker, w, h, spp = CONFIGS[cname]
     sph, orig, target = maker()
     cam = host.compute_camera(orig, target, w, h)
     with api.RtContext(w, h, diag=True) as ctx:
         ctx.set_scene(sph)
         ctx.set_camera(cam)
-        ctx.set_mode(api.instance_mode(sys.argv[2] if len(sys.argv) > 2 else ("rt_trace_parity_coop_census" if len(sph) >= 12 else "rt_trace_parity_census")))
+        if "--no-deal" in sys.argv:
+            api.load_library(diag=True).rt_debug_set_pixel_deal(ctx._h, 0)
+        for _ in range(3):                  # the shipped instance first: per-pixel costs, the deal of pixels by cost, the heavy-first order
+            ctx.reset()
+            ctx.render_pass(spp, copy=False)
+        ctx.reset()
+        ctx.set_mode(api.instance_mode(args[1] if len(args) > 1 else ("rt_trace_parity_coop_census" if len(sph) >= 12 else "rt_trace_parity_census")))
         ctx.render_pass(spp, copy=False)
         st = ctx.stats()
         buf = (C.c_ulonglong * 24)()
         api.load_library(diag=True).rt_debug_counters(ctx._h, buf)
         v = list(buf)[:12]
-        print(f"{cname}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
+        print(f"{cname}{' (no deal: 8x8 squares)' if '--no-deal' in sys.argv else ' (pixels dealt by cost)'}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
               f"active lanes per execution, executions per sample-wave")
         waves_samples = st["samples"] / 64.0
         for n, c in zip(NAMES, v):
