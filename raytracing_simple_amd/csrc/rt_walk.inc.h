@@ -104,6 +104,7 @@ RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
 // goes on looking in the next round instead of keeping the others waiting (the number of steps to the next leaf has
 // a long tail).  cen (census instances only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps.
 constexpr uint32_t kWalkDone = 0xffffffffu;
+constexpr uint32_t kWalkIndexOpen = 0xfffffffeu;        // closest-hit walks: the best slot's scene index has not been read yet
 RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
                        int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen) {
@@ -154,14 +155,27 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                     const HitRoots hr = hit_roots(p[k]);
                     // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
                     // shadow ray (.cl:234-247): the lowest scene index that blocks
-                    if (hr.hit && (shadow ? hr.t < w_far : hr.t <= w_far)) {
-                        const uint32_t ix = index[sl + k];
-                        if (shadow) {
+                    // The scene index of a slot lies in HBM / L2.  A shadow ray needs it for every blocker (the lowest one
+                    // is the answer and prunes subtrees); a closest-hit ray only to break an exact tie -- a strictly
+                    // nearer hit just takes the slot, and its index is read once, when the walk is over (kWalkIndexOpen).
+                    if (shadow) {
+                        if (hr.hit && hr.t < w_far) {
+                            const uint32_t ix = index[sl + k];
                             w_idx = ix < w_idx ? ix : w_idx;
-                        } else if (hr.t < w_far || ix < w_idx) {
+                        }
+                    } else if (hr.hit) {
+                        if (hr.t < w_far) {
                             w_far = hr.t;
                             w_slot = sl + (uint32_t)k;
-                            w_idx = ix;
+                            w_idx = kWalkIndexOpen;
+                        } else if (hr.t == w_far) {                     // the loader doubles spheres: exact ties are real
+                            const uint32_t ix = index[sl + k];
+                            const uint32_t have = w_idx == kWalkIndexOpen ? index[w_slot] : w_idx;
+                            w_idx = have;
+                            if (ix < have) {
+                                w_slot = sl + (uint32_t)k;
+                                w_idx = ix;
+                            }
                         }
                     }
                 }
@@ -370,7 +384,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     path_done = true;                                              // miss, .cl:327-330
                 } else {
                     const float4 ge = s_slots[w_slot];
-                    const uint32_t id = w_idx;
+                    const uint32_t id = w_idx == kWalkIndexOpen ? s_index[w_slot] : w_idx;
                     float4 em4, co4;
                     if (P.mat_in_lds) {
                         em4 = s_emis[id];
@@ -533,7 +547,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #endif
                 w_far = t;
                 w_slot = slot;
-                w_idx = (t < 1e20f) ? s_index[slot] : 0xffffffffu;
+                w_idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;       // (the always-list winner's index is read if it stays the winner)
                 R = bvh_ray(s_hdr, o, d);
                 cur = root_ref;
                 sp = 0;
@@ -655,9 +669,10 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
             sweep_closest(s_slots, n_always, o, d, t, slot, roots);
             w_far = t;
             w_slot = slot;
-            w_idx = (t < 1e20f) ? g_index[slot] : 0xffffffffu;
+            w_idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;
             walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, false, 0x7fffffff, 3, cur, sp, w_far, w_idx,
                        w_slot, nullptr);
+            if (w_idx == kWalkIndexOpen) w_idx = g_index[w_slot];
             float t_ref = 1e20f;
             uint32_t id_ref = 0;
             sweep_closest(P.scene.geom, n, o, d, t_ref, id_ref, roots);

@@ -60,7 +60,7 @@ def main():
             ctx.set_scene(sph)
             ctx.set_camera(cam)
             times = {v: [] for v in variants}
-            pix, stats = {}, {}
+            pix, stats, kernels = {}, {}, {}
             lib = api.load_library(diag=True)
             if args.mat_lds >= 0:
                 lib.rt_debug_set_mat_lds_limit(ctx._h, args.mat_lds)
@@ -83,6 +83,7 @@ def main():
                     ctx.reset()
                     px = ctx.render_pass(spp)
                     st = ctx.stats()
+                    kernels[v] = ctx.last_kernel
                     if r == 0:
                         pix[v], stats[v] = px, st            # warm-up round: keep outputs only
                     else:
@@ -94,7 +95,7 @@ def main():
                 rays = st["samples"] + st["shadow_rays"]
                 med, mn = statistics.median(times[v]), min(times[v])
                 same = bool(np.array_equal(pix[v], base))
-                print(json.dumps({"config": cname, "mode": m, "gate": g, "persist": q, "heavy_first": o, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                print(json.dumps({"config": cname, "mode": m, "kernel": kernels[v], "gate": g, "persist": q, "heavy_first": o, "ms_median": round(med, 4), "ms_min": round(mn, 4),
                                   "Gray_s": round(rays / med / 1e6, 2), "same_as_first": same,
                                   "psnr_vs_first": None if same else round(host.psnr(pix[v], base), 2),
                                   "tests_per_sample": round(st["sphere_tests"] / st["samples"], 2),

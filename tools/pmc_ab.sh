@@ -8,14 +8,4 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/p" -- python3 $R/tools/pmc_modes.py $CFG $MODES > "$OUT/p.log" 2>&1 || { tail -5 "$OUT/p.log"; exit 1; }
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, os
-for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
-    acc = {}
-    for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("rt_trace"):
-            k = (r["Kernel_Name"], r["Counter_Name"])
-            acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"])
-    for k in sorted(acc):
-        print(f"{k[0]:28s} {k[1]:24s} {acc[k]:.6g}")
-PY
+python3 $R/tools/pmc_last.py "$OUT"

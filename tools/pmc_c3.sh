@@ -15,14 +15,4 @@ pass() {
 pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU && \
 pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS_F32 && \
 pass sq4 SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, os
-out = sys.argv[1]
-acc = {}
-for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("rt_trace"):
-            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-for k in sorted(acc):
-    print(f"{k:28s} {acc[k]:.6g}")
-PY
+python3 $R/tools/pmc_last.py "$OUT"

@@ -10,9 +10,14 @@ modes = [int(m) if m.lstrip("-").isdigit() else api.instance_mode(m) for m in sy
 maker, w, h, spp = CONFIGS[cname]
 sph, orig, target = maker()
 cam = host.compute_camera(orig, target, w, h)
-with api.RtContext(w, h, diag=any(m >= 100 for m in modes)) as ctx:
+with api.RtContext(w, h, diag=any(m >= 100 for m in modes) or bool(os.environ.get('RT_NO_DEAL'))) as ctx:
     ctx.set_scene(sph); ctx.set_camera(cam)
+    warm = int(os.environ.get("RT_PMC_WARM", "3"))      # frames before the measured one: per-pixel costs, the deal, the heavy-first order
+    if os.environ.get("RT_NO_DEAL"):
+        ctx._check(ctx._lib.rt_debug_set_pixel_deal(ctx._h, 0))
     for m in modes:
-        ctx.set_mode(m); ctx.reset(); ctx.render_pass(spp, copy=False)
+        ctx.set_mode(m)
+        for _ in range(warm + 1):
+            ctx.reset(); ctx.render_pass(spp, copy=False)
         st = ctx.stats()
         print("MODE", m, st, flush=True)
