@@ -114,6 +114,11 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
     out["traffic"] = None
     if pm and pm.get("kernel", kernel) == kernel:
         out["traffic"] = pm.get("hbm_bytes_per_launch")
+        if out["traffic"] and out["traffic"] > 2 * alg_bytes:
+            out["traffic_note"] = ("above the algorithmic bytes on purpose: pixels are dealt to wavefronts by cost, so a wavefront's 64 pixels lie "
+                                   "scattered over a 32x32 region and its per-pixel loads and stores (seeds 8 B, colour 12 B, pixel 4 B, cost 2 B) go out "
+                                   "as single words instead of 32-96 byte segments; dealing runs of 8 adjacent pixels brings the traffic back to 1.1x "
+                                   "algorithmic and is 3 % slower (profiles/r03j_*): the kernel is VALU-bound at ~1 % of the HBM peak either way")
         if pm.get("valu_insts_per_launch"):
             # what the VALU actually issues (PMC of the committed profile, same command): the time its instructions
             # need at full issue rate, and how much of this run's kernel time that is

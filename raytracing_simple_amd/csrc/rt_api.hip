@@ -147,12 +147,16 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
 
 // The deal of a region's pixels to its wavefronts (rt_device.h LaunchParams::deal): ONE workgroup per region of 32 x deal_rows
 // pixels sorts them by the cost the last launch left for them (rays traced; descending, ties by position) -- a bitonic sort
-// in LDS, one key per thread -- and writes their positions (dy * 32 + dx) in that order.  A region that is not wholly inside
-// the rendered rows keeps the 8x8 squares (its workgroups do not all exist: ranks must not move out of their square).
+// in LDS -- and writes their positions (dy * 32 + dx) in that order.  What is sorted are runs of `group` horizontally adjacent
+// pixels (1, 2, 4 or 8; key = the run's summed cost): a run stays on adjacent lanes, so the launch's loads and stores of seeds,
+// colours and pixels still come in segments of 8 * group .. 12 * group bytes instead of single words (with single pixels the
+// launch wrote 3.5 times the bytes it produces).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
+// (its workgroups do not all exist: ranks must not move out of their square).
 __global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *__restrict__ cost, uint16_t *__restrict__ deal, int w, int rows,
-                                                              int regions_x, int deal_rows) {
+                                                              int regions_x, int deal_rows, int group) {
     __shared__ uint32_t s_key[rt::kRegionW * rt::kMaxDealRows];
-    const int tid = threadIdx.x, nt = blockDim.x, n = rt::kRegionW * deal_rows;       // n: a power of two, nt = min(n, 1024)
+    const int tid = threadIdx.x, nt = blockDim.x, n = rt::kRegionW * deal_rows;       // n pixels: a power of two
+    const int ng = n / group;                                                          // runs: a power of two as well
     const int region = blockIdx.x, ry = region / regions_x, rx = region - ry * regions_x;
     const int x0 = rx * rt::kRegionW, y0 = ry * deal_rows;
     const bool whole = (x0 + rt::kRegionW <= w) && (y0 + deal_rows <= rows);
@@ -164,15 +168,16 @@ __global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *_
         }
         return;
     }
-    for (int i = tid; i < n; i += nt) {
-        const int dx = i & 31, dy = i >> 5;
-        const uint32_t c_ = cost[(size_t)(y0 + dy) * (size_t)w + (size_t)(x0 + dx)];
-        s_key[i] = (c_ << 12) | (uint32_t)(4095 - i);       // descending sort of the key = heaviest first, then lowest position
+    for (int i = tid; i < ng; i += nt) {
+        const int p0 = i * group, dx = p0 & 31, dy = p0 >> 5;                          // (a run never crosses a row: 32 % group == 0)
+        uint32_t c_ = 0;
+        for (int j = 0; j < group; ++j) c_ += cost[(size_t)(y0 + dy) * (size_t)w + (size_t)(x0 + dx + j)];
+        s_key[i] = (c_ << 12) | (uint32_t)(4095 - i);       // descending sort of the key = heaviest run first, then lowest position
     }
     __syncthreads();
-    for (int k = 2; k <= n; k <<= 1) {
+    for (int k = 2; k <= ng; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n; i += nt) {
+            for (int i = tid; i < ng; i += nt) {
                 const int l = i ^ j;
                 if (l > i) {
                     const uint32_t a = s_key[i], b = s_key[l];
@@ -182,7 +187,10 @@ __global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *_
             __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += nt) deal[(size_t)region * n + i] = (uint16_t)(4095u - (s_key[i] & 4095u));
+    for (int i = tid; i < ng; i += nt) {
+        const uint32_t p0 = (4095u - (s_key[i] & 4095u)) * (uint32_t)group;
+        for (int j = 0; j < group; ++j) deal[(size_t)region * n + (size_t)i * group + j] = (uint16_t)(p0 + (uint32_t)j);
+    }
 }
 
 // rt_deinterleave_rows: full[y] = row (t/n)*tile_rows + y%tile_rows of rank t%n's block, t = y/tile_rows.
@@ -479,7 +487,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
             if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 8) {
                 const int regions_x = (c->w + rt::kRegionW - 1) / rt::kRegionW, regions_y = (c->local_rows + c->deal_rows - 1) / c->deal_rows;
                 hipLaunchKernelGGL(rt_order_pixels_kernel, dim3((unsigned)(regions_x * regions_y)), dim3((unsigned)std::min(rt::kRegionW * c->deal_rows, 1024)), 0, stream,
-                                   c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows);
+                                   c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows, c->deal_group);
                 HIP_TRY(hipGetLastError());
                 c->deal_valid = true;
                 c->cost_valid = c->order_valid = false;
@@ -1385,9 +1393,10 @@ static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
 static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
-static int dbg_set_deal(rt_ctx *c, int v) {       // 0 = off; 8, 16, 32 = rows of a region
+static int dbg_set_deal(rt_ctx *c, int v) {       // 0 = off; rows of a region | pixels of a run << 8
     c->use_deal = v ? 1 : 0;
-    if (v) c->deal_rows = v;
+    if (v & 255) c->deal_rows = v & 255;
+    if (v >> 8) c->deal_group = v >> 8;
     c->deal_valid = false;
     c->cost_valid = c->order_valid = false;
     return RT_OK;
@@ -1419,8 +1428,10 @@ RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in thei
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     return dbg_apply(c, dbg_set_order, on);
 }
-RT_API int rt_debug_set_pixel_deal(rt_ctx *c, int rows) {     // 0: every wavefront renders its 8x8 square (the round-2 behaviour); 8 / 16 / 32: rows of a region
-    if (!c || (rows != 0 && rows != 8 && rows != 16 && rows != 32 && rows != 64 && rows != 128)) return fail(RT_ERR_ARG, "rows %d", rows);
+RT_API int rt_debug_set_pixel_deal(rt_ctx *c, int rows) {     // 0: every wavefront renders its 8x8 square (the round-2 behaviour); else rows of a region (8 .. 128) | pixels of a run (1, 2, 4, 8; 0 = keep) << 8
+    const int r = rows & 255, g = rows >> 8;
+    if (!c || rows < 0 || (rows != 0 && r != 8 && r != 16 && r != 32 && r != 64 && r != 128) || (g != 0 && g != 1 && g != 2 && g != 4 && g != 8))
+        return fail(RT_ERR_ARG, "rows %d, run %d", r, g);
     return dbg_apply(c, dbg_set_deal, rows);
 }
 // the deal in use (valid = 0: none) -- per region 256 positions dy * 32 + dx in rank order -- and the per-pixel costs of the last launch

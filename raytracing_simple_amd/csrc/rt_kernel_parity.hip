@@ -115,21 +115,6 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS parity_lockstep        /* A/B: the four wavefronts of a workgroup in lockstep per loop trip (what a lane exchange between them would need) */
-#define RT_KERNEL_NAME rt_trace_parity_lockstep
-#define RT_OPT_LOCKSTEP 1
-#define RT_OPT_MINWAVES 6
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_coop_lockstep
-#define RT_KERNEL_NAME rt_trace_parity_coop_lockstep
-#define RT_OPT_LOCKSTEP 1
-#define RT_OPT_COOP 1
-#define RT_OPT_MINWAVES 6
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
 #define RT_NS parity_tl              /* the shipped shape + device wall-clock logging (P.timelog / P.wavelog) */
 #define RT_KERNEL_NAME rt_trace_parity_tl
 #define RT_OPT_TIMELOG 1
@@ -160,8 +145,6 @@ static const Instance kParityInstances[] = {
     { parity_persist_coop::rt_trace_parity_persist_coop, "rt_trace_parity_persist_coop", 4, kTabSweepLds, kRolePersistCoop,
       kInstPersistent | kInstNoTileCost | kInstStaticCoop },
     { parity_tl::rt_trace_parity_tl, "rt_trace_parity_tl", 4, kTabSweepLds, kRoleTimelog, 0 },
-    { parity_lockstep::rt_trace_parity_lockstep, "rt_trace_parity_lockstep", 4, kTabSweepLds, kRoleNone, 0 },
-    { parity_coop_lockstep::rt_trace_parity_coop_lockstep, "rt_trace_parity_coop_lockstep", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
 #endif
 };
 

@@ -13,4 +13,3 @@
 #undef RT_OPT_PERSIST
 #undef RT_OPT_STAMPS
 #undef RT_OPT_TIMELOG
-#undef RT_OPT_LOCKSTEP

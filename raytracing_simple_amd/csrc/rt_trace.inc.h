@@ -50,8 +50,6 @@
 //   RT_OPT_PERSIST        persistent wavefronts: the grid only fills the machine, each wavefront pulls 8x8 pixel tiles
 //                         from a global queue and hands their pixels to its lanes one by one as lanes finish
 //   RT_OPT_STAMPS         section census (executions and active lanes per section, counters[8..19])
-//   RT_OPT_LOCKSTEP       the four wavefronts of a workgroup take every loop trip together (the synchronisation an exchange of
-//                         lanes between them would need; measured against the free-running shape: DESIGN.md section 5)
 //   RT_OPT_TIMELOG        device wall clock (s_memrealtime) of the launch and of every wavefront (P.timelog / P.wavelog)
 #ifndef RT_OPT_WG_WAVES
 #define RT_OPT_WG_WAVES 4
@@ -76,9 +74,6 @@
 #endif
 #ifndef RT_OPT_TIMELOG
 #define RT_OPT_TIMELOG 0
-#endif
-#ifndef RT_OPT_LOCKSTEP
-#define RT_OPT_LOCKSTEP 0
 #endif
 // Heavy tiles first (P.order / P.tile_cost): every workgroup leaves the wall-clock time of its slowest
 // wavefront in P.tile_cost[tile]; a later launch of the same scene and camera walks the tiles in
@@ -689,20 +684,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         if (!idle) {   // (no `continue`: every lane must meet again at the loop top, see below)
         if (need_ray) {
 #else
-#if RT_OPT_LOCKSTEP
-        // The four wavefronts of the workgroup take every trip of the loop TOGETHER (one barrier with a vote per trip; a
-        // lane without work idles inside instead of leaving): the least synchronisation any exchange of lanes between the
-        // wavefronts -- compacting the thin mirror / glass section across them -- would need, and nothing else of it.
-        const bool has_work = !(need_ray && s >= s_end);
-        if (!__syncthreads_or(has_work ? 1 : 0)) break;
-        idle = !has_work;
-        if (P.regen_gate > 1) {
-            const unsigned long long bw = __builtin_amdgcn_ballot_w64(need_ray && has_work);
-            const unsigned long long ba = __builtin_amdgcn_ballot_w64(!need_ray);
-            const bool go = (__popcll(bw) >= P.regen_gate) || (ba == 0ull);
-            idle = idle || (need_ray && !go);
-        }
-#else
         if (need_ray && s >= s_end) break;
         if (P.regen_gate > 1) {
             const unsigned long long bw = __builtin_amdgcn_ballot_w64(need_ray);
@@ -710,7 +691,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             const bool go = (__popcll(bw) >= P.regen_gate) || (ba == 0ull);
             idle = need_ray && !go;
         }
-#endif
         if (!idle) {   // (no `continue`: every lane must meet again at the loop top, see below)
         if (need_ray) {
 #endif
@@ -995,10 +975,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =               // .cl:594-596
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);   // .cl:598-599
-        if (Q.pixel_cost) {                                                // what this pixel cost: the next deal sorts by it
-            const uint32_t rays = c_closest + c_shadow;
-            Q.pixel_cost[(size_t)le * (size_t)Q.w + (size_t)xe] = (uint16_t)(rays < 65535u ? rays : 65535u);
-        }
+        if (Q.pixel_cost)                                                  // what this pixel cost, in loop trips its lane took part in (one per
+            Q.pixel_cost[(size_t)le * (size_t)Q.w + (size_t)xe] =           // closest-hit ray): the next deal sorts by it
+                (uint16_t)(c_closest < 65535u ? c_closest : 65535u);
     }
 
 #endif

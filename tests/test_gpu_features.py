@@ -514,12 +514,16 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
             _assert_same(_state(ctx, ctx.render_pass(spp)), want)              # 8x8 squares; leaves the cost of every pixel
             deal, cost, valid = deal_state(ctx, w, h, deal_rows)
             st = ctx.stats()
-            assert not valid and int(cost.astype(np.int64).sum()) == st["closest_rays"] + st["shadow_rays"]
+            # the cost of a pixel = loop trips spent on it: one per closest-hit ray, in the hierarchy walk one per ray of either kind
+            walked = "_pairs" in ctx.last_kernel          # (a scene of 56 spheres and more may be walked: the library measures)
+            assert not valid and int(cost.astype(np.int64).sum()) == st["closest_rays"] + (st["shadow_rays"] if walked else 0)
             for _ in range(3):
                 ctx.reset()
                 _assert_same(_state(ctx, ctx.render_pass(spp)), want)          # dealt by cost (the same frame costs the same again)
             deal, cost2, valid = deal_state(ctx, w, h, deal_rows)
-            assert valid == deal_rows and np.array_equal(cost2, cost)
+            assert valid == deal_rows
+            if ("_pairs" in ctx.last_kernel) == walked:
+                assert np.array_equal(cost2, cost)                              # the same frame costs the same again
             regions_x = (w + 31) // 32
             whole = 0
             for r in range(deal.shape[0]):

@@ -16,7 +16,7 @@ from tools.ab_bench import CONFIGS  # noqa: E402
 names = (sys.argv[1] if len(sys.argv) > 1 else "c2,c16,c3,c5").split(",")
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 lib = api.load_library(diag=True)
-DEALS = [int(v) for v in os.environ.get("RT_DEALS", "0,8,16,32").split(",")]       # rows of a deal region (0 = no deal)
+DEALS = [int(v, 0) for v in os.environ.get("RT_DEALS", "0,8,16,32").split(",")]    # rows of a deal region (0 = no deal) | pixels of a run << 8 (0x420 = runs of 4, 32 rows)
 for name in names:
     maker, w, h, spp = CONFIGS[name]
     sph, orig, target = maker()

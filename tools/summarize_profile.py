@@ -33,8 +33,20 @@ def main():
             if r["Name"] == kern:
                 summary["avg_kernel_ns"] = float(r["AverageNs"])
                 summary["calls"] = int(r["Calls"])
+    # the timed launches = the last RT_PROF_LAST dispatches of the kernel (bench.py --steps; the ones before them are the
+    # untimed frames that leave per-pixel costs, the deal of pixels by cost and the heavy-first order)
+    last_n = int(os.environ.get("RT_PROF_LAST", "10"))
     trace = find(os.path.join(src, "trace"), "*kernel_trace.csv")
     if trace:
+        with open(trace) as f:
+            rows = [r for r in csv.DictReader(f) if r["Kernel_Name"] == kern]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        tail = rows[-last_n:]
+        if tail:
+            durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail]
+            summary["timed_launches"] = len(tail)
+            summary["avg_kernel_ns_timed_launches"] = sum(durs) / len(durs)
+            summary["min_kernel_ns_timed_launches"] = min(durs)
         with open(trace) as f:
             for r in csv.DictReader(f):
                 if r["Kernel_Name"] == kern:
@@ -49,10 +61,15 @@ def main():
         if not f:
             continue
         with open(f) as fh:
-            for r in csv.DictReader(fh):
-                if r.get("Kernel_Name") != kern:
-                    continue
-                counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            rows = [r for r in csv.DictReader(fh) if r.get("Kernel_Name") == kern]
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-last_n:]
+        per = {}
+        for r in rows:                      # (a counter is reported once per XCD / SE instance of a dispatch: sum those, average the dispatches)
+            if int(r["Dispatch_Id"]) in ids:
+                per.setdefault((r["Counter_Name"], int(r["Dispatch_Id"])), 0.0)
+                per[(r["Counter_Name"], int(r["Dispatch_Id"]))] += float(r["Counter_Value"])
+        for (name, _), v in per.items():
+            counters.setdefault(name, []).append(v)
     avg = {k: sum(v) / len(v) for k, v in counters.items()}
     summary["pmc_per_launch_avg"] = avg
     if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
@@ -100,7 +117,7 @@ def main():
         except (OSError, ValueError):
             data = {}
         rec = {"kernel": kern, "valu_insts_per_launch": summary["valu_insts_per_launch"], "active_lane_frac": round(summary["active_lane_frac"], 4),
-               "profiled_kernel_ms": round(summary["avg_kernel_ns"] / 1e6, 4),
+               "profiled_kernel_ms": round(summary.get("avg_kernel_ns_timed_launches", summary["avg_kernel_ns"]) / 1e6, 4),
                "source": f"profiles/{out_name}.{{md,json}} (rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --workload {key} --no-extras`, tools/profile_gpu.sh)"}
         if "valu_busy_frac_single_stream" in summary:
             rec["valu_busy_frac_single_stream"] = round(summary["valu_busy_frac_single_stream"], 4)
