@@ -729,6 +729,16 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
 
 }  // namespace
 
+namespace rt {
+// a shard's launch on its own stream, for the multi-device context: like rt_render_async, but a BLOCKING frame (may_block) lets
+// the shard that measures hierarchy against sweep hold all its probes inside this call, as rt_render_pass does
+int render_shard(rt_ctx *c, int n_samples, bool may_block) {
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    return launch(c, n_samples, c->stream, may_block);
+}
+}  // namespace rt
+
 extern "C" {
 
 RT_API const char *rt_last_error(void) { return g_err; }

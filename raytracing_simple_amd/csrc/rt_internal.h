@@ -127,6 +127,7 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // context's host mirror holds (sets c->bvh / c->bvh_ok; nothing is read back)
 hipError_t prepare_bvh_build();
 int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream);
+int render_shard(rt_ctx *c, int n_samples, bool may_block);      // rt_api.hip: one shard's launch on its own stream
 
 // multi-device context (rt_multi.hip); `front` is the rt_ctx whose `multi` points at the record
 void multi_destroy(rt_ctx *front);

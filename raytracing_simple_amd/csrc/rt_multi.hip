@@ -345,7 +345,7 @@ int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking
         rt_ctx *s = m->shard[r];
         HIP_TRY(hipSetDevice(s->device));
         if (blocking) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-        int rc = rt_render_async(s, n_samples, s->stream);
+        int rc = rt::render_shard(s, n_samples, blocking);
         if (rc != RT_OK) return rc;
         if (blocking) HIP_TRY(hipEventRecord(s->ev1, s->stream));
     }
