@@ -23,6 +23,10 @@ RT_API int rt_debug_instance(const char *kernel_symbol);
 RT_API const char *rt_debug_instance_name(int fast, int row);
 /* the kernel instance the last launch of shard `shard` of a multi-device context used (rt_last_kernel names the first shard's) */
 RT_API const char *rt_debug_shard_kernel(rt_ctx *ctx, int shard);
+/* `repeats` launches of a kernel that does EXACTLY the table staging of the render kernels' prologue (every workgroup of the grid the
+ * library would launch reads the scene tables into LDS) and nothing else: under rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum its counters are
+ * the L2 hit rate of the LDS-staged sphere reads in isolation (tools/pmc_staging.sh) */
+RT_API int rt_debug_stage_tables(rt_ctx *ctx, int n_samples, int repeats);
 /* failure injection: puts a multi-device context into the state a failed gather (ncclGroupEnd) leaves it in and returns that
  * failure's code; every later rendering / state call on the context must then return RT_ERR_STATE until it is destroyed */
 RT_API int rt_debug_break_gather(rt_ctx *ctx);

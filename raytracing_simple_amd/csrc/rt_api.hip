@@ -211,6 +211,33 @@ __global__ void __launch_bounds__(256) rt_deinterleave_kernel(uint32_t *__restri
 }
 
 #if RT_DIAGNOSTICS
+// diagnostic only (rt_debug_stage_tables): EXACTLY the table staging of the render kernels' prologue -- every workgroup reads the
+// geometry, light and (if they ride along) material tables into LDS -- and nothing else, so that the L2 counters of a profiler
+// run show the hit rate of those reads in isolation (north_star: "L2-hit rate on the LDS-staged sphere reads").  One word per
+// workgroup goes out so that the loads are not dead.
+__global__ void rt_stage_probe_kernel(const rt::SceneTables T, int mat_in_lds, uint32_t *sink) {
+    extern __shared__ float4 lds[];
+    const uint32_t n = T.n_spheres, nl = T.n_lights;
+    float4 *s_geom = lds, *s_la = s_geom + n, *s_lb = s_la + nl, *s_em = s_lb + nl, *s_co = s_em + n;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_geom[i] = T.geom[i];
+    for (uint32_t i = threadIdx.x; i < nl; i += blockDim.x) {
+        s_la[i] = T.lightA[i];
+        s_lb[i] = T.lightB[i];
+    }
+    if (mat_in_lds)
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            s_em[i] = T.emis[i];
+            s_co[i] = T.colr[i];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.f;
+        for (uint32_t i = 0; i < n; ++i) acc += s_geom[i].w + (mat_in_lds ? s_em[i].x + s_co[i].x : 0.f);
+        for (uint32_t i = 0; i < nl; ++i) acc += s_la[i].w + s_lb[i].w;
+        sink[blockIdx.x & 1023u] = __float_as_uint(acc);
+    }
+}
+
 // diagnostic only (rt_debug_reset_by_copy): the reset this library used in round 1 -- a copy kernel that
 // restores the seed words, which the next launch then reads back.  Logs into its timelog record (tl) the
 // device wall-clock of its first start / last end and the number of workgroups that ran, and per workgroup
@@ -1383,6 +1410,34 @@ RT_API int rt_debug_instance(const char *name) {
 RT_API const char *rt_debug_shard_kernel(rt_ctx *c, int shard) {
     if (!c || !c->multi || shard < 0 || shard >= rt::multi_shards(c)) return "";
     return rt::multi_shard(c, shard)->last_kernel;
+}
+// The render kernels' table staging alone (rt_stage_probe_kernel), `repeats` launches of the grid and workgroup shape the library
+// would use for `n_samples` passes of the current scene: for a profiler run that isolates the L2 behaviour of those reads.
+RT_API int rt_debug_stage_tables(rt_ctx *c, int n_samples, int repeats) {
+    if (!c || c->multi || !c->have_scene) return fail(RT_ERR_ARG, "null / multi-device context, or no scene");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = chain(c, c->stream);
+    if (rc != RT_OK) return rc;
+    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
+    const int mat = lds_all <= (size_t)c->mat_lds_limit ? 1 : 0;
+    const size_t lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, mat != 0, n_samples);
+    if (lds > kLdsMax) return fail(RT_ERR_ARG, "tables of %zu B do not fit LDS", lds);
+    const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+    const bool w1 = lds + (coop ? 1536u : 256u) <= 6 * 1024;
+    const int tile_w = w1 ? 8 : 32;
+    const dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + 7) / 8));
+    uint32_t *sink = reinterpret_cast<uint32_t *>(c->d_tile_cost);          // (scratch: n_tiles >= 1024 words are not needed -- index & 1023 of a buffer that large)
+    if (!sink || c->n_tiles < 1024) return fail(RT_ERR_ARG, "image too small for the probe");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_stage_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_stage_tables: %s", hipGetErrorString(e));
+    for (int k = 0; k < repeats; ++k) {
+        hipLaunchKernelGGL(rt_stage_probe_kernel, grid, dim3(w1 ? 64 : 256), lds, c->stream, c->scene, mat, sink);
+        HIP_TRY(hipGetLastError());
+    }
+    c->cost_valid = c->order_valid = false;                                 // (the probe scribbled over the tile costs)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
 }
 // failure injection: the state a failed gather (ncclGroupEnd) leaves a multi-device context in -- every later call is refused
 RT_API int rt_debug_break_gather(rt_ctx *c) {
