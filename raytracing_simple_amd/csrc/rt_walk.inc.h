@@ -109,11 +109,6 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
                        int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen) {
     const int lane_ = threadIdx.x & 63;
-    // The stack's top entry rides in a register while the walk runs (entries 0 .. sp - 2 in LDS): a pop then hands over the
-    // register and re-reads the new top behind it -- that read is not needed before the NEXT pop or push, so the dependent
-    // chain of a step that pops is one LDS latency (the pair it goes to), not two.  (An index of -1 is clamped to 0: entry 0
-    // is dead whenever that happens.)
-    uint32_t top = my_stack[(sp > 0 ? sp - 1 : 0) * stack_stride];
     while (cur != kWalkDone && budget > 0) {
         for (int round = round_len; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
             budget -= 1;
@@ -133,14 +128,13 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             const bool second_first = both ? (tn1 < tn0) : m0;
             const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
             if (both) {
-                my_stack[(sp > 0 ? sp - 1 : 0) * stack_stride] = (uint16_t)top;
-                top = far;
+                my_stack[sp * stack_stride] = (uint16_t)far;
                 sp += 1;
             }
             if (none) {
-                cur = sp > 0 ? top : kWalkDone;
-                sp = sp > 0 ? sp - 1 : 0;
-                top = my_stack[(sp > 0 ? sp - 1 : 0) * stack_stride];
+                sp -= 1;
+                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+                sp = sp < 0 ? 0 : sp;
             } else {
                 cur = near;
             }
@@ -186,12 +180,11 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                     }
                 }
             }
-            cur = sp > 0 ? top : kWalkDone;
-            sp = sp > 0 ? sp - 1 : 0;
-            top = my_stack[(sp > 0 ? sp - 1 : 0) * stack_stride];
+            sp -= 1;
+            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+            sp = sp < 0 ? 0 : sp;
         }
     }
-    my_stack[(sp > 0 ? sp - 1 : 0) * stack_stride] = (uint16_t)top;
 }
 
 
