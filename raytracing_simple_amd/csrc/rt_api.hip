@@ -106,42 +106,73 @@ __global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *s
     if (tid == 0) *n_lights_out = s_base;
 }
 
-// Heavy-first order of the 32x8 tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a
-// counting sort over 1024 cost classes (largest first; the order inside a class does not matter).
-__global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *cost, uint32_t *order, uint32_t n) {
+// Heavy-first order of the tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a counting sort over
+// 1024 cost classes (largest first; the order inside a class does not matter).
+// With n_home > 1 the order also keeps the tiles of a REGION (region_tx x region_ty tiles: the 32 x 32 pixels whose lanes the
+// deal by cost mixes) on one XCD: workgroups are dealt to the 8 XCDs round-robin (block b and b + 8 share one: observed, not
+// promised -- only traffic depends on it), so every region gets a home ((column + 3 x row) mod n_home), each home's tiles are sorted
+// heavy first on their own, and position n_home * k + h takes the k-th tile of home h.  The wavefronts of a region then store
+// their scattered pixels, colours and seeds through ONE L2, where the partial lines meet before they leave, and read the
+// region's seeds and deal from it.  (Homes hold equally many tiles up to a region or two; the tiles beyond the shortest
+// list's length -- the cheapest ones -- follow at the end.)
+__global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t grid_x,
+                                                             uint32_t region_tx, uint32_t region_ty, uint32_t n_home) {
+    constexpr unsigned kMaxHome = 8;
     __shared__ unsigned s_max;
-    __shared__ unsigned s_hist[1024];
+    __shared__ unsigned s_hist[kMaxHome][1024];
+    __shared__ unsigned s_len[kMaxHome], s_tail[kMaxHome], s_min;
     const unsigned tid = threadIdx.x;
     constexpr unsigned kCap = 0x1FFFFFu;            // 21 ms of ticks: cost * 1023 stays inside 32 bits
+    if (n_home < 1u || n_home > kMaxHome) n_home = 1u;
+    auto home_of = [&](uint32_t i) -> unsigned {
+        if (n_home == 1u) return 0u;
+        const uint32_t ty = i / grid_x, tx = i - ty * grid_x;
+        return (tx / region_tx + 3u * (ty / region_ty)) % n_home;       // (neighbours across AND down get different homes: a tall or a wide expensive object is spread over all of them)
+    };
+    auto key_of = [&](uint32_t i) -> unsigned { return cost[i] < kCap ? cost[i] : kCap; };
     if (tid == 0) s_max = 1u;
-    s_hist[tid] = 0u;
+    for (unsigned h = 0; h < kMaxHome; ++h) s_hist[h][tid] = 0u;
     __syncthreads();
     unsigned m = 0;
     for (uint32_t i = tid; i < n; i += 1024) {
-        const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
+        const unsigned c_ = key_of(i);
         m = c_ > m ? c_ : m;
     }
     atomicMax(&s_max, m);
     __syncthreads();
     const unsigned top = s_max;
     for (uint32_t i = tid; i < n; i += 1024) {
-        const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
-        atomicAdd(&s_hist[1023u - c_ * 1023u / top], 1u);
+        const unsigned c_ = key_of(i);
+        atomicAdd(&s_hist[home_of(i)][1023u - c_ * 1023u / top], 1u);
     }
     __syncthreads();
-    if (tid == 0) {                     // exclusive prefix over the classes, most expensive class first
+    if (tid < kMaxHome) {               // exclusive prefix over the classes of one home, most expensive class first
         unsigned run = 0;
         for (int k = 0; k < 1024; ++k) {
-            const unsigned c_ = s_hist[k];
-            s_hist[k] = run;
+            const unsigned c_ = s_hist[tid][k];
+            s_hist[tid][k] = run;
             run += c_;
+        }
+        s_len[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned lo = 0xffffffffu;
+        for (unsigned h = 0; h < n_home; ++h) lo = s_len[h] < lo ? s_len[h] : lo;
+        s_min = lo;
+        unsigned run = lo * n_home;
+        for (unsigned h = 0; h < n_home; ++h) {
+            s_tail[h] = run;
+            run += s_len[h] - lo;
         }
     }
     __syncthreads();
+    const unsigned shortest = s_min;
     for (uint32_t i = tid; i < n; i += 1024) {
-        const unsigned c_ = cost[i] < kCap ? cost[i] : kCap;
-        const unsigned pos = atomicAdd(&s_hist[1023u - c_ * 1023u / top], 1u);
-        order[pos] = i;
+        const unsigned c_ = key_of(i);
+        const unsigned h = home_of(i);
+        const unsigned k = atomicAdd(&s_hist[h][1023u - c_ * 1023u / top], 1u);
+        order[k < shortest ? k * n_home + h : s_tail[h] + (k - shortest)] = i;
     }
 }
 
@@ -527,7 +558,9 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
         if (c->cost_valid && !c->order_valid && n_samples >= 8) {
-            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
+            // (a region: 32 pixels across = 4 single-wavefront tiles or one 4-wavefront tile; the deal's rows down)
+            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles, grid.x,
+                               inst->waves == 1 ? 4u : 1u, (uint32_t)(c->deal_rows / rt::kTileH), (uint32_t)c->order_homes);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
             c->order_age = 0;
@@ -1457,7 +1490,7 @@ static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
-static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
+static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; if (v >> 8) c->order_homes = v >> 8; c->order_valid = false; return RT_OK; }
 static int dbg_set_deal(rt_ctx *c, int v) {       // 0 = off; rows of a region | pixels of a run << 8
     c->use_deal = v ? 1 : 0;
     if (v & 255) c->deal_rows = v & 255;
@@ -1489,8 +1522,8 @@ RT_API int rt_debug_set_wg_waves(rt_ctx *c, int waves) {    // 0 = automatic, 1 
     if (!c || (waves != 0 && waves != 1 && waves != 4)) return fail(RT_ERR_ARG, "waves %d", waves);
     return dbg_apply(c, dbg_set_wg, waves);
 }
-RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour)
-    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour); 1: heavy first; | homes << 8 (1 .. 8; 1 = regions not kept on one XCD)
+    if (!c || on < 0 || (on >> 8) > 8) return fail(RT_ERR_ARG, "ctx is null / order %d", on);
     return dbg_apply(c, dbg_set_order, on);
 }
 RT_API int rt_debug_set_pixel_deal(rt_ctx *c, int rows) {     // 0: every wavefront renders its 8x8 square (the round-2 behaviour); else rows of a region (8 .. 128) | pixels of a run (1, 2, 4, 8; 0 = keep) << 8
@@ -1521,10 +1554,11 @@ RT_API int rt_debug_read_tile_order(rt_ctx *c, uint32_t *order_out, uint32_t *co
     if (rc != RT_OK) return rc;
     rc = wait_all(c);
     if (rc != RT_OK) return rc;
-    const uint32_t n = cap < c->n_tiles ? cap : c->n_tiles;
+    const uint32_t in_use = c->cost_valid && c->cost_tiles ? c->cost_tiles : c->n_tiles;      // (the tiles of the last launch's workgroup shape)
+    const uint32_t n = cap < in_use ? cap : in_use;
     if (order_out && n) HIP_TRY(hipMemcpy(order_out, c->d_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (cost_out && n) HIP_TRY(hipMemcpy(cost_out, c->d_tile_cost, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (n_tiles) *n_tiles = c->n_tiles;
+    if (n_tiles) *n_tiles = in_use;
     if (valid) *valid = c->order_valid ? 1 : 0;
     return RT_OK;
 }

@@ -299,7 +299,29 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         assert valid and sorted(order.tolist()) == list(range(len(order)))
         capped = np.minimum(cost, 0x1FFFFF).astype(np.uint64)
         cls = 1023 - (capped * 1023 // int(capped.max())).astype(np.int64)                    # the kernel's cost classes
-        assert np.all(np.diff(cls[order]) >= 0)                                # most expensive class first
+        # The tiles of one 32x32-pixel region (4 x 4 of these tiles: the pixels the deal mixes) run under workgroup numbers
+        # that are equal modulo 8 -- on one XCD, whose L2 their scattered stores meet in -- and each of the eight lists is
+        # sorted most expensive class first.  The lists' lengths differ by whole regions: what is beyond the shortest
+        # list's length follows at the end of the order.
+        tiles_x = (w + 7) // 8
+        home = ((order % tiles_x) // 4 + 3 * ((order // tiles_x) // 4)) % 8
+        per_home = np.bincount(home, minlength=8)
+        head = 8 * int(per_home.min())
+        assert np.array_equal(home[:head], np.arange(head) % 8)
+        for x in range(8):
+            assert np.all(np.diff(cls[order[:head][x::8]]) >= 0)
+            rest = order[head:][home[head:] == x]
+            assert len(rest) == per_home[x] - per_home.min()
+            assert np.all(np.diff(cls[np.concatenate([order[:head][x::8], rest])]) >= 0)
+        # homes = 1: the plain order, most expensive class first over all tiles
+        api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (1 << 8)), lib)
+        ctx.reset()
+        _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+        order1, cost1, valid = order_state(ctx)
+        assert valid and sorted(order1.tolist()) == list(range(len(order1)))
+        capped1 = np.minimum(cost2, 0x1FFFFF).astype(np.uint64)                # (sorted from the costs the launch before left)
+        assert np.all(np.diff((1023 - capped1 * 1023 // int(capped1.max())).astype(np.int64)[order1]) >= 0)
+        api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (8 << 8)), lib)
         # short launches neither sort nor need an order
         ctx.reset(); ctx.render_pass(2); ctx.render_pass(6)
         _assert_same(_state(ctx, ctx.read_pixels()), want)
