@@ -163,10 +163,21 @@ int main() {
         if (!(t[i] < 1e19f)) continue;
         Ray b; float hp[3];
         for (int k = 0; k < 3; ++k) hp[k] = prim[i].o[k] + prim[i].d[k] * t[i];
-        // a direction in the upper hemisphere (the ground's normal: most hits are ground or sphere tops), cosine-weighted
-        const float r1 = 6.2831853f * U(rng), r2 = U(rng), r2s = std::sqrt(r2);
-        b.d[0] = std::cos(r1) * r2s; b.d[2] = std::sin(r1) * r2s; b.d[1] = std::sqrt(1 - r2);
-        for (int k = 0; k < 3; ++k) b.o[k] = hp[k] + 0.02f * b.d[k];
+        // cosine-weighted around the surface normal at the hit (the sphere whose surface the point lies on; else the ground's)
+        float nrm[3] = {0.f, 1.f, 0.f};
+        for (const S &q : sph) {
+            const float v[3] = {hp[0] - q.x, hp[1] - q.y, hp[2] - q.z};
+            const float dist = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            if (std::fabs(dist - q.r) < 1e-3f * q.r + 1e-3f) { for (int k = 0; k < 3; ++k) nrm[k] = v[k] / dist; break; }
+        }
+        float uu[3] = {nrm[2], 0.f, -nrm[0]};                        // (0,1,0) x n, or (1,0,0) x n for a vertical normal
+        if (std::fabs(nrm[0]) < 0.1f && std::fabs(nrm[2]) < 0.1f) { uu[0] = 0.f; uu[1] = -nrm[2]; uu[2] = nrm[1]; }
+        const float ul = std::sqrt(uu[0] * uu[0] + uu[1] * uu[1] + uu[2] * uu[2]);
+        for (float &v : uu) v /= ul;
+        const float vv[3] = {nrm[1] * uu[2] - nrm[2] * uu[1], nrm[2] * uu[0] - nrm[0] * uu[2], nrm[0] * uu[1] - nrm[1] * uu[0]};
+        const float r1 = 6.2831853f * U(rng), r2 = U(rng), r2s = std::sqrt(r2), cz = std::sqrt(1 - r2);
+        for (int k = 0; k < 3; ++k) b.d[k] = uu[k] * std::cos(r1) * r2s + vv[k] * std::sin(r1) * r2s + nrm[k] * cz;
+        for (int k = 0; k < 3; ++k) b.o[k] = hp[k] + 0.02f * nrm[k];
         b.far = 1e20f; b.any = false;
         bounce.push_back(b);
         Ray s; float len = 0;
