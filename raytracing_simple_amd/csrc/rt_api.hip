@@ -179,9 +179,11 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
 // The deal of a region's pixels to its wavefronts (rt_device.h LaunchParams::deal): ONE workgroup per region of 32 x deal_rows
 // pixels sorts them by the cost the last launch left for them (rays traced; descending, ties by position) -- a bitonic sort
 // in LDS -- and writes their positions (dy * 32 + dx) in that order.  What is sorted are runs of `group` horizontally adjacent
-// pixels (1, 2, 4 or 8; key = the run's summed cost): a run stays on adjacent lanes, so the launch's loads and stores of seeds,
-// colours and pixels still come in segments of 8 * group .. 12 * group bytes instead of single words (with single pixels the
-// launch wrote 3.5 times the bytes it produces).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
+// pixels (1, 2, 4 or 8; key = the run's summed cost; 4 by default): a run stays on adjacent lanes, so the launch's loads and
+// stores of seeds, colours and pixels still come in segments of 8 * group .. 12 * group bytes instead of single words (with
+// single pixels the launch wrote 3.5 times the bytes it produces).  What the previous launch cost predicts the next launch only
+// as far as a pixel's EXPECTED cost goes -- single pixels sorted by the realised cost are an exact fit for the same frame rendered
+// again (same random numbers) and a slight loss on new passes; runs of 4 gain on both (tools/deal_progressive.py).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
 // (its workgroups do not all exist: ranks must not move out of their square).
 __global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *__restrict__ cost, uint16_t *__restrict__ deal, int w, int rows,
                                                               int regions_x, int deal_rows, int group) {

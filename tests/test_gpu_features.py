@@ -516,12 +516,18 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
         b, q, l = r >> 8, (r >> 6) & 3, r & 63
         return (((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7))).astype(np.uint16)
 
-    cases = [(lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32),                # single-wavefront workgroups, ragged: 200 = 6 * 32 + 8, 120 = 3 * 32 + 24
-             (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 8),
-             (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 256, 64, 8, {"wg": 4}, 16),    # four-wavefront workgroups
-             (lambda: scenes.random_spheres(300), 160, 96, 8, {"walk": 1}, 32),  # the hierarchy walk
-             (lambda: scenes.mirror_box(64), 96, 72, 8, {}, 32)]                 # cooperative any-hit
-    for maker, w, h, spp, knobs, deal_rows in cases:
+    # (the last column: pixels of a run -- what is sorted are runs of 1, 2, 4 or 8 horizontally adjacent pixels, by their summed
+    # cost, and a run stays on adjacent lanes; None = the library's default, runs of 4)
+    cases = [(lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32, 1),             # single-wavefront workgroups, ragged: 200 = 6 * 32 + 8, 120 = 3 * 32 + 24
+             (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32, None),
+             (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 8, 8),
+             (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 256, 64, 8, {"wg": 4}, 16, 1),    # four-wavefront workgroups
+             (lambda: scenes.random_spheres(300), 160, 96, 8, {"walk": 1}, 32, 1),  # the hierarchy walk
+             (lambda: scenes.random_spheres(300), 160, 96, 8, {"walk": 1}, 32, 4),
+             (lambda: scenes.mirror_box(64), 96, 72, 8, {}, 32, 2)]              # cooperative any-hit
+    for maker, w, h, spp, knobs, deal_rows, run in cases:
+        knob = deal_rows | ((run or 0) << 8)
+        run = run or 4
         sph, orig, target = maker()
         cam = host.compute_camera(orig, target, w, h)
         want = O.render(sph, cam, w, h, spp)
@@ -531,7 +537,7 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
             if "walk" in knobs:
                 ctx._check(lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
                 ctx._check(lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
-            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, deal_rows))
+            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, knob))
             ctx.set_scene(sph); ctx.set_camera(cam)
             _assert_same(_state(ctx, ctx.render_pass(spp)), want)              # 8x8 squares; leaves the cost of every pixel
             deal, cost, valid = deal_state(ctx, w, h, deal_rows)
@@ -554,7 +560,9 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
                     whole += 1
                     assert sorted(deal[r].tolist()) == list(range(32 * deal_rows)), r
                     c = cost[ry * deal_rows + (deal[r] >> 5).astype(int), rx * 32 + (deal[r] & 31).astype(int)].astype(int)
-                    assert np.all(np.diff(c) <= 0), r                          # heaviest pixel first
+                    assert np.all(np.diff(c.reshape(-1, run).sum(axis=1)) <= 0), r        # heaviest run first
+                    pos = deal[r].astype(int).reshape(-1, run)                             # a run: adjacent pixels of one row, aligned
+                    assert np.all(np.diff(pos, axis=1) == 1) and np.all(pos[:, 0] % run == 0), r
                 else:
                     assert np.array_equal(deal[r], identity(deal_rows)), r     # a region over the edge keeps its squares
             assert whole > 0
@@ -562,7 +570,7 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
             ctx.reset()
             _assert_same(_state(ctx, ctx.render_pass(spp)), want)
             # progressive passes on a dealt context, and a pass count that changes the launch shape
-            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, deal_rows))
+            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, knob))
             ctx.reset(); ctx.render_pass(spp); ctx.reset()
             ctx.render_pass(3); ctx.render_pass(9); ctx.render_pass(4)
             _assert_same(_state(ctx, ctx.read_pixels()), O.render(sph, cam, w, h, 16))
