@@ -114,11 +114,10 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
     out["traffic"] = None
     if pm and pm.get("kernel", kernel) == kernel:
         out["traffic"] = pm.get("hbm_bytes_per_launch")
-        if out["traffic"] and out["traffic"] > 2 * alg_bytes:
-            out["traffic_note"] = ("above the algorithmic bytes on purpose: pixels are dealt to wavefronts by cost, so a wavefront's 64 pixels lie "
-                                   "scattered over a 32x32 region and its per-pixel loads and stores (seeds 8 B, colour 12 B, pixel 4 B, cost 2 B) go out "
-                                   "as single words instead of 32-96 byte segments; dealing runs of 8 adjacent pixels brings the traffic back to 1.1x "
-                                   "algorithmic and is 3 % slower (profiles/r03j_*): the kernel is VALU-bound at ~1 % of the HBM peak either way")
+        if out["traffic"] and out["traffic"] > 1.15 * alg_bytes:
+            out["traffic_note"] = ("above the algorithmic bytes because pixels are dealt to wavefronts by cost in runs of 4: a wavefront's 64 pixels are 16 "
+                                   "runs scattered over a 32x32 region, so its per-pixel loads and stores (seeds 8 B, colour 12 B, pixel 4 B, cost 2 B) go out "
+                                   "in 16-48 byte segments instead of 32-96 byte ones (DESIGN.md section 5); the kernel is VALU-bound at under 1 % of the HBM peak")
         if pm.get("valu_insts_per_launch"):
             # what the VALU actually issues (PMC of the committed profile, same command): the time its instructions
             # need at full issue rate, and how much of this run's kernel time that is
