@@ -115,9 +115,9 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
     if pm and pm.get("kernel", kernel) == kernel:
         out["traffic"] = pm.get("hbm_bytes_per_launch")
         if out["traffic"] and out["traffic"] > 1.15 * alg_bytes:
-            out["traffic_note"] = ("above the algorithmic bytes because pixels are dealt to wavefronts by cost in runs of 4: a wavefront's 64 pixels are 16 "
+            out["traffic_note"] = ("above the algorithmic bytes because pixels are dealt to wavefronts by cost in runs of 8: a wavefront's 64 pixels are 8 "
                                    "runs scattered over a 32x32 region, so its per-pixel loads and stores (seeds 8 B, colour 12 B, pixel 4 B, cost 2 B) go out "
-                                   "in 16-48 byte segments instead of 32-96 byte ones (DESIGN.md section 5); the kernel is VALU-bound at under 1 % of the HBM peak")
+                                   "in 16-96 byte segments rather than whole lines (DESIGN.md section 5); the kernel is VALU-bound at under 1 % of the HBM peak")
         if pm.get("valu_insts_per_launch"):
             # what the VALU actually issues (PMC of the committed profile, same command): the time its instructions
             # need at full issue rate, and how much of this run's kernel time that is

@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) rt_build_tables_kernel(const rt_sphere *s
 
 // Heavy-first order of the tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a counting sort over
 // 1024 cost classes (largest first; the order inside a class does not matter).
-// With n_home > 1 the order also keeps the tiles of a REGION (region_tx x region_ty tiles: the 32 x 32 pixels whose lanes the
+// With n_home > 1 (rt_debug_set_tile_order; NOT the default: it saves a fifth of the launch's traffic and costs 1 % of its time)
+// the order also keeps the tiles of a REGION (region_tx x region_ty tiles: the 32 x 32 pixels whose lanes the
 // deal by cost mixes) on one XCD: workgroups are dealt to the 8 XCDs round-robin (block b and b + 8 share one: observed, not
 // promised -- only traffic depends on it), so every region gets a home ((column + 3 x row) mod n_home), each home's tiles are sorted
 // heavy first on their own, and position n_home * k + h takes the k-th tile of home h.  The wavefronts of a region then store
@@ -179,11 +180,11 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
 // The deal of a region's pixels to its wavefronts (rt_device.h LaunchParams::deal): ONE workgroup per region of 32 x deal_rows
 // pixels sorts them by the cost the last launch left for them (rays traced; descending, ties by position) -- a bitonic sort
 // in LDS -- and writes their positions (dy * 32 + dx) in that order.  What is sorted are runs of `group` horizontally adjacent
-// pixels (1, 2, 4 or 8; key = the run's summed cost; 4 by default): a run stays on adjacent lanes, so the launch's loads and
+// pixels (1, 2, 4 or 8; key = the run's summed cost; 8 by default): a run stays on adjacent lanes, so the launch's loads and
 // stores of seeds, colours and pixels still come in segments of 8 * group .. 12 * group bytes instead of single words (with
 // single pixels the launch wrote 3.5 times the bytes it produces).  What the previous launch cost predicts the next launch only
 // as far as a pixel's EXPECTED cost goes -- single pixels sorted by the realised cost are an exact fit for the same frame rendered
-// again (same random numbers) and a slight loss on new passes; runs of 4 gain on both (tools/deal_progressive.py).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
+// again (same random numbers) and a slight loss on new passes; runs of 4 and 8 gain on both (tools/deal_progressive.py).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
 // (its workgroups do not all exist: ranks must not move out of their square).
 __global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *__restrict__ cost, uint16_t *__restrict__ deal, int w, int rows,
                                                               int regions_x, int deal_rows, int group) {

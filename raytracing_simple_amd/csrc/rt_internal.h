@@ -68,10 +68,12 @@ struct rt_ctx {
     uint16_t *d_deal = nullptr;
     bool pixel_cost_valid = false, deal_valid = false;
     int use_deal = 1, deal_rows = 32;   // rows of a region (8 .. 128)
-    int order_homes = 8;                // heavy-first order: the tiles of a region go to workgroup numbers equal modulo this (one XCD); 1 = plain order
-    int deal_group = 4;                 // horizontally adjacent pixels that stay together (a run on adjacent lanes: coalesced loads and stores).
-                                        // Chosen on passes the costs have NOT seen (tools/deal_progressive.py): single pixels win only when the
-                                        // very frame the costs were measured on is rendered again
+    int order_homes = 1;                // heavy-first order: the tiles of a region go to workgroup numbers equal modulo this (8 = one XCD per region:
+                                        // a fifth less traffic, 1 % more time -- measured, not the default); 1 = plain order
+    int deal_group = 8;                 // horizontally adjacent pixels that stay together (a run on adjacent lanes: coalesced loads and stores).
+                                        // Chosen on passes the costs have NOT seen (tools/deal_progressive.py, tools/ab_bench.py --unseen): single
+                                        // pixels win only when the very frame the costs were measured on is rendered again; runs of 4 and 8 are
+                                        // level there, and runs of 8 keep the launch's traffic at 1.16 x what it produces (runs of 4: 1.48 x)
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
     uint32_t stage_cap = 0;             // records per slot
     int stage_next = 0;

@@ -299,29 +299,28 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         assert valid and sorted(order.tolist()) == list(range(len(order)))
         capped = np.minimum(cost, 0x1FFFFF).astype(np.uint64)
         cls = 1023 - (capped * 1023 // int(capped.max())).astype(np.int64)                    # the kernel's cost classes
-        # The tiles of one 32x32-pixel region (4 x 4 of these tiles: the pixels the deal mixes) run under workgroup numbers
-        # that are equal modulo 8 -- on one XCD, whose L2 their scattered stores meet in -- and each of the eight lists is
-        # sorted most expensive class first.  The lists' lengths differ by whole regions: what is beyond the shortest
-        # list's length follows at the end of the order.
+        assert np.all(np.diff(cls[order]) >= 0)                                # most expensive class first
+        # homes = 8 (a knob: a fifth less traffic, 1 % more time): the tiles of one 32x32-pixel region (4 x 4 of these tiles: the
+        # pixels the deal mixes) run under workgroup numbers that are equal modulo 8 -- on one XCD, whose L2 their scattered
+        # stores meet in -- and each of the eight lists is sorted most expensive class first.  The lists' lengths differ by whole
+        # regions: what is beyond the shortest list's length follows at the end of the order.
+        api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (8 << 8)), lib)
+        ctx.reset()
+        _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+        order8, cost3, valid = order_state(ctx)
+        assert valid and sorted(order8.tolist()) == list(range(len(order8)))
+        capped2 = np.minimum(cost2, 0x1FFFFF).astype(np.uint64)               # (sorted from the costs the launch before left)
+        cls2 = 1023 - (capped2 * 1023 // int(capped2.max())).astype(np.int64)
         tiles_x = (w + 7) // 8
-        home = ((order % tiles_x) // 4 + 3 * ((order // tiles_x) // 4)) % 8
+        home = ((order8 % tiles_x) // 4 + 3 * ((order8 // tiles_x) // 4)) % 8
         per_home = np.bincount(home, minlength=8)
         head = 8 * int(per_home.min())
         assert np.array_equal(home[:head], np.arange(head) % 8)
         for x in range(8):
-            assert np.all(np.diff(cls[order[:head][x::8]]) >= 0)
-            rest = order[head:][home[head:] == x]
+            rest = order8[head:][home[head:] == x]
             assert len(rest) == per_home[x] - per_home.min()
-            assert np.all(np.diff(cls[np.concatenate([order[:head][x::8], rest])]) >= 0)
-        # homes = 1: the plain order, most expensive class first over all tiles
+            assert np.all(np.diff(cls2[np.concatenate([order8[:head][x::8], rest])]) >= 0)
         api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (1 << 8)), lib)
-        ctx.reset()
-        _assert_same(_state(ctx, ctx.render_pass(spp)), want)
-        order1, cost1, valid = order_state(ctx)
-        assert valid and sorted(order1.tolist()) == list(range(len(order1)))
-        capped1 = np.minimum(cost2, 0x1FFFFF).astype(np.uint64)                # (sorted from the costs the launch before left)
-        assert np.all(np.diff((1023 - capped1 * 1023 // int(capped1.max())).astype(np.int64)[order1]) >= 0)
-        api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (8 << 8)), lib)
         # short launches neither sort nor need an order
         ctx.reset(); ctx.render_pass(2); ctx.render_pass(6)
         _assert_same(_state(ctx, ctx.read_pixels()), want)
@@ -517,7 +516,7 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
         return (((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7))).astype(np.uint16)
 
     # (the last column: pixels of a run -- what is sorted are runs of 1, 2, 4 or 8 horizontally adjacent pixels, by their summed
-    # cost, and a run stays on adjacent lanes; None = the library's default, runs of 4)
+    # cost, and a run stays on adjacent lanes; None = the library's default, runs of 8)
     cases = [(lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32, 1),             # single-wavefront workgroups, ragged: 200 = 6 * 32 + 8, 120 = 3 * 32 + 24
              (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32, None),
              (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 8, 8),
@@ -527,7 +526,7 @@ def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
              (lambda: scenes.mirror_box(64), 96, 72, 8, {}, 32, 2)]              # cooperative any-hit
     for maker, w, h, spp, knobs, deal_rows, run in cases:
         knob = deal_rows | ((run or 0) << 8)
-        run = run or 4
+        run = run or 8
         sph, orig, target = maker()
         cam = host.compute_camera(orig, target, w, h)
         want = O.render(sph, cam, w, h, spp)
