@@ -183,8 +183,9 @@ RT_API int rt_reset_async(rt_ctx *ctx, void *hip_stream);
  * a sharded one).  out_host may be NULL to skip the copy.  Blocking.
  * Scheduling, never results: every launch leaves what each pixel and each tile cost it, and long launches (8 passes and
  * more) of the same scene and camera use that -- the second deals the pixels of every 32x32 region to wavefronts by cost
- * (in runs of 8), the third also walks the tiles heaviest first -- so a scene's first frame is a few percent slower than its
- * later ones.  What a launch cost predicts the next one exactly only if it is the same frame again (reset, same passes);
+ * (in runs of 8), the third also walks the tiles heaviest first -- and a launch of 24 passes or more that has no costs to go
+ * by renders 4 of its passes first to get them, then the rest heaviest first -- so a scene's first two frames are a few percent
+ * slower than its later ones.  What a launch cost predicts the next one exactly only if it is the same frame again (reset, same passes);
  * the defaults are the ones that pay on passes not seen before.                                      */
 RT_API int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
 

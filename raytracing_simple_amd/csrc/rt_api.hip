@@ -545,7 +545,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         // deal no longer describe the workgroups: the heavy-first order is sorted again from the next launch's.
         if (c->use_deal && c->d_pixel_cost && !persist) {
             p.pixel_cost = c->d_pixel_cost;
-            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 8) {
+            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 4) {
                 const int regions_x = (c->w + rt::kRegionW - 1) / rt::kRegionW, regions_y = (c->local_rows + c->deal_rows - 1) / c->deal_rows;
                 hipLaunchKernelGGL(rt_order_pixels_kernel, dim3((unsigned)(regions_x * regions_y)), dim3((unsigned)std::min(rt::kRegionW * c->deal_rows, 1024)), 0, stream,
                                    c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows, c->deal_group);
@@ -600,7 +600,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         c->cost_valid = true;
         c->cost_tiles = n_tiles;
     }
-    if (p.pixel_cost && n_samples >= 4) c->pixel_cost_valid = true;
+    if (p.pixel_cost && n_samples >= 8) c->pixel_cost_valid = true;         // (per-pixel costs of fewer passes are mostly noise: no deal from them)
     c->seeds_default = false;           // this launch has written every seed pair the context renders
     c->pixels_current = c->pixel_write != 0;
     return RT_OK;
@@ -674,18 +674,34 @@ void rearm_probe_if_changed(rt_ctx *c) {
     if (moved(tree, c->probe_tree) || moved(always, c->probe_always) || ++c->probe_updates >= 256) rearm_probe(c);
 }
 
+// A long launch that would walk its tiles in image order although their costs can be had -- the first frame of a scene or camera,
+// and the frame after it, whose deal of pixels changes what a tile is -- renders 4 of its passes first (they are passes of the
+// frame like any other: progressive launches equal one launch bit for bit), which prices the tiles, and the rest heavy first.
+// A renderer that draws one frame per scene would otherwise never leave image order ("Heavy tiles first").
+constexpr int kPricePasses = 4, kPriceFrom = 24;
+int launch_priced(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
+    const bool explicit_mode = form == 0;
+    const bool will_deal = c->use_deal && c->pixel_cost_valid && !c->deal_valid;
+    if (!explicit_mode && c->use_order && c->d_tile_cost && n_samples >= kPriceFrom && ((!c->order_valid && !c->cost_valid) || will_deal)) {
+        const int rc = launch_form(c, kPricePasses, stream, form);
+        if (rc != RT_OK) return rc;
+        n_samples -= kPricePasses;
+    }
+    return launch_form(c, n_samples, stream, form);
+}
+
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false) {
     const bool measured = c->walk_forced == 0 && c->mode < 100;
     if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c))
-        return launch_form(c, n_samples, stream, measured ? 2 : 0);
+        return measured ? launch_priced(c, n_samples, stream, 2) : launch_form(c, n_samples, stream, 0);
     // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
     // scene measured, open or packed, and one pass of the sweep at 1080p costs 2.6 ms at 1024 spheres,
     // 28 ms at 4096, 138 ms at 8192, seconds beyond LDS
-    if (c->bvh.n_slots - c->bvh.n_always >= 1500u || !tables_fit_lds(c, n_samples)) return launch_form(c, n_samples, stream, 1);
+    if (c->bvh.n_slots - c->bvh.n_always >= 1500u || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
     if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
-        return launch_form(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);
+        return launch_priced(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);
     probe_poll(c, false);
-    if (c->bvh_pick != 0) return launch_form(c, n_samples, stream, c->bvh_pick);
+    if (c->bvh_pick != 0) return launch_priced(c, n_samples, stream, c->bvh_pick);
     if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 1);    // probes in flight: the usual winner meanwhile
     if (may_block && n_samples >= 16) {
         int done = 0;
@@ -696,7 +712,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false)
             done += k;
         }
         probe_poll(c, true);
-        return launch_form(c, n_samples - done, stream, c->bvh_pick ? c->bvh_pick : 1);
+        return launch_priced(c, n_samples - done, stream, c->bvh_pick ? c->bvh_pick : 1);
     }
     return launch_probe(c, n_samples, stream);
 }

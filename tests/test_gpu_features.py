@@ -264,6 +264,34 @@ def test_rt_render_second_call_costs_little_more_than_its_kernel():
 
 
 # ---- heavy tiles first -------------------------------------------------------------------------------------
+def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
+    """A launch of 24 passes or more that has no tile costs to go by -- the first frame of a scene, and the frame after it, whose
+    deal of pixels changes what a tile is -- renders 4 of its passes first and the rest heavy first (rt_api.hip launch_priced):
+    two launches instead of one, the same frame bit for bit; from the third frame on one launch.  Shorter frames are not split."""
+    w, h = 160, 96
+    sph, orig, target = scenes.demo_plus(16)
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h) as ctx:
+        ctx.set_scene(sph); ctx.set_camera(cam)
+        want = O.render(sph, cam, w, h, 24)
+        launches = []
+        for _ in range(4):
+            ctx.reset()
+            _assert_same(_state(ctx, ctx.render_pass(24)), want)
+            launches.append(ctx.stats()["launches"])
+        assert launches == [2, 2, 1, 1]
+        ctx.set_scene(scenes.demo_plus(12)[0])                                 # another scene: priced again
+        ctx.reset(); ctx.render_pass(30)
+        assert ctx.stats()["launches"] == 2
+        ctx.set_scene(scenes.demo_plus(9)[0])                                  # ... but not for a short frame
+        ctx.reset(); ctx.render_pass(20)
+        assert ctx.stats()["launches"] == 1
+        # progressive launches split the same way and stay the oracle's
+        ctx.set_scene(sph)
+        ctx.reset(); ctx.render_pass(40); ctx.render_pass(24)
+        _assert_same(_state(ctx, ctx.read_pixels()), O.render(sph, cam, w, h, 64))
+
+
 def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_bit():
     """Long launches of one scene and camera walk the tiles in descending order of the cost the launch before measured (the
     third one on: the second deals the pixels of every region to its wavefronts by cost, which changes what a tile is).
