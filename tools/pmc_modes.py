@@ -23,5 +23,7 @@ with api.RtContext(w, h, diag=any(m >= 100 for m in modes) or bool(os.environ.ge
         ctx.set_mode(m)
         for _ in range(warm + 1):
             ctx.reset(); ctx.render_pass(spp, copy=False)
+        for _ in range(int(os.environ.get("RT_PMC_UNSEEN", "0"))):      # launches on passes not rendered before (the LAST launches of the run)
+            ctx.render_pass(spp, copy=False)
         st = ctx.stats()
         print("MODE", m, st, flush=True)
