@@ -102,6 +102,7 @@ bad = []
 for seed in range(first, first + count):
     sph, orig, target = gen(seed)
     w, h, spp = [(40, 24, 3), (33, 17, 2), (64, 32, 5), (25, 40, 4), (96, 64, 2), (17, 9, 9)][seed % 6]
+    spp *= int(os.environ.get("RT_FUZZ_SPP_SCALE", "1"))          # (8: frames of 16 .. 72 passes -- long enough for a first frame to price its tiles, rt_api.hip launch_priced)
     cam = host.compute_camera(orig, target, w, h)
     with np.errstate(all="ignore"):
         want = O.render(sph, cam, w, h, spp)
