@@ -803,7 +803,7 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
         HIP_TRY(hipGetLastError());
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, n_total, nl };
-    return rt::build_bvh(c, n_total, stream);
+    return rt::build_bvh(c, n_total, stream, first == 0 && count == n_total && count > 0);
 }
 
 }  // namespace
@@ -1591,7 +1591,17 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     rc = chain(c, c->stream);
-    return rc != RT_OK ? rc : rt::build_bvh(c, c->scene.n_spheres, c->stream);
+    return rc != RT_OK ? rc : rt::build_bvh(c, c->scene.n_spheres, c->stream, true);
+}
+static int dbg_set_tree_shape(rt_ctx *c, int v) {
+    c->bvh_sah = v ? 1 : 0;
+    return dbg_set_bvh_min(c, c->bvh_min);          // (rebuilds the current scene's tables, re-arms the probe)
+}
+// 1: full scene uploads build the hierarchy on the host with its shape chosen by surface area (the default); 0: the device build
+// and its fixed shape for them too (what device-resident updates always use).  Takes effect at once.
+RT_API int rt_debug_set_tree_shape(rt_ctx *c, int by_area) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    return dbg_apply(c, dbg_set_tree_shape, by_area);
 }
 static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
@@ -1649,7 +1659,8 @@ RT_API int rt_debug_set_bvh(rt_ctx *c, int min_spheres, int lds_limit) {
     int rc = dbg_apply(c, dbg_set_bvh_lds, lds_limit);
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_bvh_min, min_spheres);
 }
-// the blob of rt_device.h BvhTables as it lies in HBM (float4 units), and its four counts {always, leaves, stack depth, slots};
+// the blob of rt_device.h BvhTables as it lies in HBM (float4 units), and four numbers {always, leaves, stack depth, root pair}
+// (slots = always + 8 * leaves);
 // counts of 0 = the scene has no hierarchy
 RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, uint32_t *counts4) {
     if (!c || c->multi || !counts4) return fail(RT_ERR_ARG, "null / multi-device context");
@@ -1659,7 +1670,7 @@ RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, ui
     if (rc != RT_OK) return rc;
     counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
     if (!c->bvh_ok) return RT_OK;
-    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.stack_depth; counts4[3] = c->bvh.n_slots;
+    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.stack_depth; counts4[3] = c->bvh.root;
     const size_t need = rt::bvh_blob_float4s(c->bvh.n_leaves, c->bvh.n_slots);
     if (blob_out) {
         if (cap_float4 < need) return fail(RT_ERR_ARG, "blob needs %zu float4", need);

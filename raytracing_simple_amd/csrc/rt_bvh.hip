@@ -387,6 +387,191 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     return RT_OK;
 }
 
+
+// The same tables with the tree's SHAPE chosen by surface area (a full scene upload, where the host has the records and the call
+// blocks anyway; device-resident updates keep the device build above and its fixed shape).  Top-down: a node's spheres are
+// sorted along each axis in turn and cut where  area(left) * leaves(left) + area(right) * leaves(right)  is smallest
+// (leaves(n) = ceil(n / 8): the cost of a visit is a leaf's eight sphere tests whether the leaf is full or not, so partial
+// leaves are made only where they pay); 8 spheres or fewer are a leaf.  Leaves are numbered in the order the recursion emits
+// them, every subtree holds a contiguous range of them, and the pair of a node sits at (first leaf of its right child) - 1 --
+// the numbering of the fixed shape, which never depended on where the split lies.  The root's pair goes out through
+// BvhTables::root since it is no longer n_leaves / 2 - 1.  Against the fixed shape, on C3's rays (tools/sim_tree_shape.cpp): pair
+// steps per ray -15 % (shadow rays -28 %), leaf visits -7 %.  Returns RT_OK with *built = false when the result does not fit
+// the tables' allocation or the stack budget (the caller then takes the fixed shape).
+constexpr uint32_t kSahMaxTree = 16384;         // leaf and pair numbers stay below kBvhLeafRef; the build stays a few milliseconds
+constexpr uint32_t kSahMinTree = 128;           // below 16 leaves the halved shape is as good (64 spheres: 6.95 against 7.03 ms) and one level shallower
+constexpr uint32_t kSahMaxDepth = 30;
+struct SahOut {
+    HostBox box;
+    uint32_t ref;
+    uint32_t depth;
+};
+int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, uint32_t n_tree, hipStream_t stream, uint32_t *n_leaves_out,
+                      uint32_t *depth_out, bool *built) {
+    *built = false;
+    const std::vector<rt_sphere> &sph = c->h_spheres;
+    std::vector<uint32_t> order, always;
+    order.reserve(n_tree);
+    float rmin = 3.4e38f, rmax = 0.f;
+    for (uint32_t i = 0; i < n_total; ++i) {
+        const rt_sphere &s = sph[i];
+        if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) {
+            always.push_back(i);
+        } else {
+            order.push_back(i);
+            rmin = fminf(rmin, fabsf(s.rad));
+            rmax = fmaxf(rmax, fabsf(s.rad));
+        }
+    }
+    if (always.size() != n_always || order.size() != n_tree) return rt::fail(RT_ERR_STATE, "hierarchy: the split changed under the build");
+    auto coord = [&](uint32_t ix, int axis) { const rt_sphere &s = sph[ix]; return axis == 0 ? s.p.x : (axis == 1 ? s.p.y : s.p.z); };
+    auto grow = [&](HostBox &b, uint32_t ix) {
+        const rt_sphere &s = sph[ix];
+        const float p[3] = { s.p.x, s.p.y, s.p.z }, ar = fabsf(s.rad);
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = fminf(b.lo[a], host_down(p[a] - ar));
+            b.hi[a] = fmaxf(b.hi[a], host_up(p[a] + ar));
+        }
+        b.low = ix < b.low ? ix : b.low;
+    };
+    auto area = [](const HostBox &b) {
+        const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    const HostBox empty{ { 3.4e38f, 3.4e38f, 3.4e38f }, { -3.4e38f, -3.4e38f, -3.4e38f }, 0xffffffffu };
+    std::vector<uint32_t> leaf_first, leaf_count;
+    std::vector<float4> pair_rows;          // 4 per pair, at 4 * (mid - 1); grown as leaves are emitted
+    std::vector<double> right_area;
+    bool too_deep = false;
+    auto put_pair = [&](uint32_t mid, const SahOut &L, const SahOut &R) {
+        if (pair_rows.size() < 4 * (size_t)mid) pair_rows.resize(4 * (size_t)mid, make_float4(0.f, 0.f, 0.f, 0.f));
+        const SahOut *side[2] = { &L, &R };
+        for (int sd = 0; sd < 2; ++sd) {
+            pair_rows[4 * (size_t)(mid - 1) + 2 * sd] = make_float4(side[sd]->box.lo[0], side[sd]->box.lo[1], side[sd]->box.lo[2], bits_float(side[sd]->ref));
+            pair_rows[4 * (size_t)(mid - 1) + 2 * sd + 1] = make_float4(side[sd]->box.hi[0], side[sd]->box.hi[1], side[sd]->box.hi[2], bits_float(side[sd]->box.low));
+        }
+    };
+    auto by_axis = [&](int axis) {
+        return [&coord, axis](uint32_t x, uint32_t y) {
+            const float cx = coord(x, axis), cy = coord(y, axis);
+            return cx < cy || (cx == cy && x < y);
+        };
+    };
+    auto build = [&](size_t first, size_t last, uint32_t depth, auto &&self) -> SahOut {
+        const size_t count = last - first;
+        if (depth > kSahMaxDepth) too_deep = true;
+        if (count <= (size_t)rt::kBvhLeaf || too_deep) {
+            // (too deep: the rest becomes leaves of 8 in whatever order it is in -- the result is discarded anyway)
+            SahOut out{ empty, 0u, 1u };
+            if (count <= (size_t)rt::kBvhLeaf) {
+                const uint32_t id = (uint32_t)leaf_first.size();
+                leaf_first.push_back((uint32_t)first);
+                leaf_count.push_back((uint32_t)count);
+                for (size_t j = first; j < last; ++j) grow(out.box, order[j]);
+                out.ref = rt::kBvhLeafRef | id;
+                return out;
+            }
+            const size_t half = first + ((count / 2 + rt::kBvhLeaf - 1) / rt::kBvhLeaf) * rt::kBvhLeaf;
+            const SahOut L = self(first, std::min(half, last - 1), depth + 1, self);
+            const uint32_t mid = (uint32_t)leaf_first.size();
+            const SahOut R = self(std::min(half, last - 1), last, depth + 1, self);
+            put_pair(mid, L, R);
+            out.box = L.box;
+            for (int a = 0; a < 3; ++a) { out.box.lo[a] = fminf(L.box.lo[a], R.box.lo[a]); out.box.hi[a] = fmaxf(L.box.hi[a], R.box.hi[a]); }
+            out.box.low = L.box.low < R.box.low ? L.box.low : R.box.low;
+            out.ref = mid - 1u;
+            out.depth = 1u + (L.depth > R.depth ? L.depth : R.depth);
+            return out;
+        }
+        int best_axis = 0;
+        size_t best_cut = count / 2;
+        double best = 1e300;
+        right_area.resize(count);
+        for (int axis = 0; axis < 3; ++axis) {
+            std::sort(order.begin() + first, order.begin() + last, by_axis(axis));
+            HostBox b = empty;
+            for (size_t i = count; i-- > 1;) {              // right_area[i] = area of spheres [i, count)
+                grow(b, order[first + i]);
+                right_area[i] = area(b);
+            }
+            b = empty;
+            for (size_t cut = 1; cut < count; ++cut) {
+                grow(b, order[first + cut - 1]);
+                const double cost = area(b) * (double)((cut + rt::kBvhLeaf - 1) / rt::kBvhLeaf) +
+                                    right_area[cut] * (double)((count - cut + rt::kBvhLeaf - 1) / rt::kBvhLeaf);
+                if (cost < best) {
+                    best = cost;
+                    best_axis = axis;
+                    best_cut = cut;
+                }
+            }
+        }
+        if (best_axis != 2) std::sort(order.begin() + first, order.begin() + last, by_axis(best_axis));
+        const SahOut L = self(first, first + best_cut, depth + 1, self);
+        const uint32_t mid = (uint32_t)leaf_first.size();
+        const SahOut R = self(first + best_cut, last, depth + 1, self);
+        put_pair(mid, L, R);
+        SahOut out{ L.box, mid - 1u, 1u + (L.depth > R.depth ? L.depth : R.depth) };
+        for (int a = 0; a < 3; ++a) { out.box.lo[a] = fminf(L.box.lo[a], R.box.lo[a]); out.box.hi[a] = fmaxf(L.box.hi[a], R.box.hi[a]); }
+        out.box.low = L.box.low < R.box.low ? L.box.low : R.box.low;
+        return out;
+    };
+    const SahOut root = build(0, order.size(), 1u, build);
+    const uint32_t n_leaves = (uint32_t)leaf_first.size();
+    const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
+    const size_t total4 = rt::bvh_blob_float4s(n_leaves, n_slots);
+    if (too_deep || n_leaves >= rt::kBvhLeafRef || total4 > (size_t)c->scene_cap * 3 + 64) return RT_OK;      // (the allocation of ensure_scene_capacity)
+    if (c->bvh_stage_cap < total4) {
+        if (c->bvh_stage_used) HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));
+        if (c->h_bvh_stage) (void)hipHostFree(c->h_bvh_stage);
+        c->h_bvh_stage = nullptr;
+        c->bvh_stage_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_bvh_stage), total4 * sizeof(float4), hipHostMallocDefault));
+        c->bvh_stage_cap = total4;
+    } else if (c->bvh_stage_used) {
+        HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));       // the last build's copy still reads the buffer
+    }
+    float4 *blob = c->h_bvh_stage;
+    float4 *hdr = blob, *slots = blob + rt::bvh_slots_at();
+    uint32_t *index = reinterpret_cast<uint32_t *>(blob + rt::bvh_index_at(n_slots));
+    float4 *pairs = blob + rt::bvh_pairs_at(n_slots);
+    memset(blob, 0, total4 * sizeof(float4));
+    for (uint32_t k = 0; k < n_always; ++k) {
+        const rt_sphere &s = sph[always[k]];
+        slots[k] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
+        index[k] = always[k];
+    }
+    const float qnan = bits_float(0x7fc00000u);
+    for (uint32_t l = 0; l < n_leaves; ++l)
+        for (int q = 0; q < rt::kBvhLeaf; ++q) {
+            const size_t at = (size_t)n_always + (size_t)rt::kBvhLeaf * l + q;
+            if ((uint32_t)q >= leaf_count[l]) {
+                slots[at] = make_float4(qnan, qnan, qnan, qnan);
+                index[at] = 0xffffffffu;
+                continue;
+            }
+            const uint32_t ix = order[leaf_first[l] + q];
+            const rt_sphere &s = sph[ix];
+            slots[at] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
+            index[at] = ix;
+        }
+    for (size_t k = 0; k < 4 * (size_t)(n_leaves ? n_leaves - 1 : 0) && k < pair_rows.size(); ++k) pairs[k] = pair_rows[k];
+    const HostBox &rb = root.box;
+    const float cx = 0.5f * rb.lo[0] + 0.5f * rb.hi[0], cy = 0.5f * rb.lo[1] + 0.5f * rb.hi[1], cz = 0.5f * rb.lo[2] + 0.5f * rb.hi[2];
+    const float ex = rb.hi[0] - cx, ey = rb.hi[1] - cy, ez = rb.hi[2] - cz;
+    hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
+    hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
+    HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, total4 * sizeof(float4), hipMemcpyHostToDevice, stream));
+    if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
+    HIP_TRY(hipEventRecord(c->bvh_stage_ev, stream));
+    c->bvh_stage_used = true;
+    *n_leaves_out = n_leaves;
+    *depth_out = root.depth;
+    c->bvh_sah_root = root.ref;
+    *built = true;
+    return RT_OK;
+}
+
 }  // namespace
 
 namespace rt {
@@ -398,7 +583,7 @@ hipError_t prepare_bvh_build() {
 // The hierarchy of a large scene (rt_bvh_build_kernel), on `stream` behind the records.  Which spheres stay outside
 // the tree is decided here, from the host mirror, with the test the device applies to the same bits: 16 times the
 // median |radius| is the cut (ground, walls, big lights), non-finite records stay outside as well.
-int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
+int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
     c->bvh_ok = false;
     c->bvh = rt::BvhTables{};
     if (c->bvh_min <= 0 || n_total < (uint32_t)c->bvh_min || !c->d_bvh) return RT_OK;
@@ -419,6 +604,20 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
     if (n_tree < (uint32_t)c->bvh_min) return RT_OK;
     const uint32_t n_always = n_total - n_tree;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    // a full upload (rt_set_scene: the call blocks and the host has every record): the shape by surface area, on the host
+    if (full_upload && c->bvh_sah && n_tree >= kSahMinTree && n_tree <= kSahMaxTree) {
+        uint32_t sah_leaves = 0, sah_depth = 0;
+        bool built = false;
+        const int rc = build_on_host_sah(c, n_total, r_cut, n_always, n_tree, stream, &sah_leaves, &sah_depth, &built);
+        if (rc != RT_OK) return rc;
+        if (built) {
+            uint32_t root = rt::kBvhLeafRef;
+            if (sah_leaves > 1) root = c->bvh_sah_root;
+            c->bvh = rt::BvhTables{ c->d_bvh, n_always, sah_leaves, n_always + rt::kBvhLeaf * sah_leaves, sah_depth, root };
+            c->bvh_ok = true;
+            return RT_OK;
+        }
+    }
     if (n_tree <= kDeviceBuildMax) {
         uint32_t n_pad = 2;
         while (n_pad < n_tree) n_pad *= 2;
@@ -433,7 +632,7 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
     }
     uint32_t depth = 1;
     while ((1u << depth) < n_leaves) depth += 1;
-    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1 };
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1, n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef };
     c->bvh_ok = true;
     return RT_OK;
 }

@@ -47,13 +47,16 @@ struct SceneTables {
 //   pairs[4m .. 4m+3] = the two children of inner node m as { lo.xyz, bits(ref) }, { hi.xyz, bits(lowest scene index) }
 //            twice; ref = kBvhLeafRef | leaf number, or the number of the child's own pair.  The walk takes the nearer
 //            child first and keeps the other on a per-lane stack.  Inner node m - 1 is the one that splits its range
-//            of leaves in front of leaf m; the root is pair n_leaves / 2 - 1 (a tree of one leaf has no pairs).
+//            of leaves in front of leaf m, wherever that split lies: the device build halves every range (root = pair
+//            n_leaves / 2 - 1), the host build of a full scene upload cuts by surface area (rt_bvh.hip); BvhTables::root says
+//            which pair the walk starts at (a tree of one leaf has no pairs).
 constexpr int kBvhLeaf = 8;
 constexpr uint32_t kBvhLeafRef = 0x8000u;
 struct BvhTables {
     const float4 *blob;     // hdr | slots | index | pairs
     uint32_t n_always, n_leaves, n_slots;
     uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1)
+    uint32_t root;          // the root's pair (kBvhLeafRef: the tree is one leaf)
 };
 // offsets into the blob, in float4 units
 __host__ __device__ inline uint32_t bvh_slots_at() { return 2u; }

@@ -38,6 +38,8 @@ struct rt_ctx {
     size_t bvh_stage_cap = 0;           // float4
     hipEvent_t bvh_stage_ev = nullptr;
     bool bvh_stage_used = false;
+    int bvh_sah = 1;                    // full scene uploads build the hierarchy on the host with its shape chosen by surface area (rt_bvh.hip)
+    uint32_t bvh_sah_root = 0;
     int bvh_min = 56;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
@@ -131,7 +133,7 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // the hierarchy of large scenes (rt_bvh.hip): per-device set-up of the build kernel; build on `stream` for the scene the
 // context's host mirror holds (sets c->bvh / c->bvh_ok; nothing is read back)
 hipError_t prepare_bvh_build();
-int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream);
+int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload = false);
 int render_shard(rt_ctx *c, int n_samples, bool may_block);      // rt_api.hip: one shard's launch on its own stream
 
 // multi-device context (rt_multi.hip); `front` is the rt_ctx whose `multi` points at the record

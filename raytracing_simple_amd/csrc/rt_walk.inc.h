@@ -203,7 +203,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     float4 *s_hdr = lds;
     const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
-    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
+    const uint32_t root_ref = n_pairs ? P.bvh.root : kBvhLeafRef;
     constexpr uint32_t kNone = kWalkDone;
 #if RT_OPT_GLOBAL_TABLES
     // tables too large for LDS: pairs, slots and lights are read where they lie; staged: hdr | one stack per lane
@@ -630,7 +630,7 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
     float4 *s_pairs = s_hdr + 2;
     float4 *s_slots = s_pairs + 4 * n_pairs;
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
-    const uint32_t root_ref = n_pairs ? P.bvh.n_leaves / 2u - 1u : kBvhLeafRef;
+    const uint32_t root_ref = n_pairs ? P.bvh.root : kBvhLeafRef;
     const int tid = threadIdx.x;
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
     {

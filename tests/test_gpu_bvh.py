@@ -17,8 +17,9 @@ import bvh_check  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None):
+def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None, by_area=1):
     with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
         ctx.set_scene(sph)
@@ -44,15 +45,25 @@ def _same(got, want):
                                    lambda: scenes.mirror_box(64), lambda: scenes.demo_plus(16),
                                    lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET)])
 def test_device_built_tables_are_a_valid_hierarchy(maker):
+    """Both builds: the device's (leaf ranges halved; what device-resident updates get) and the host's of a full scene upload
+    (the shape chosen by surface area, leaves of up to 8; the default) -- every leaf reached once from the root pair the tables
+    name, every sphere in one leaf, inside every box above it, lowest scene indices right, the stack deep enough."""
     sph, _, _ = maker()
     sph = api.as_spheres(sph)
-    with api.RtContext(64, 64, diag=True) as ctx:
-        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
-        ctx.set_scene(sph)
-        b = bvh_check.read_bvh(ctx)
-    assert b is not None
-    assert bvh_check.check_structure(sph, b) == []
-    assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(sph)
+    leaves = {}
+    for by_area in (0, 1):
+        with api.RtContext(64, 64, diag=True) as ctx:
+            ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+            ctx.set_scene(sph)
+            b = bvh_check.read_bvh(ctx)
+        assert b is not None
+        assert bvh_check.check_structure(sph, b) == []
+        assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(sph)
+        leaves[by_area] = b["n_leaves"]
+        if by_area == 0 and b["n_leaves"] > 1:
+            assert b["root"] == b["n_leaves"] // 2 - 1
+    assert leaves[0] <= leaves[1] <= 2 * leaves[0]              # partial leaves only where they pay (below 128 tree spheres both are the device's)
 
 
 @pytest.mark.parametrize("maker,w,h,spp", [
@@ -70,6 +81,7 @@ def test_the_walk_equals_the_oracle(maker, w, h, spp):
     want = O.render(sph, cam, w, h, spp)
     got = _render(sph, cam, w, h, spp)
     _same(got, want)
+    _same(_render(sph, cam, w, h, spp, by_area=0), want)        # the device build's fixed shape
 
 
 def test_walk_and_plain_sweep_agree_ray_by_ray():
@@ -117,6 +129,7 @@ def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
     cam = host.compute_camera(orig, target, w, h)
     want = O.render(sph, cam, w, h, spp)
     _same(_render(sph, cam, w, h, spp), want)
+    _same(_render(sph, cam, w, h, spp, by_area=0), want)
     r = bvh_check.agreement(sph, cam, w, h, 60000)
     assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
 

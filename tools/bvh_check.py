@@ -31,7 +31,8 @@ from raytracing_simple_amd import api, host, scenes  # noqa: E402
 def read_bvh(ctx):
     counts = (C.c_uint32 * 4)()
     ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, None, 0, counts))
-    n_always, n_leaves, depth, n_slots = list(counts)
+    n_always, n_leaves, depth, root = list(counts)
+    n_slots = n_always + 8 * n_leaves
     if n_leaves == 0:
         return None
     at_index = 2 + n_slots
@@ -41,7 +42,7 @@ def read_bvh(ctx):
     ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, blob.ctypes.data_as(C.c_void_p), n4, counts))
     b4 = blob.reshape(n4, 4)
     return {"hdr": b4[:2], "slots": b4[2:at_index], "index": blob[4 * at_index:].view(np.uint32)[:n_slots], "pairs": b4[at_pairs:],
-            "n_always": n_always, "n_leaves": n_leaves, "stack_depth": depth, "n_slots": n_slots}
+            "n_always": n_always, "n_leaves": n_leaves, "stack_depth": depth, "n_slots": n_slots, "root": root}
 
 
 def check_structure(sph, b):
@@ -76,12 +77,19 @@ def check_structure(sph, b):
     pr = b["pairs"]
     seen_leaves, seen_pairs = [], set()
 
-    def below(ref):
+    deepest = [1]
+
+    def below(ref, level=1):
         """(spheres below ref), walking the pairs"""
+        deepest[0] = max(deepest[0], level)
         if ref & LEAF:
             lf = ref & (LEAF - 1)
             seen_leaves.append(lf)
-            return [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size] if i != 0xffffffff]
+            members = [int(i) for i in tree_idx[leaf_size * lf:leaf_size * lf + leaf_size]]
+            real_n = sum(1 for i in members if i != 0xffffffff)
+            if real_n == 0 or any(i != 0xffffffff for i in members[real_n:]):
+                bad.append(f"leaf {lf}: empty, or padding before a record")
+            return [i for i in members if i != 0xffffffff]
         if ref in seen_pairs or ref >= nl - 1:
             bad.append(f"pair {ref} reached twice or out of range")
             return []
@@ -90,7 +98,7 @@ def check_structure(sph, b):
         for side in (0, 1):
             A, B = pr[4 * ref + 2 * side], pr[4 * ref + 2 * side + 1]
             child = int(A[3:4].view(np.uint32)[0])
-            members = below(child)
+            members = below(child, level + 1)
             if members:
                 m = np.array(members)
                 ar = np.abs(rad[m]).astype(np.float64)
@@ -105,13 +113,14 @@ def check_structure(sph, b):
 
     import sys as _sys
     _sys.setrecursionlimit(10000)
-    root = (nl // 2 - 1) if nl > 1 else LEAF
+    # the root's pair comes with the tables: the device build halves every range of leaves (root = pair nl // 2 - 1), the
+    # host build of a full upload cuts by surface area
+    root = b["root"]
+    if nl == 1 and root != LEAF:
+        bad.append("a tree of one leaf has no root pair")
     everything = below(root)
-    depth = 1
-    while (1 << depth) < nl:
-        depth += 1
-    if b["stack_depth"] != depth + 1:
-        bad.append(f"stack depth {b['stack_depth']} != tree depth + 1 = {depth + 1}")
+    if b["stack_depth"] < deepest[0] or b["stack_depth"] > deepest[0] + 1:
+        bad.append(f"stack depth {b['stack_depth']} for a tree of {deepest[0]} levels")
     if sorted(seen_leaves) != list(range(nl)):
         bad.append("the pairs do not reach every leaf exactly once")
     if sorted(everything) != sorted(int(i) for i in real):

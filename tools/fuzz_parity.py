@@ -108,6 +108,8 @@ for seed in range(first, first + count):
         want = O.render(sph, cam, w, h, spp)
     with api.RtContext(w, h, diag=bvh_form != 0) as ctx:
         if bvh_form:
+            if os.environ.get("RT_FUZZ_TREE_SHAPE"):                     # 0: the device build's fixed shape (default: by surface area, on the host)
+                ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, int(os.environ["RT_FUZZ_TREE_SHAPE"])))
             ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
             ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))      # RT_FUZZ_BVH != 0: the hierarchy forced
         ctx.set_scene(sph); ctx.set_camera(cam)
