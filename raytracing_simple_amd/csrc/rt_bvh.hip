@@ -398,7 +398,8 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
 // BvhTables::root since it is no longer n_leaves / 2 - 1.  Against the fixed shape, on C3's rays (tools/sim_tree_shape.cpp): pair
 // steps per ray -15 % (shadow rays -28 %), leaf visits -7 %.  Returns RT_OK with *built = false when the result does not fit
 // the tables' allocation or the stack budget (the caller then takes the fixed shape).
-constexpr uint32_t kSahMaxTree = 16384;         // leaf and pair numbers stay below kBvhLeafRef; the build stays a few milliseconds
+constexpr uint32_t kSahMaxTree = 4096;          // the build stays a few milliseconds (rt_set_scene with it: 1.2 ms for 1024 spheres, 5.9 for 4096,
+                                                // 13 for 8192, 30 for 16384 against 0.4 / 1.2 / 2.2 / 3.2 with the device build: tools/tree_build_time.py)
 constexpr uint32_t kSahMinTree = 128;           // below 16 leaves the halved shape is as good (64 spheres: 6.95 against 7.03 ms) and one level shallower
 constexpr uint32_t kSahMaxDepth = 30;
 struct SahOut {
