@@ -262,10 +262,14 @@ RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
  * (12 and more: wave-ballot any-hit sharing), "..._pairs" (hundreds of small spheres: a hierarchy, where it measured
  * faster than the sweep on this scene), the same with "fast".  "" before the first launch.  Frames do not depend on it. */
 RT_API const char *rt_last_kernel(const rt_ctx *ctx);
-/* What the measurement on the current scene said (scenes with 56 to 1500 small spheres:
- * the first pass walks the hierarchy, the second sweeps, the faster form renders the rest): returns 0 = not decided
- * (yet, or a scene that is not measured), 1 = hierarchy, 2 = plain sweep, and the two measured times per pass in
- * milliseconds (0 when not measured).  Never blocks; of a multi-device context, the first shard's. */
+/* Hierarchy or plain sweep for the current scene (scenes with 56 to 1500 small spheres; larger ones always walk the
+ * hierarchy).  rt_set_scene builds the tree on the host and with it a surface-area estimate of what a ray costs either
+ * way; where the estimate is clear (predicted ratio outside 0.75 .. 1.33) it decides and nothing is measured, so a new
+ * scene's first frame costs what a frame costs.  Inside that band -- and after device-resident updates that changed the
+ * tree's size by a quarter -- the first launches time both forms (hierarchy warm, hierarchy timed, sweep warm, sweep timed;
+ * passes of the frame like any other) and the faster one renders the rest.  Returns 0 = not decided (yet, or a scene that
+ * has no choice), 1 = hierarchy, 2 = plain sweep, and the two MEASURED times per pass in milliseconds (0 when the estimate
+ * decided or nothing was measured).  Never blocks; of a multi-device context, the first shard's. */
 RT_API int rt_scene_choice(rt_ctx *ctx, double *hierarchy_ms_per_pass, double *sweep_ms_per_pass);
 
 /* Text of the calling thread's last failure ("" if none).                                    */

@@ -544,8 +544,13 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         // launches hand rank r of a region to wavefront r / 64, lane r % 64.  The tile costs measured under the old
         // deal no longer describe the workgroups: the heavy-first order is sorted again from the next launch's.
         if (c->use_deal && c->d_pixel_cost && !persist) {
-            p.pixel_cost = c->d_pixel_cost;
-            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 4) {
+            // only launches of 8 passes and more leave per-pixel costs (fewer are mostly noise, and the pricing launches and the
+            // adapter's small batches would overwrite a good plane with them); the unit is the form's own -- loop trips of the
+            // sweep kernels, rays of the walk -- so costs written by the other form are not sorted from
+            const int form_now = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal) ? 1 : 2;
+            if (c->pixel_cost_valid && c->pixel_cost_form != form_now) c->pixel_cost_valid = false;
+            if (n_samples >= 8) p.pixel_cost = c->d_pixel_cost;
+            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 4 && !natural_order) {
                 const int regions_x = (c->w + rt::kRegionW - 1) / rt::kRegionW, regions_y = (c->local_rows + c->deal_rows - 1) / c->deal_rows;
                 hipLaunchKernelGGL(rt_order_pixels_kernel, dim3((unsigned)(regions_x * regions_y)), dim3((unsigned)std::min(rt::kRegionW * c->deal_rows, 1024)), 0, stream,
                                    c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows, c->deal_group);
@@ -560,7 +565,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         }
         if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
-        if (c->cost_valid && !c->order_valid && n_samples >= 8) {
+        if (c->cost_valid && !c->order_valid && n_samples >= 8 && !natural_order) {
             // (a region: 32 pixels across = 4 single-wavefront tiles or one 4-wavefront tile; the deal's rows down)
             hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles, grid.x,
                                inst->waves == 1 ? 4u : 1u, (uint32_t)(c->deal_rows / rt::kTileH), (uint32_t)c->order_homes);
@@ -600,7 +605,10 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         c->cost_valid = true;
         c->cost_tiles = n_tiles;
     }
-    if (p.pixel_cost && n_samples >= 8) c->pixel_cost_valid = true;         // (per-pixel costs of fewer passes are mostly noise: no deal from them)
+    if (p.pixel_cost) {
+        c->pixel_cost_valid = true;
+        c->pixel_cost_form = c->last_form;
+    }
     c->seeds_default = false;           // this launch has written every seed pair the context renders
     c->pixels_current = c->pixel_write != 0;
     return RT_OK;
@@ -633,7 +641,8 @@ void probe_poll(rt_ctx *c, bool wait) {
     c->probe_ms[0] = ta;
     c->probe_ms[1] = tb;
     c->bvh_pick = ta <= 1.05 * tb ? 1 : 2;      // (a dead band of 5 % towards the usual winner: no flipping on a tie)
-    c->probe_tree = c->bvh.n_slots - c->bvh.n_always;
+    c->pick_estimated = false;
+    c->probe_tree = c->bvh_n_tree;
     c->probe_always = c->bvh.n_always;
     c->probe_updates = 0;
 }
@@ -657,6 +666,7 @@ int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
 
 void rearm_probe(rt_ctx *c) {
     c->bvh_pick = 0;
+    c->pick_estimated = false;
     c->probe_state = 0;
     c->probe_ms[0] = c->probe_ms[1] = 0.0;
     c->probe_updates = 0;
@@ -669,9 +679,12 @@ void rearm_probe_if_changed(rt_ctx *c) {
         rearm_probe(c);
         return;
     }
-    const uint32_t tree = c->bvh.n_slots - c->bvh.n_always, always = c->bvh.n_always;
+    const uint32_t tree = c->bvh_n_tree, always = c->bvh.n_always;        // spheres, not padded slots: the shaped tree of an upload has partial leaves
     auto moved = [](uint32_t now, uint32_t then) { return 4u * (now > then ? now - then : then - now) > then + 8u; };
-    if (moved(tree, c->probe_tree) || moved(always, c->probe_always) || ++c->probe_updates >= 256) rearm_probe(c);
+    if (moved(tree, c->probe_tree) || moved(always, c->probe_always) || ++c->probe_updates >= 256) {
+        rearm_probe(c);
+        c->bvh_est_valid = false;               // (the areas were the uploaded tree's: the changed scene is measured)
+    }
 }
 
 // A long launch that would walk its tiles in image order although their costs can be had -- the first frame of a scene or camera,
@@ -690,6 +703,21 @@ int launch_priced(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     return launch_form(c, n_samples, stream, form);
 }
 
+// The same question answered WITHOUT a launch, from the surface areas of the tree the host built at rt_set_scene (rt_bvh.hip):
+// a random line through the root box is expected to visit  P = sum of area(inner node) / area(root)  pairs and
+// L = sum of area(leaf) / area(root)  leaves, each ray sweeps the always-list besides, and the plain sweep tests all n
+// spheres.  Predicted time per ray of the walk over that of the sweep, the weights fitted to the probe's own timings of
+// both forms on the scene families of tools/choice_calibration.py (profiles/r04a_choice_calibration.jsonl):
+//     ratio = (kEstPair * P + kEstLeaf * L + n_always + kEstWalkFixed) / (n + kEstSweepFixed)
+// in units of one sphere test of the sweep.  Outside a band around 1 the estimate decides and nothing is measured -- a
+// new scene's first frame then costs what a frame costs; inside it the four probe launches run as before.
+constexpr double kEstPair = 6.0, kEstLeaf = 14.0, kEstWalkFixed = 30.0, kEstSweepFixed = 24.0;
+constexpr double kEstBandLo = 0.75, kEstBandHi = 1.33;
+double estimate_ratio(const rt_ctx *c) {
+    const double walk = kEstPair * c->bvh_est_pairs + kEstLeaf * c->bvh_est_leaves + (double)c->bvh.n_always + kEstWalkFixed;
+    return walk / ((double)c->scene.n_spheres + kEstSweepFixed);
+}
+
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false) {
     const bool measured = c->walk_forced == 0 && c->mode < 100;
     if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c))
@@ -697,10 +725,21 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false)
     // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
     // scene measured, open or packed, and one pass of the sweep at 1080p costs 2.6 ms at 1024 spheres,
     // 28 ms at 4096, 138 ms at 8192, seconds beyond LDS
-    if (c->bvh.n_slots - c->bvh.n_always >= 1500u || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
+    if (c->bvh_n_tree >= 1500u || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
     if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
         return launch_priced(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);
     probe_poll(c, false);
+    if (c->bvh_pick == 0 && c->probe_state == 0 && c->use_estimate && c->bvh_est_valid) {
+        const double r = estimate_ratio(c);
+        c->est_ratio = r;
+        if (r < kEstBandLo || r > kEstBandHi) {
+            c->bvh_pick = r < 1.0 ? 1 : 2;
+            c->pick_estimated = true;
+            c->probe_tree = c->bvh_n_tree;
+            c->probe_always = c->bvh.n_always;
+            c->probe_updates = 0;
+        }
+    }
     if (c->bvh_pick != 0) return launch_priced(c, n_samples, stream, c->bvh_pick);
     if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 1);    // probes in flight: the usual winner meanwhile
     if (may_block && n_samples >= 16) {
@@ -775,8 +814,10 @@ int ensure_stage_capacity(rt_ctx *c, uint32_t count) {
     return RT_OK;
 }
 
-// records [first, first+count) -> device, then the tables, all on `stream`
-int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *spheres, uint32_t n_total, hipStream_t stream) {
+// records [first, first+count) -> device, then the tables, all on `stream`.  `full_upload` is said by the caller, never inferred
+// from the range: only rt_set_scene (which blocks anyway) may take the host-side build of the hierarchy; an update --
+// whatever range it rewrites -- stays on the stream (rt_api.h: rt_update_spheres_async waits for nothing).
+int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *spheres, uint32_t n_total, hipStream_t stream, bool full_upload) {
     int rc = chain(c, stream);
     if (rc != RT_OK) return rc;
     if (count) {
@@ -803,7 +844,7 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
         HIP_TRY(hipGetLastError());
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, n_total, nl };
-    return rt::build_bvh(c, n_total, stream, first == 0 && count == n_total && count > 0);
+    return rt::build_bvh(c, n_total, stream, full_upload);
 }
 
 }  // namespace
@@ -921,8 +962,10 @@ RT_API void rt_destroy(rt_ctx *c) {
         return;
     }
     if (hipSetDevice(c->device) == hipSuccess) {
-        if (c->last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
-        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (!c->abandon_streams) {
+            if (c->last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+        }
         if (c->pinned_out) (void)hipHostUnregister(c->pinned_out);
         (void)hipFree(c->d_seeds);
         (void)hipFree(c->d_seeds0);
@@ -989,7 +1032,7 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     c->cost_valid = c->order_valid = false;
     c->pixel_cost_valid = c->deal_valid = false;
     rearm_probe(c);                     // a new scene: hierarchy or plain sweep is measured again
-    rc = upload_spheres(c, 0, count, spheres, count, c->stream);
+    rc = upload_spheres(c, 0, count, spheres, count, c->stream, true);
     if (rc != RT_OK) {
         c->have_scene = false;          // the tables are in an unknown state
         return rc;
@@ -1011,7 +1054,7 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     // the last frames' costs still predict this one (moving spheres): the order stays, and is sorted again from
     // fresh costs after a few changes
     if (++c->order_age >= 8) c->order_valid = c->deal_valid = false;
-    rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream);
+    rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream, false);
     if (rc == RT_OK) rearm_probe_if_changed(c);
     return rc;
 }
@@ -1648,6 +1691,23 @@ RT_API int rt_debug_walk_rays(rt_ctx *c, const float *rays8, uint32_t n_rays, ui
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_debug_walk_rays: %s", hipGetErrorString(e));
     return RT_OK;
+}
+// the estimate that settles hierarchy against sweep without a launch: out4 = { expected pair steps, expected leaf visits,
+// predicted walk / sweep time per ray, 1 if the verdict in force came from it (0: measured, or none yet) }; returns 1 when
+// the context holds an estimate for its scene.  rt_debug_set_choice_estimate(ctx, 0) switches it off: every undecided
+// scene is then measured (the calibration's way of getting both timings).
+RT_API int rt_debug_tree_estimate(rt_ctx *c, double *out4) {
+    if (!c || c->multi || !out4) return fail(RT_ERR_ARG, "null / multi-device context");
+    out4[0] = c->bvh_est_pairs;
+    out4[1] = c->bvh_est_leaves;
+    out4[2] = c->bvh_est_valid && c->bvh_ok ? estimate_ratio(c) : 0.0;
+    out4[3] = c->pick_estimated ? 1.0 : 0.0;
+    return c->bvh_est_valid && c->bvh_ok ? 1 : 0;
+}
+static int dbg_set_estimate(rt_ctx *c, int v) { c->use_estimate = v ? 1 : 0; rearm_probe(c); return RT_OK; }
+RT_API int rt_debug_set_choice_estimate(rt_ctx *c, int on) {
+    if (!c) return fail(RT_ERR_ARG, "ctx is null");
+    return dbg_apply(c, dbg_set_estimate, on);
 }
 RT_API int rt_debug_bvh_pick(rt_ctx *c) {
     if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");

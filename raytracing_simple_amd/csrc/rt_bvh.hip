@@ -262,6 +262,11 @@ struct HostBox {
     uint32_t low;
 };
 
+inline double host_box_area(const HostBox &b) {
+    const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
 int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, uint32_t n_tree, hipStream_t stream) {
     const std::vector<rt_sphere> &sph = c->h_spheres;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
@@ -356,6 +361,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
         leaf[l] = b;
     }
     // sibling pairs: a recursion over leaf ranges (a range's box is the union of its halves')
+    double area_inner = 0.0, area_leaf = 0.0;       // surface areas of the inner nodes below the root / of the leaves (estimate_forms)
     auto range_box = [&](uint32_t a, uint32_t b, auto &&self) -> HostBox {
         if (b - a == 1) return leaf[a];
         const uint32_t mid = (a + b) / 2;
@@ -363,6 +369,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
         const HostBox side[2] = { L, R };
         const uint32_t ca[2] = { a, mid }, cb[2] = { mid, b };
         for (int sd = 0; sd < 2; ++sd) {
+            (cb[sd] - ca[sd] == 1 ? area_leaf : area_inner) += host_box_area(side[sd]);
             const uint32_t ref = (cb[sd] - ca[sd] == 1) ? (rt::kBvhLeafRef | ca[sd]) : (ca[sd] + cb[sd]) / 2 - 1;
             pairs[4 * (size_t)(mid - 1) + 2 * sd] = make_float4(side[sd].lo[0], side[sd].lo[1], side[sd].lo[2], bits_float(ref));
             pairs[4 * (size_t)(mid - 1) + 2 * sd + 1] = make_float4(side[sd].hi[0], side[sd].hi[1], side[sd].hi[2], bits_float(side[sd].low));
@@ -384,6 +391,11 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
     HIP_TRY(hipEventRecord(c->bvh_stage_ev, stream));
     c->bvh_stage_used = true;
+    const double a_root = host_box_area(root);
+    if (n_leaves == 1) area_leaf = a_root;
+    c->bvh_est_valid = a_root > 0.0 && std::isfinite(a_root);
+    c->bvh_est_pairs = c->bvh_est_valid ? (n_leaves > 1 ? 1.0 : 0.0) + area_inner / a_root : 0.0;
+    c->bvh_est_leaves = c->bvh_est_valid ? area_leaf / a_root : 0.0;
     return RT_OK;
 }
 
@@ -444,10 +456,12 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
     std::vector<float4> pair_rows;          // 4 per pair, at 4 * (mid - 1); grown as leaves are emitted
     std::vector<double> right_area;
     bool too_deep = false;
+    double area_inner = 0.0, area_leaf = 0.0;       // as in build_on_host
     auto put_pair = [&](uint32_t mid, const SahOut &L, const SahOut &R) {
         if (pair_rows.size() < 4 * (size_t)mid) pair_rows.resize(4 * (size_t)mid, make_float4(0.f, 0.f, 0.f, 0.f));
         const SahOut *side[2] = { &L, &R };
         for (int sd = 0; sd < 2; ++sd) {
+            ((side[sd]->ref & rt::kBvhLeafRef) ? area_leaf : area_inner) += area(side[sd]->box);
             pair_rows[4 * (size_t)(mid - 1) + 2 * sd] = make_float4(side[sd]->box.lo[0], side[sd]->box.lo[1], side[sd]->box.lo[2], bits_float(side[sd]->ref));
             pair_rows[4 * (size_t)(mid - 1) + 2 * sd + 1] = make_float4(side[sd]->box.hi[0], side[sd]->box.hi[1], side[sd]->box.hi[2], bits_float(side[sd]->box.low));
         }
@@ -570,6 +584,11 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
     *depth_out = root.depth;
     c->bvh_sah_root = root.ref;
     *built = true;
+    const double a_root = area(rb);
+    if (n_leaves == 1) area_leaf = a_root;
+    c->bvh_est_valid = a_root > 0.0 && std::isfinite(a_root);
+    c->bvh_est_pairs = c->bvh_est_valid ? (n_leaves > 1 ? 1.0 : 0.0) + area_inner / a_root : 0.0;
+    c->bvh_est_leaves = c->bvh_est_valid ? area_leaf / a_root : 0.0;
     return RT_OK;
 }
 
@@ -587,6 +606,8 @@ hipError_t prepare_bvh_build() {
 int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
     c->bvh_ok = false;
     c->bvh = rt::BvhTables{};
+    c->bvh_n_tree = 0;
+    if (full_upload) c->bvh_est_valid = false;          // (a device-resident update keeps the upload's estimate: the probe logic decides when it is stale)
     if (c->bvh_min <= 0 || n_total < (uint32_t)c->bvh_min || !c->d_bvh) return RT_OK;
     std::vector<float> radii;
     radii.reserve(n_total);
@@ -605,6 +626,7 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     if (n_tree < (uint32_t)c->bvh_min) return RT_OK;
     const uint32_t n_always = n_total - n_tree;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    c->bvh_n_tree = n_tree;
     // a full upload (rt_set_scene: the call blocks and the host has every record): the shape by surface area, on the host
     if (full_upload && c->bvh_sah && n_tree >= kSahMinTree && n_tree <= kSahMaxTree) {
         uint32_t sah_leaves = 0, sah_depth = 0;
@@ -619,7 +641,10 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
             return RT_OK;
         }
     }
-    if (n_tree <= kDeviceBuildMax) {
+    // a full upload of a small tree: the fixed shape built on the host (the same tree the device builds: same splits, same
+    // boxes), because the host then knows the surface areas the choice between hierarchy and sweep is estimated from
+    const bool host_small = full_upload && n_tree < kSahMinTree;
+    if (n_tree <= kDeviceBuildMax && !host_small) {
         uint32_t n_pad = 2;
         while (n_pad < n_tree) n_pad *= 2;
         uint32_t level_nodes = 1;

@@ -40,6 +40,11 @@ struct rt_ctx {
     bool bvh_stage_used = false;
     int bvh_sah = 1;                    // full scene uploads build the hierarchy on the host with its shape chosen by surface area (rt_bvh.hip)
     uint32_t bvh_sah_root = 0;
+    uint32_t bvh_n_tree = 0;            // spheres inside the tree (the slots are padded to whole leaves)
+    // surface-area sums of a host-built tree (rt_bvh.hip): what a random line through the root box is expected to visit --
+    // pair steps (inner nodes, the root counted once) and leaves; the estimate that settles hierarchy against sweep without a launch
+    double bvh_est_pairs = 0.0, bvh_est_leaves = 0.0;
+    bool bvh_est_valid = false;
     int bvh_min = 56;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
@@ -48,6 +53,9 @@ struct rt_ctx {
     // hierarchy or plain sweep?  Decided per scene by measurement (rt_api.hip launch()): each form once warm and once
     // timed between events, in the same tile order; whichever took less time per pass renders the rest
     int bvh_pick = 0;                   // 0 = not decided yet, 1 = hierarchy, 2 = plain sweep
+    bool pick_estimated = false;        // ... and it came from the surface-area estimate, not from a measurement
+    int use_estimate = 1;               // diagnostics knob: 0 = every undecided scene is measured
+    double est_ratio = 0.0;             // the estimate's predicted walk / sweep time (0 = none made)
     int probe_state = 0;                // probe launches issued (0..4)
     uint32_t probe_tree = 0, probe_always = 0;   // the tree the verdict was measured on
     int probe_updates = 0;              // device-resident updates since the verdict (it is measured again after 256)
@@ -69,6 +77,7 @@ struct rt_ctx {
     uint16_t *d_pixel_cost = nullptr;
     uint16_t *d_deal = nullptr;
     bool pixel_cost_valid = false, deal_valid = false;
+    int pixel_cost_form = 0;            // the form (1 = walk: rays per pixel, 2 = sweep: loop trips per pixel) whose launch wrote d_pixel_cost
     int use_deal = 1, deal_rows = 32;   // rows of a region (8 .. 128)
     int order_homes = 1;                // heavy-first order: the tiles of a region go to workgroup numbers equal modulo this (8 = one XCD per region:
                                         // a fifth less traffic, 1 % more time -- measured, not the default); 1 = plain order
@@ -99,6 +108,8 @@ struct rt_ctx {
     hipStream_t stream = nullptr;       // the context's own (non-blocking) stream
     hipStream_t last_stream = nullptr;  // stream of the most recent launch / update (what readers wait for)
     bool used_foreign_stream = false;   // some launch went to a caller's stream
+    bool abandon_streams = false;       // a shard of a multi-device context whose gather failed: its stream may hold a transfer that never
+                                        // completes, so rt_destroy does not wait for it
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
     // rt_throttle: the rt_render_async launches in flight, each between two events (a ring, oldest at flight_next)
     struct Flight {

@@ -34,6 +34,7 @@ struct Rccl {
     void *handle = nullptr;
     int (*CommInitAll)(rcclComm *, int, const int *) = nullptr;
     int (*CommDestroy)(rcclComm) = nullptr;
+    int (*CommAbort)(rcclComm) = nullptr;         // optional: older libraries lack it
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, rcclComm, hipStream_t) = nullptr;
@@ -61,6 +62,7 @@ int load_rccl() {
     r.handle = h;
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
@@ -113,9 +115,20 @@ int refuse_if_broken(const rt_multi *m) {
     return RT_OK;
 }
 
+// A gather that failed half-way may have posted a receive or a send whose partner never comes: whether ncclGroupEnd then
+// returns the error or enqueues a transfer that never completes depends on the RCCL version.  So the communicators are
+// ABORTED (ncclCommAbort tears down what is in flight on them), and the shards' streams -- which may hold such a transfer --
+// are never synchronised again: rt_destroy skips the wait for a shard marked so.
 int mark_broken(rt_multi *m, int code, const char *what, const char *detail) {
     m->broken = true;
     snprintf(m->broken_why, sizeof m->broken_why, "%s: %s", what, detail ? detail : "?");
+    for (rcclComm &c : m->comm) {
+        if (c && g_rccl.CommAbort) {
+            (void)g_rccl.CommAbort(c);
+            c = nullptr;
+        }
+    }
+    for (rt_ctx *s : m->shard) s->abandon_streams = true;
     return fail(code, "%s failed: %s -- the multi-device context is now unusable", what, detail ? detail : "?");
 }
 

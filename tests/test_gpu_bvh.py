@@ -180,6 +180,32 @@ def test_moving_spheres_rebuild_the_hierarchy_on_the_stream():
             assert bvh_check.check_structure(sph, b) == []
 
 
+def test_an_update_of_the_whole_scene_stays_on_the_stream():
+    """rt_update_spheres_async that rewrites EVERY record (the usual animated scene) is still an update: the device build
+    on the stream (fixed shape: root pair = n_leaves / 2 - 1, full leaves), never the host build of rt_set_scene, which
+    waits for the staging buffer's previous copy (the range must not decide)."""
+    sph, orig, target = scenes.random_spheres(300)
+    sph = api.as_spheres(sph).copy()
+    w, h, spp = 64, 48, 2
+    cam = host.compute_camera(orig, target, w, h)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        shaped = bvh_check.read_bvh(ctx)
+        sph["p"][:, 0] += np.float32(0.5)
+        ctx.update_spheres(0, sph)                      # first = 0, count = n: the whole scene
+        b = bvh_check.read_bvh(ctx)
+        n_tree = b["n_slots"] - b["n_always"]
+        assert b["n_leaves"] == (int((np.abs(sph["rad"]) <= 16 * np.median(np.abs(sph["rad"]))).sum()) + 7) // 8
+        assert n_tree == 8 * b["n_leaves"] and b["root"] == b["n_leaves"] // 2 - 1
+        assert shaped["root"] != shaped["n_leaves"] // 2 - 1 or shaped["n_leaves"] != b["n_leaves"]     # (the upload's tree was the shaped one)
+        assert bvh_check.check_structure(sph, b) == []
+        got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        _same(got, O.render(sph, cam, w, h, spp))
+
+
 def test_fast_mode_with_the_hierarchy_is_as_close_as_fast_mode_without():
     """Fused arithmetic changes single bounces, and on a scene with mirrors and glass a changed bounce changes a path:
     fast mode's distance from parity mode is a property of the scene (the 50 dB gate is quoted on the Demo scene).
