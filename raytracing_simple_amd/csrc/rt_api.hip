@@ -704,18 +704,20 @@ int launch_priced(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
 }
 
 // The same question answered WITHOUT a launch, from the surface areas of the tree the host built at rt_set_scene (rt_bvh.hip):
-// a random line through the root box is expected to visit  P = sum of area(inner node) / area(root)  pairs and
-// L = sum of area(leaf) / area(root)  leaves, each ray sweeps the always-list besides, and the plain sweep tests all n
-// spheres.  Predicted time per ray of the walk over that of the sweep, the weights fitted to the probe's own timings of
-// both forms on the scene families of tools/choice_calibration.py (profiles/r04a_choice_calibration.jsonl):
-//     ratio = (kEstPair * P + kEstLeaf * L + n_always + kEstWalkFixed) / (n + kEstSweepFixed)
-// in units of one sphere test of the sweep.  Outside a band around 1 the estimate decides and nothing is measured -- a
-// new scene's first frame then costs what a frame costs; inside it the four probe launches run as before.
-constexpr double kEstPair = 6.0, kEstLeaf = 14.0, kEstWalkFixed = 30.0, kEstSweepFixed = 24.0;
+// a random line through the root box is expected to visit  P = sum of area(inner node) / area(root)  pairs (and leaves in
+// proportion), each ray sweeps the always-list besides, and the plain sweep tests all n spheres.  Predicted time per ray of
+// the walk over that of the sweep, in units of one sphere test of the sweep:
+//     ratio = (kEstPair * P + kEstAlways * n_always) / (n + kEstSweepFixed)
+// The three weights are a least-squares fit (log ratio) to the probe's own timings of both forms on 32 scenes of four
+// families -- spheres scattered on a plane, a closed box packed with mirror / glass spheres, a cloud in the air, the Demo
+// scene plus scattered spheres; 64 to 1400 spheres -- tools/choice_calibration.py, profiles/r04a_choice_calibration.jsonl:
+// rms error 10 %, 8 % at worst between 0.6 and 1.7.  (A term for the expected leaf visits fitted to zero: they go with P.)
+// Outside a band around 1 the estimate decides and nothing is measured -- a new scene's first frame then costs what a frame
+// costs; inside it the four probe launches run as before.
+constexpr double kEstPair = 20.9, kEstAlways = 10.1, kEstSweepFixed = 20.1;
 constexpr double kEstBandLo = 0.75, kEstBandHi = 1.33;
 double estimate_ratio(const rt_ctx *c) {
-    const double walk = kEstPair * c->bvh_est_pairs + kEstLeaf * c->bvh_est_leaves + (double)c->bvh.n_always + kEstWalkFixed;
-    return walk / ((double)c->scene.n_spheres + kEstSweepFixed);
+    return (kEstPair * c->bvh_est_pairs + kEstAlways * (double)c->bvh.n_always) / ((double)c->scene.n_spheres + kEstSweepFixed);
 }
 
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false) {

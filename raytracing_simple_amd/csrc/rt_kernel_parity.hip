@@ -73,6 +73,19 @@
 #include "rt_opts_reset.h"
 
 #if RT_DIAGNOSTICS
+#define RT_NS parity_pairs2          /* the second form of the walk kernel (rt_walk2.inc.h), under A/B */
+#define RT_KERNEL_NAME rt_trace_parity_pairs2
+#define RT_OPT_WALK 3
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs2_census
+#define RT_KERNEL_NAME rt_trace_parity_pairs2_census
+#define RT_OPT_WALK 4
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_pairs_census    /* the pair walk with a census of what it executes (counters[20..28]) */
 #define RT_KERNEL_NAME rt_trace_parity_pairs_census
 #define RT_OPT_WALK 2
@@ -135,6 +148,8 @@ static const Instance kParityInstances[] = {
     { parity_pairs_g::rt_trace_parity_pairs_g, "rt_trace_parity_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, 0 },
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
+    { parity_pairs2::rt_trace_parity_pairs2, "rt_trace_parity_pairs2", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs2_census::rt_trace_parity_pairs2_census, "rt_trace_parity_pairs2_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },

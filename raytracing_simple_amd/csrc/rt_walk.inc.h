@@ -188,6 +188,9 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
 }
 
 
+#if RT_OPT_WALK >= 3
+#include "rt_walk2.inc.h"      // the second form of the kernel (its own kernel body); RT_OPT_WALK 4: with its census
+#else
 #undef RT_WALK_COUNT
 #undef RT_WALK_CLOCK
 
@@ -611,6 +614,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
+#endif   // RT_OPT_WALK < 3
 
 #if RT_OPT_WALK == 1 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
 // Diagnostics (rt_debug_walk_rays): arbitrary rays through the walk AND through the plain sweep over the full table,

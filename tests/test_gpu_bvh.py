@@ -17,8 +17,9 @@ import bvh_check  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None, by_area=1):
+def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None, by_area=1, estimate=1):
     with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_choice_estimate(ctx._h, estimate))
         ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, bvh_min, 152 * 1024))
         ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, form))
@@ -135,18 +136,33 @@ def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
 
 
 def test_measured_choice_changes_no_bit_and_probes_split_a_blocking_call():
-    """form 0 = the library's behaviour: the first pass of a new scene walks the hierarchy, the second sweeps, the
-    faster form renders the rest.  Whatever it picks, and however the passes are split, the frame is the oracle's."""
+    """form 0 = the library's behaviour.  Where the surface-area estimate of the uploaded tree is clear it decides and nothing
+    is measured (one launch); inside its band -- or with the estimate switched off -- the first launches of a new scene time
+    both forms (hierarchy warm, hierarchy timed, sweep warm, sweep timed) and the faster renders the rest.  Whatever is
+    picked, and however the passes are split, the frame is the oracle's."""
     sph, orig, target = scenes.random_spheres(200)
     w, h, spp = 96, 64, 20
     cam = host.compute_camera(orig, target, w, h)
     want = O.render(sph, cam, w, h, spp)
-    one = _render(sph, cam, w, h, spp, bvh_min=64, form=0)
+    clear = _render(sph, cam, w, h, spp, bvh_min=64, form=0)
+    _same(clear, want)
+    assert clear["pick"] == 1 and clear["stats"]["launches"] == 1       # 200 spheres scattered on a plane: predicted ratio 0.43
+    one = _render(sph, cam, w, h, spp, bvh_min=64, form=0, estimate=0)
     _same(one, want)
     assert one["pick"] in (1, 2)                     # a blocking call of >= 16 passes waits for the verdict
     assert one["stats"]["launches"] == 5             # each form warm and timed, then the rest
-    many = _render(sph, cam, w, h, spp, bvh_min=64, form=0, passes=[1, 1, 2, 3, 13])
+    many = _render(sph, cam, w, h, spp, bvh_min=64, form=0, passes=[1, 1, 2, 3, 13], estimate=0)
     _same(many, want)
+    box, borig, btarget = scenes.mirror_box(200)     # a packed box of 200: predicted 0.97, inside the band -> measured
+    bcam = host.compute_camera(borig, btarget, w, h)
+    banded = _render(box, bcam, w, h, spp, bvh_min=64, form=0)
+    _same(banded, O.render(box, bcam, w, h, spp))
+    assert banded["pick"] in (1, 2) and banded["stats"]["launches"] == 5
+    c5, corig, ctarget = scenes.mirror_box(64)       # C5's box: predicted 1.65 -> the sweep, unmeasured
+    ccam = host.compute_camera(corig, ctarget, w, h)
+    swept = _render(c5, ccam, w, h, spp, bvh_min=56, form=0)
+    _same(swept, O.render(c5, ccam, w, h, spp))
+    assert swept["pick"] == 2 and swept["stats"]["launches"] == 1
     small = _render(*((lambda s: (s[0], host.compute_camera(s[1], s[2], w, h)))(scenes.demo_plus(16))), w, h, 4, bvh_min=64, form=0)
     assert small["pick"] == 0 and small["stats"]["launches"] == 1      # no hierarchy below bvh_min: nothing to measure
     big, orig, target = scenes.random_spheres(1700)                    # from 1500 spheres on the answer is known: no probe
@@ -239,11 +255,20 @@ def test_last_kernel_names_the_instance_the_scene_got():
         ctx.set_scene(sph)
         ctx.render_pass(2)
         assert ctx.last_kernel == "rt_trace_parity_coop_w1"
-        sph, orig, target = scenes.random_spheres(600)
+        sph, orig, target = scenes.random_spheres(600)     # 600 spheres scattered on a plane: the estimate is clear, nothing is measured
         ctx.set_scene(sph)
         ctx.set_camera(host.compute_camera(orig, target, w, h))
         ctx.reset()
-        ctx.render_pass(1)                    # the first two launches of a new large scene walk the hierarchy (warm, timed),
+        for _ in range(3):
+            ctx.render_pass(1)
+            assert ctx.last_kernel == "rt_trace_parity_pairs"
+        ch = ctx.scene_choice()
+        assert ch["picked"] == "hierarchy" and ch["hierarchy_ms_per_pass"] == 0 and ch["sweep_ms_per_pass"] == 0
+        sph, orig, target = scenes.mirror_box(200)         # a packed box of 200: inside the estimate's band, so it is measured
+        ctx.set_scene(sph)
+        ctx.set_camera(host.compute_camera(orig, target, w, h))
+        ctx.reset()
+        ctx.render_pass(1)                    # the first two launches of such a scene walk the hierarchy (warm, timed),
         assert ctx.last_kernel == "rt_trace_parity_pairs"
         ctx.render_pass(1)
         assert ctx.last_kernel == "rt_trace_parity_pairs"

@@ -421,6 +421,7 @@ def test_one_kernel_instance_renders_every_shard():
     w, h = 128, 96
     cam = host.compute_camera(orig, target, w, h)
     with api.RtContext(w, h, devices=[0, 0, 0], diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_choice_estimate(ctx._h, 0))           # (measured, whatever the surface-area estimate says of this scene)
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         done = 0
