@@ -38,7 +38,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 W, H, SPP = 1920, 1080, 64            # the headline workload (BASELINE.json configs[1]); --workload changes them
 TILE_ROWS = 8
-FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, chip-level parameters: 64 FLOP/clk/SIMD, i.e. every instruction a fused multiply-add
+FP32_UNFUSED_PEAK_TFLOPS = 78.65     # the same issue rate with one FLOP per instruction: what parity mode (no contraction allowed) can reach at most
 HBM_PEAK_GBS = 8000.0                # same table
 FLOP_PER_SPHERE_TEST = 20            # ray-sphere test
 FLOP_PER_BOX_TEST = 12               # the hierarchy's slab test: six fused multiply-adds (one per box plane)
@@ -56,6 +57,15 @@ def pmc_record(workload, mode):
     except (OSError, ValueError):
         return None
     return (data.get(workload) or {}).get(mode)
+
+
+def library_build_id():
+    """rt_build_id() of the product library this run renders with (a hash of csrc/, the public headers and the compiler flags)."""
+    try:
+        from raytracing_simple_amd import api
+        return api.build_id()
+    except Exception:       # noqa: BLE001 -- a library that cannot be asked has no identity to match
+        return None
 
 
 def walk_census(api, spheres, cam, w, h, spp):
@@ -87,6 +97,8 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
     ref_flops = FLOP_PER_SPHERE_TEST * sphere_tests
     alg_bytes = BYTES_PER_PIXEL_PER_LAUNCH * n_pixels + 44 * n_spheres + 60
     out = {"bound": "valu-fp32", "kernel": kernel, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "kernel_ms": round(kernel_ms, 4)}
+    if mode == "parity":
+        out["peak_unfused"] = FP32_UNFUSED_PEAK_TFLOPS
     if census is not None:
         flops = FLOP_PER_BOX_TEST * census["box_tests"] + FLOP_PER_SPHERE_TEST * (census["leaf_sphere_tests"] + census["always_sphere_tests"])
         out.update({"achieved": round(flops / sec / 1e12, 3), "frac": round(flops / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
@@ -103,6 +115,8 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
                     "algorithmic_flops_per_launch": ref_flops,
                     "work_model": "the reference's sweep, which this kernel executes test for test: every ray tests the spheres in scene order (all of them, "
                                   "or up to its first blocker): 20 FLOP x rt_stats.sphere_tests"})
+    if mode == "parity":        # parity mode may not fuse a multiply with an add: its ceiling is the issue rate at one FLOP per instruction
+        out["frac_unfused"] = round(out["achieved"] / FP32_UNFUSED_PEAK_TFLOPS, 5)
     if choice is not None and choice.get("picked") is not None:
         out["measured_choice"] = {"picked": choice["picked"], "hierarchy_ms_per_pass": round(choice["hierarchy_ms_per_pass"], 4),
                                   "sweep_ms_per_pass": round(choice["sweep_ms_per_pass"], 4),
@@ -112,7 +126,14 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
                   "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 6)}
     pm = pmc_record(workload, mode)
     out["traffic"] = None
-    if pm and pm.get("kernel", kernel) == kernel:
+    lib_id = library_build_id()
+    if pm and (pm.get("kernel", kernel) != kernel or pm.get("build_id") != lib_id):
+        # counters of a committed profile describe the code they were measured on, nothing else
+        out["counters_withheld"] = ("profiles/pmc_traffic.json holds counters of kernel %s from the library with build id %s; this run is kernel %s of "
+                                    "library %s: `traffic` and `executed` are not printed beside code they were not measured on (tools/profile_gpu.sh + "
+                                    "tools/summarize_profile.py make a record for this library)" % (pm.get("kernel"), pm.get("build_id"), kernel, lib_id))
+        pm = None
+    if pm:
         out["traffic"] = pm.get("hbm_bytes_per_launch")
         if out["traffic"] and out["traffic"] > 1.15 * alg_bytes:
             out["traffic_note"] = ("above the algorithmic bytes because pixels are dealt to wavefronts by cost in runs of 8: a wavefront's 64 pixels are 8 "

@@ -272,6 +272,10 @@ RT_API const char *rt_last_kernel(const rt_ctx *ctx);
  * decided or nothing was measured).  Never blocks; of a multi-device context, the first shard's. */
 RT_API int rt_scene_choice(rt_ctx *ctx, double *hierarchy_ms_per_pass, double *sweep_ms_per_pass);
 
+/* Identity of the sources and compiler flags this library was built from (16 hex digits).  tools/summarize_profile.py stamps
+ * every profile record with it; bench.py prints a committed profile's counters only beside the library they were measured on. */
+RT_API const char *rt_build_id(void);
+
 /* Text of the calling thread's last failure ("" if none).                                    */
 RT_API const char *rt_last_error(void);
 

@@ -35,9 +35,33 @@ UNITS = [
     ("rt_multi.hip", ["-ffp-contract=off"]),
     ("rt_bvh.hip", ["-ffp-contract=off"]),
     ("rt_host.cpp", ["-ffp-contract=off"]),
+    ("rt_build_id.cpp", []),
 ]
 DEPS = ["rt_device.h", "rt_internal.h", "rt_detmath.h", "rt_trace.inc.h", "rt_walk.inc.h", "rt_walk2.inc.h", "rt_sched.inc.h", "rt_opts_reset.h",
         os.path.join("..", "..", "include", "rt_api.h"), os.path.join("..", "..", "include", "rt_debug.h")]
+
+
+def source_hash():
+    """What the libraries are built from, as one number: every source under csrc/, the two public headers and the compiler flags.
+    It is compiled into both libraries (rt_build_id()), and tools/summarize_profile.py stamps every counter record with the id of
+    the library it profiled -- so that bench.py can tell whether a committed instruction count still describes the code it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h", ".cpp")))
+    for path in [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "rt_api.h"), os.path.join(ROOT, "include", "rt_debug.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    h.update(repr((COMMON, UNITS)).encode())
+    return h.hexdigest()[:16]
+
+
+def _build_id_header():
+    """csrc/_obj/rt_build_id.h, rewritten only when the id changes (its timestamp is what makes rt_build_id.cpp stale)."""
+    path = os.path.join(OBJ, "rt_build_id.h")
+    text = '#define RT_BUILD_ID "%s"\n' % source_hash()
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
 
 
 def hipcc():
@@ -82,11 +106,16 @@ def _version_script(path, headers):
 
 def _build_lib(cc, out, tag, defines, force, verbose, headers=("rt_api.h",)):
     deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
+    id_header = _build_id_header()
     jobs, objs = [], []
     for src, extra in UNITS:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ, src + tag + ".o")
         objs.append(op)
+        if src == "rt_build_id.cpp":            # depends on nothing but the id itself
+            if force or _stale(op, [sp, id_header]):
+                jobs.append([cc] + COMMON + defines + ["-I" + OBJ, "-c", sp, "-o", op])
+            continue
         if force or _stale(op, [sp] + deps):
             jobs.append([cc] + COMMON + defines + extra + ["-c", sp, "-o", op])
     if jobs:

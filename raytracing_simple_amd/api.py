@@ -20,11 +20,11 @@ SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_
            "rt_pin_output", "rt_set_pixel_write", "rt_read_pixels", "rt_read_pixels_async", "rt_throttle", "rt_device_pixels", "rt_set_pixel_buffer", "rt_stream",
            "rt_local_rows", "rt_current_sample", "rt_read_colors",
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_deinterleave_rows", "rt_compute_camera",
-           "rt_default_seeds", "rt_demo_scene", "rt_read_scene"]
+           "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_build_id"]
 # include/rt_debug.h: what librt_hip_diag.so exports on top of that
 DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_instance", "rt_debug_instance_name", "rt_debug_shard_kernel", "rt_debug_break_gather", "rt_debug_stage_tables", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
                  "rt_debug_rcp_probe", "rt_debug_set_regen_gate", "rt_debug_set_mat_lds_limit", "rt_debug_set_persist",
-                 "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_set_bvh", "rt_debug_set_tree_shape", "rt_debug_set_walk", "rt_debug_set_walk_round", "rt_debug_bvh_pick", "rt_debug_tree_estimate", "rt_debug_set_choice_estimate", "rt_debug_walk_rays", "rt_debug_read_bvh", "rt_debug_set_tile_order", "rt_debug_read_tile_order", "rt_debug_set_pixel_deal", "rt_debug_read_pixel_deal", "rt_debug_set_wg_waves", "rt_debug_counters", "rt_debug_counters_raw",
+                 "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_set_bvh", "rt_debug_set_tree_shape", "rt_debug_set_walk", "rt_debug_set_walk_round", "rt_debug_bvh_pick", "rt_debug_tree_estimate", "rt_debug_set_choice_estimate", "rt_debug_set_walk_tail", "rt_debug_walk_rays", "rt_debug_read_bvh", "rt_debug_set_tile_order", "rt_debug_read_tile_order", "rt_debug_set_pixel_deal", "rt_debug_read_pixel_deal", "rt_debug_set_wg_waves", "rt_debug_counters", "rt_debug_counters_raw",
                  "rt_debug_reset_by_copy", "rt_debug_probe_seeds", "rt_debug_sidelog_read", "rt_debug_timelog_enable", "rt_debug_timelog_tag",
                  "rt_debug_timelog_read", "rt_debug_wavelog_read"]
 
@@ -77,6 +77,7 @@ def load_library(diag=False):
         "rt_shard_count": (i32, [vp]),
         "rt_last_kernel": (C.c_char_p, [vp]),
         "rt_scene_choice": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "rt_build_id": (C.c_char_p, []),
         "rt_update_spheres_async": (i32, [vp, u32, u32, vp, vp]),
         "rt_read_pixels": (i32, [vp, vp]),
         "rt_read_pixels_async": (i32, [vp, vp, vp]),
@@ -131,6 +132,7 @@ def load_library(diag=False):
             "rt_debug_bvh_pick": (i32, [vp]),
             "rt_debug_tree_estimate": (i32, [vp, C.POINTER(C.c_double)]),
             "rt_debug_set_choice_estimate": (i32, [vp, i32]),
+            "rt_debug_set_walk_tail": (i32, [vp, i32, i32]),
             "rt_debug_walk_rays": (i32, [vp, vp, u32, vp]),
             "rt_debug_set_walk_round": (i32, [vp, i32]),
             "rt_debug_read_bvh": (i32, [vp, vp, u32, vp]),
@@ -384,6 +386,11 @@ def deinterleave_rows(full_ptr, gathered_ptr, w, h, nranks, tile_rows, pad_rows,
     """rt_deinterleave_rows on raw device pointers (the gather root's frame assembly)."""
     _check(load_library().rt_deinterleave_rows(C.c_void_p(full_ptr), C.c_void_p(gathered_ptr), w, h, nranks, tile_rows,
                                                pad_rows, device, C.c_void_p(stream or 0)))
+
+
+def build_id(diag=False):
+    """rt_build_id(): the identity of the sources and flags the loaded library was built from."""
+    return load_library(diag).rt_build_id().decode()
 
 
 def instance_mode(kernel_symbol):

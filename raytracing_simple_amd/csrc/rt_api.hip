@@ -513,6 +513,8 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
     }
     p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
+    p.walk_tail = c->walk_tail;
+    p.walk_tail_ready = c->walk_tail_ready;
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {
@@ -1657,6 +1659,12 @@ RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     return dbg_apply(c, dbg_set_walk_round, steps);
 }
 
+static int dbg_set_walk_tail(rt_ctx *c, int v) { c->walk_tail = v & 255; c->walk_tail_ready = v >> 8; return RT_OK; }
+// rt_walk2.inc.h: end a trip's walk phase once no more than `lanes` lanes still walk while at least `ready` wait to shade (0, 0 = never)
+RT_API int rt_debug_set_walk_tail(rt_ctx *c, int lanes, int ready) {
+    if (!c || lanes < 0 || lanes > 64 || ready < 0 || ready > 64) return fail(RT_ERR_ARG, "lanes %d, ready %d", lanes, ready);
+    return dbg_apply(c, dbg_set_walk_tail, lanes | (ready << 8));
+}
 static int dbg_set_walk_forced(rt_ctx *c, int v) { c->walk_forced = v ? 1 : 0; rearm_probe(c); return RT_OK; }
 // rt_walk.inc.h: pair steps per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
 // forced: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = the hierarchy whenever the scene has one

@@ -273,6 +273,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 const bool at_pair = W.cur < kBvhLeafRef;
                 const bool at_leaf = (W.cur >= kBvhLeafRef) & (W.cur != kWalkDone);
                 const unsigned long long bp = __builtin_amdgcn_ballot_w64(at_pair), bl = __builtin_amdgcn_ballot_w64(at_leaf);
+                // the tail of a trip: the last few walks run with a handful of lanes (two fifths of all steps ran with 8 lanes or
+                // fewer) while the lanes that are done wait.  Once few enough still walk and enough wait to make a full shade
+                // phase, the walk phase ends: the stragglers go on in the next trip, beside the rays that phase starts
+                if (P.walk_tail_ready > 0) {
+                    const int walking = __popcll(bp | bl);
+                    const int waiting = __popcll(__builtin_amdgcn_ballot_w64(W.cur == kWalkDone));
+                    if (walking <= P.walk_tail && waiting >= P.walk_tail_ready) break;
+                }
                 if (bp != 0ull && budget > 0 && (round > 0 || bl == 0ull)) {
                     budget = __builtin_amdgcn_readfirstlane(budget - 1);
                     round = __builtin_amdgcn_readfirstlane(round - 1);

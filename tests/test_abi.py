@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -219,3 +220,41 @@ def test_bench_refuses_to_measure_without_the_gpus_it_was_asked_for():
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=300,
                              env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
         assert res.returncode != 0 and text in (res.stderr + res.stdout), (argv, res.stderr[-500:])
+
+
+def test_profile_counters_are_bound_to_the_code_they_describe(tmp_path, monkeypatch):
+    """`roofline.executed` / `roofline.traffic` are constants of a committed profile.  They carry the build id
+    of the library they were measured on (rt_build_id(): a hash of csrc/, the public headers and the compiler flags), and
+    bench.py prints them only beside that library.  A touched kernel changes the id, and the line then drops both figures
+    and says why."""
+    import json
+    import shutil
+    sys.path.insert(0, ROOT)
+    import bench
+    from raytracing_simple_amd import _build
+    # (1) the library knows its id, and the id is what the build recipe computes from the sources it compiled
+    lib_id = api.build_id()
+    assert len(lib_id) == 16 and lib_id == _build.source_hash() == api.build_id(diag=True)
+    # (2) one character of one kernel source changes it
+    copy = tmp_path / "csrc"
+    shutil.copytree(_build.CSRC, copy, ignore=shutil.ignore_patterns("_obj"))
+    monkeypatch.setattr(_build, "CSRC", str(copy))
+    assert _build.source_hash() == lib_id
+    with open(copy / "rt_trace.inc.h", "a") as f:
+        f.write("// touched\n")
+    assert _build.source_hash() != lib_id
+    # (3) bench.py: counters beside the library they were measured on, withheld beside any other
+    rec = {"kernel": "rt_trace_parity_w1", "build_id": lib_id, "valu_insts_per_launch": 2.4e9, "active_lane_frac": 0.64,
+           "profiled_kernel_ms": 2.6, "valu_busy_frac_single_stream": 0.83, "hbm_bytes_per_launch": 77000000, "source": "test"}
+    pmc = tmp_path / "pmc.json"
+    pmc.write_text(json.dumps({"c2": {"parity": rec}}))
+    monkeypatch.setattr(bench, "PMC_FILE", str(pmc))
+    same = bench.roofline_block("rt_trace_parity_w1", 2.6, 1788296212, 1920 * 1080, 6, "c2", "parity")
+    assert same["traffic"] == 77000000 and same["executed"]["valu_insts_per_launch"] == 2.4e9 and "counters_withheld" not in same
+    assert same["frac_unfused"] == pytest.approx(2 * same["frac"], rel=1e-3) and same["peak_unfused"] < same["peak"]
+    monkeypatch.setattr(bench, "library_build_id", lambda: "0123456789abcdef")          # the library has changed since the profile
+    stale = bench.roofline_block("rt_trace_parity_w1", 2.6, 1788296212, 1920 * 1080, 6, "c2", "parity")
+    assert stale["traffic"] is None and "executed" not in stale and lib_id in stale["counters_withheld"]
+    monkeypatch.setattr(bench, "library_build_id", lambda: lib_id)                       # same library, another kernel instance
+    other = bench.roofline_block("rt_trace_parity", 2.6, 1788296212, 1920 * 1080, 6, "c2", "parity")
+    assert other["traffic"] is None and "executed" not in other

@@ -11,6 +11,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
+# which library these counters describe (raytracing_simple_amd/_build.py source_hash; bench.py compares it with the library it runs)
+python3 -c "import sys; sys.path.insert(0, '$R'); from raytracing_simple_amd import api; print(api.build_id())" > "$OUT/build_id.txt"
 BENCH="python3 $R/bench.py --mode $MODE --workload $WL --steps 10 --warmup 3 --no-cpu --no-extras"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {

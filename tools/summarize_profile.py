@@ -21,12 +21,18 @@ def main():
     src = os.path.join(root, "gpurun_out", tag)
     kern = sys.argv[4] if len(sys.argv) > 4 else "rt_trace_" + mode + "_w1"      # the C2 instance: single-wavefront workgroups
     summary = {"mode": mode, "kernel": kern, "source": f"gpurun_out/{tag} (tools/profile_gpu.sh)"}
+    # the library the counters were measured on (written on the GPU box by tools/profile_gpu.sh: rt_build_id() = a hash of
+    # csrc/, the public headers and the compiler flags); bench.py prints these figures only beside that very library
+    try:
+        summary["build_id"] = open(os.path.join(src, "build_id.txt")).read().strip()
+    except OSError:
+        summary["build_id"] = None
     stats = find(os.path.join(src, "trace"), "*kernel_stats.csv")
     lines = []
     if stats:
         with open(stats) as f:
             rows = list(csv.DictReader(f))
-        lines.append("| kernel | calls | avg ns | min ns | max ns | % |")
+        lines.append("| kernel | calls | avg ns, ALL launches (pricing and probe launches of a few passes included: compare `avg_kernel_ns_timed_launches` below with ms_per_step) | min ns | max ns | % |")
         lines.append("|---|---|---|---|---|---|")
         for r in rows:
             lines.append(f"| {r['Name']} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
@@ -116,7 +122,7 @@ def main():
             data = json.load(open(pmc_path))
         except (OSError, ValueError):
             data = {}
-        rec = {"kernel": kern, "valu_insts_per_launch": summary["valu_insts_per_launch"], "active_lane_frac": round(summary["active_lane_frac"], 4),
+        rec = {"kernel": kern, "build_id": summary.get("build_id"), "valu_insts_per_launch": summary["valu_insts_per_launch"], "active_lane_frac": round(summary["active_lane_frac"], 4),
                "profiled_kernel_ms": round(summary.get("avg_kernel_ns_timed_launches", summary["avg_kernel_ns"]) / 1e6, 4),
                "source": f"profiles/{out_name}.{{md,json}} (rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --workload {key} --no-extras`, tools/profile_gpu.sh)"}
         if "valu_busy_frac_single_stream" in summary:
