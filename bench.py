@@ -87,6 +87,27 @@ def walk_census(api, spheres, cam, w, h, spp):
             "lanes_per_leaf_step": round(raw[23] / max(raw[22], 1), 1), "reference_equivalent_sphere_tests": st["sphere_tests"]}
 
 
+def first_frame(api, mode, spheres, cam, w, h, spp, steady_ms):
+    """A NEW scene's first frame -- what rt_render(scene, cam, out, w, h, spp), the call north_star names, is by definition: a
+    fresh context (GPU warm, outside every timed region), rt_set_scene + rt_set_camera + ONE blocking frame.  `ms` is the device
+    time between the events around everything that frame launched (pricing launches, probes if the scene is measured),
+    `wall_ms` the host time of set_scene + the frame (tree build on the host, uploads), `vs_steady` = ms over the steady frame."""
+    with api.RtContext(w, h) as c:
+        c.set_mode(mode)
+        c.set_camera(cam)
+        t0 = time.perf_counter()
+        c.set_scene(spheres)
+        c.render_pass(spp, copy=False)
+        wall = time.perf_counter() - t0
+        st, ch = c.stats(), c.scene_choice()
+        out = {"ms": round(st["last_kernel_ms"], 4), "launches": int(st["launches"]), "vs_steady": round(st["last_kernel_ms"] / steady_ms, 3),
+               "wall_ms_with_set_scene": round(wall * 1e3, 3), "kernel": c.last_kernel}
+        if ch["picked"] is not None:
+            out["choice"] = ch["picked"] + (" (measured: four probe launches inside this frame)" if ch["hierarchy_ms_per_pass"] > 0
+                                            else " (from the uploaded tree's surface areas: nothing measured)")
+    return out
+
+
 def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workload, mode, census=None, choice=None):
     """The `roofline` object of one kernel: algorithmic work per launch over its measured duration against the FP32 vector
     peak, with the HBM view nested beside it.  Plain sweeps execute exactly the reference's tests, so there the algorithmic
@@ -468,7 +489,7 @@ def main():
         frames_ok = {"frames_checked": frames_checked[0], "wrong_pixels": bad} if rank == 0 else None
 
     # ---- extras, N = 1, outside the headline's timed regions -------------------------------------------
-    other, target, in_library, large, unseen = None, None, None, None, None
+    other, target, in_library, large, unseen, first = None, None, None, None, None, None
     if world == 1 and not args.no_extras:
         # The headline renders the SAME frame K times (reset + SPP passes, fixed seed stream: what makes it checkable against the
         # oracle), and the library schedules a launch from what the launch before cost (tile order, deal of pixels) -- costs that
@@ -488,6 +509,9 @@ def main():
                           "the deal of pixels have never seen" % (SPP, SPP, 7 * SPP - 1),
                   "launches": 6, "kernel_ms": round(sum(ms_u) / 6, 4), "value": round(rays_u / sum(ms_u) / 1e3, 1), "unit": "Mray/s (kernel time)",
                   "headline_kernel_ms": round(kernel_ms, 4)}
+        first = {"what": "a new scene's first frame on a warm GPU: fresh context, rt_set_scene, rt_set_camera, one blocking frame (device ms between "
+                         "the events around everything it launched); vs_steady = over this line's steady kernel time of the same frame",
+                 "headline": first_frame(api, mode, spheres, cam, W, H, SPP, kernel_ms)}
         # the other arithmetic mode on the same workload
         other_mode = api.RT_MODE_FAST if mode == api.RT_MODE_PARITY else api.RT_MODE_PARITY
         for c in ctxs:
@@ -520,6 +544,7 @@ def main():
                       "value": round(rays16 * k16 / el16 / 1e6, 1), "unit": "Mray/s", "kernel": c16[0].last_kernel, "kernel_ms": round(kms16, 4),
                       "roofline": roofline_block(c16[0].last_kernel, kms16, st16["sphere_tests"], W * H, len(sph16), "c16", args.mode),
                       "frames_in_flight": {"frames": F, "ms_per_step": round(el16F / k16 * 1e3, 4), "value": round(rays16 * k16 / el16F / 1e6, 1)}}
+            first["north_star_target"] = first_frame(api, mode, sph16, cam16, W, H, SPP, kms16)
             if not args.no_cpu and mode == api.RT_MODE_PARITY:
                 base16, cpu16 = cpu_baseline(sph16, cam16, W, H, SPP, reference_too=False)
                 target["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(px16, cpu16["pixels"]))
@@ -542,6 +567,7 @@ def main():
                         cl.reset_async(); cl.render_pass(16, copy=False)
                     dt3 = time.perf_counter() - t0
                     st3, ch3, kern3 = cl.stats(), cl.scene_choice(), cl.last_kernel
+                first["large_scene"] = first_frame(api, mode, sph3, cam3, W, H, 16, st3["last_kernel_ms"])
                 cen3 = walk_census(api, sph3, cam3, W, H, 16) if "_pairs" in kern3 else None
                 large = {"workload": "C3: 1024 random spheres, 1920x1080, 16 spp, default seed stream", "steps": k3,
                          "ms_per_step": round(dt3 / k3 * 1e3, 4), "value": round((st3["samples"] + st3["shadow_rays"]) * k3 / dt3 / 1e6, 1),
@@ -637,6 +663,8 @@ def main():
                                     "note": "the same K frames, F in flight on separate streams: throughput, not ms/frame"}
     if unseen is not None:
         line["unseen_passes"] = unseen
+    if first is not None:
+        line["first_frame"] = first
     if target is not None:
         line["north_star_target"] = target
     if large is not None:

@@ -60,7 +60,8 @@ RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a la
  * distance bits and scene index (~0 for a miss); shadow ray: the first blocking scene index (the sphere count for
  * none) and 0.  The two must be equal for every ray whatever its origin and direction. */
 RT_API int rt_debug_walk_rays(rt_ctx *ctx, const float *rays8, uint32_t n_rays, uint32_t *out4);
-RT_API int rt_debug_set_walk_tail(rt_ctx *ctx, int lanes, int ready);   /* the second form of the walk kernel: a trip's walk phase ends once <= lanes lanes still walk and >= ready lanes wait to shade (0, 0: never) */
+RT_API int rt_debug_create_breakdown(double *out8);   /* host ms of the last rt_create of this process: device query, stream + events, allocations, kernel function attributes (code object load on a first context), seed stream generated, its upload, restore kernel + wait, total */
+RT_API int rt_debug_set_walk_tail(rt_ctx *ctx, int lanes);   /* the second form of the walk kernel: leaf steps of no more than `lanes` lanes are done by the wavefront, one sphere test per lane (0: never) */
 RT_API int rt_debug_tree_estimate(rt_ctx *ctx, double *out4);   /* { expected pair steps, expected leaf visits, predicted walk / sweep time per ray, verdict came from the estimate }; returns 1 if the scene has an estimate */
 RT_API int rt_debug_set_choice_estimate(rt_ctx *ctx, int on);  /* 0: the surface-area estimate never decides hierarchy against sweep (every undecided scene is measured) */
 RT_API int rt_debug_bvh_pick(rt_ctx *ctx);   /* 0 = not decided yet, 1 = the hierarchy, 2 = the plain sweep (of this scene, by measurement) */

@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -27,6 +28,16 @@
 
 namespace {
 thread_local char g_err[512] = "";
+// where the last rt_create / rt_create_sharded spent its host time, in milliseconds (rt_debug_create_breakdown):
+// [0] device query, [1] stream + events, [2] device allocations, [3] kernel function attributes (the first context of a
+// process pays the load of the library's code object here), [4] default seed stream generated on the host, [5] its upload,
+// [6] the restore kernel (first launch) and the wait for it, [7] total
+double g_create_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
 }
 
 namespace rt {
@@ -358,8 +369,10 @@ int wait_all(rt_ctx *c) {
 
 int upload_default_seeds(rt_ctx *c) {
     const size_t count = 2 * (size_t)c->w * (size_t)c->h;
+    const double t0 = now_ms();
     std::vector<uint32_t> host(count);
     rt_default_seeds(host.data(), count);
+    g_create_ms[4] = now_ms() - t0;
     HIP_TRY(hipMemcpyAsync(c->d_seeds0, host.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));          // `host` goes out of scope
     return RT_OK;
@@ -514,7 +527,6 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
     p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
     p.walk_tail = c->walk_tail;
-    p.walk_tail_ready = c->walk_tail_ready;
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {
@@ -878,6 +890,7 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
     if (tile_rows <= 0 || tile_rows % rt::kTileH != 0)
         return fail(RT_ERR_ARG, "tile_rows must be a positive multiple of %d", rt::kTileH);
 
+    const double t_begin = now_ms();
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
@@ -909,7 +922,10 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
 
     int rc = select_device(c);
     const size_t px = (size_t)w * (size_t)h;
+    g_create_ms[0] = now_ms() - t_begin;
     auto alloc_all = [&]() -> int {
+        double t = now_ms();
+        auto lap = [&](int k) { const double n_ = now_ms(); g_create_ms[k] = n_ - t; t = n_; };
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->last_stream = c->stream;
         HIP_TRY(hipEventCreate(&c->ev0));
@@ -917,6 +933,7 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
         for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreate(&c->probe_ev[k]));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming));
         for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming));
+        lap(1);
         HIP_TRY(hipMalloc(&c->d_seeds, 2 * px * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_seeds0, 2 * px * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_colors, 3 * px * sizeof(float)));
@@ -932,6 +949,7 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
             HIP_TRY(hipMalloc(&c->d_pixel_cost, ((size_t)rows * w + 4) * sizeof(uint16_t)));
             HIP_TRY(hipMalloc(&c->d_deal, deal_entries * sizeof(uint16_t)));
         }
+        lap(2);
         // function attributes (dynamic-LDS limit) are per device, not per context
         static std::mutex mu;
         static bool prepared[64] = {};
@@ -944,8 +962,14 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
                 if (device < 64) prepared[device] = true;
             }
         }
+        lap(3);
         int r2 = upload_default_seeds(c);
-        return r2 == RT_OK ? restore_state(c) : r2;
+        lap(5);
+        g_create_ms[5] -= g_create_ms[4];
+        if (r2 == RT_OK) r2 = restore_state(c);
+        lap(6);
+        g_create_ms[7] = now_ms() - t_begin;
+        return r2;
     };
     if (rc == RT_OK) rc = alloc_all();
     if (rc != RT_OK) {
@@ -1489,6 +1513,12 @@ RT_API int rt_render(const rt_scene *scene, const rt_camera *cam, uint32_t *out,
 #if RT_DIAGNOSTICS
 // =============================== diagnostics build only (rt_debug.h) ===========================
 
+// host milliseconds of the last rt_create / rt_create_sharded of this process, by phase (g_create_ms above)
+RT_API int rt_debug_create_breakdown(double *out8) {
+    if (!out8) return fail(RT_ERR_ARG, "null argument");
+    memcpy(out8, g_create_ms, sizeof g_create_ms);
+    return RT_OK;
+}
 RT_API int rt_debug_variant_count(int fast) {
     int n = 0;
     (void)instances(fast != 0, &n);
@@ -1659,11 +1689,11 @@ RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     return dbg_apply(c, dbg_set_walk_round, steps);
 }
 
-static int dbg_set_walk_tail(rt_ctx *c, int v) { c->walk_tail = v & 255; c->walk_tail_ready = v >> 8; return RT_OK; }
-// rt_walk2.inc.h: end a trip's walk phase once no more than `lanes` lanes still walk while at least `ready` wait to shade (0, 0 = never)
-RT_API int rt_debug_set_walk_tail(rt_ctx *c, int lanes, int ready) {
-    if (!c || lanes < 0 || lanes > 64 || ready < 0 || ready > 64) return fail(RT_ERR_ARG, "lanes %d, ready %d", lanes, ready);
-    return dbg_apply(c, dbg_set_walk_tail, lanes | (ready << 8));
+static int dbg_set_walk_tail(rt_ctx *c, int v) { c->walk_tail = v; return RT_OK; }
+// rt_walk2.inc.h: leaf steps that no more than `lanes` lanes take part in are done by the wavefront, one sphere test per lane (0 = never)
+RT_API int rt_debug_set_walk_tail(rt_ctx *c, int lanes) {
+    if (!c || lanes < 0 || lanes > 64) return fail(RT_ERR_ARG, "lanes %d", lanes);
+    return dbg_apply(c, dbg_set_walk_tail, lanes);
 }
 static int dbg_set_walk_forced(rt_ctx *c, int v) { c->walk_forced = v ? 1 : 0; rearm_probe(c); return RT_OK; }
 // rt_walk.inc.h: pair steps per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and

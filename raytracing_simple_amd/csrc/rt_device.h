@@ -111,8 +111,7 @@ struct LaunchParams {
     // offsets, and with them their scalar loads and SGPR allocation, are what they were without it
     int walk_steps;         // rt_walk.inc.h: pair steps a lane may take per loop trip
     int walk_round;         // ... and in a row before the leaf step of the lanes that hold a leaf
-    int walk_tail;          // rt_walk2.inc.h: the walk phase of a trip ends early once no more than this many lanes still walk ...
-    int walk_tail_ready;    // ... while at least this many wait to shade (0 = never: a trip lasts as long as its longest walk)
+    int walk_tail;          // rt_walk2.inc.h: a leaf step that no more than this many lanes take part in is done by the wavefront (leaf_step_coop; 0 = never)
     BvhTables bvh;
 };
 

@@ -106,6 +106,99 @@ RT_DEV void leaf_step2(const float4 *s_slots, const uint32_t *index, uint16_t *m
     W.sp = below;
 }
 
+// The same leaf step done by the WAVEFRONT for a few lanes.  Half of all leaf steps run with eight lanes or fewer -- the last
+// walks of a trip, while the other lanes wait -- and each costs eight sphere tests one after the other.  Here the lanes that
+// hold a leaf (`holders`, at most 8 per round) post their ray in a per-wavefront LDS mailbox, and each is served by a group of
+// eight lanes: lane m of group q runs the reference's test of sphere m of ray q's leaf -- ONE test per lane, whoever's lane it
+// is -- and the group combines with three DPP minima: the nearest hit's distance bits (a closest-hit ray), or the lowest
+// blocking scene index (a shadow ray: the blockers read their index, the others do not).  The candidate and the rule are the
+// per-lane step's; an exact tie in distance (two spheres of the leaf, or a sphere and the ray's best so far) sends the ray's
+// own lane through that step instead.  Every lane of the wavefront is in the loop that calls this (no lane leaves the kernel's
+// loop before the wavefront does), which is what lets a group count on its eight lanes.
+constexpr int kCoopLeafRays = 8;
+RT_DEV uint32_t group8_min(uint32_t key) {
+    uint32_t k = key, t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]: lane ^ 1
+    k = t < k ? t : k;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]: lane ^ 2
+    k = t < k ? t : k;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, 0x141, 0xf, 0xf, false);     // row_half_mirror: lane -> 7 - lane of its eight
+    k = t < k ? t : k;
+    return k;
+}
+// Returns true for a holder that must still take the per-lane step.
+RT_DEV bool leaf_step_coop(const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stride, uint32_t n_always, V3 o, V3 d,
+                           bool shadow, bool at_leaf, unsigned long long holders, float4 *mail, uint2 *res, Walk &W) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int q = lane >> 3, m = lane & 7;
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(holders >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)holders, 0u));
+    const int n_hold = __popcll(holders);
+    const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (W.cur & (kBvhLeafRef - 1u));
+    bool exact = false;                         // this holder must take the per-lane step (a tie)
+    for (int first = 0; first < n_hold; first += kCoopLeafRays) {       // (wave-uniform: rounds of up to eight rays)
+        const bool mine = at_leaf & (rank >= first) & (rank < first + kCoopLeafRays);
+        if (mine) {
+            mail[2 * (rank - first)] = make_float4(o.x, o.y, o.z, W.far);
+            mail[2 * (rank - first) + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(sl | (shadow ? 0x80000000u : 0u)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool serve = q < n_hold - first;
+        uint32_t key = 0xffffffffu, cand = 0u;
+        bool tie = false;
+        if (serve) {
+            const float4 ra = mail[2 * q], rb = mail[2 * q + 1];
+            const uint32_t tag = __float_as_uint(rb.w);
+            cand = (tag & 0x7fffffffu) + (uint32_t)m;
+            const bool sh = (tag >> 31) != 0u;
+            const HitRoots hr = hit_roots(hit_pre(s_slots[cand], mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z)));
+            const bool nearer = hr.hit & (hr.t < ra.w);
+            tie = !sh & hr.hit & (hr.t == ra.w);
+            if (sh) {
+                if (nearer) key = index[cand];                                      // a blocker: its scene index
+            } else {
+                key = nearer ? __float_as_uint(hr.t) : 0xffffffffu;                 // (distances are positive: their bits order like they do)
+            }
+        }
+        const uint32_t best = group8_min(key);
+        const bool win = serve & (key == best) & (key != 0xffffffffu);
+        const unsigned long long wins = __builtin_amdgcn_ballot_w64(win), ties = __builtin_amdgcn_ballot_w64(tie);
+        const uint32_t my_wins = (uint32_t)(wins >> (8 * q)) & 0xffu, my_ties = (uint32_t)(ties >> (8 * q)) & 0xffu;
+        const uint32_t need_exact = ((my_wins & (my_wins - 1u)) != 0u || my_ties != 0u) ? 0x80000000u : 0u;
+        if (serve) {
+            if (my_wins != 0u) {
+                if ((my_wins & (0u - my_wins)) == (1u << m)) res[q] = make_uint2(best, cand | need_exact);      // the (first) winner reports
+            } else if (m == 0) {
+                res[q] = make_uint2(0xffffffffu, need_exact);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (mine) {
+            const uint2 rr = res[rank - first];
+            exact = (rr.y >> 31) != 0u;
+            if (!exact) {
+                if (shadow) {
+                    W.idx = rr.x < W.idx ? rr.x : W.idx;
+                } else if (rr.x != 0xffffffffu) {
+                    W.far = __uint_as_float(rr.x);
+                    W.slot = rr.y & 0x7fffffffu;
+                    W.idx = kWalkIndexOpen;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (at_leaf & !exact) {
+        const int below = W.sp > 0 ? W.sp - 1 : 0;
+        W.cur = W.sp > 0 ? (uint32_t)my_stack[below * stride] : kWalkDone;
+        W.sp = below;
+    }
+    return exact;
+}
+
 #undef RT_W2_COUNT
 #undef RT_W2_CLOCK
 #undef RT_W2_HIST
@@ -255,8 +348,13 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #define RT_W2_CLOCK(arr, k, t0)
 #endif
 
+    __shared__ __attribute__((aligned(16))) float4 s_mail[RT_OPT_WG_WAVES][2 * kCoopLeafRays];
+    __shared__ uint2 s_res[RT_OPT_WG_WAVES][kCoopLeafRays];
     for (;;) {
-        if (st == kNew && s >= s_end) break;
+        // (a lane that has rendered its samples stays in the loop, idle, until its wavefront has: the cooperative leaf step
+        // counts on all 64 lanes, and the loop's exit is then a scalar branch)
+        const bool finished = st == kNew && s >= s_end;
+        if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) break;
 #if RT_OPT_WALK == 4
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
         const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
@@ -273,14 +371,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 const bool at_pair = W.cur < kBvhLeafRef;
                 const bool at_leaf = (W.cur >= kBvhLeafRef) & (W.cur != kWalkDone);
                 const unsigned long long bp = __builtin_amdgcn_ballot_w64(at_pair), bl = __builtin_amdgcn_ballot_w64(at_leaf);
-                // the tail of a trip: the last few walks run with a handful of lanes (two fifths of all steps ran with 8 lanes or
-                // fewer) while the lanes that are done wait.  Once few enough still walk and enough wait to make a full shade
-                // phase, the walk phase ends: the stragglers go on in the next trip, beside the rays that phase starts
-                if (P.walk_tail_ready > 0) {
-                    const int walking = __popcll(bp | bl);
-                    const int waiting = __popcll(__builtin_amdgcn_ballot_w64(W.cur == kWalkDone));
-                    if (walking <= P.walk_tail && waiting >= P.walk_tail_ready) break;
-                }
                 if (bp != 0ull && budget > 0 && (round > 0 || bl == 0ull)) {
                     budget = __builtin_amdgcn_readfirstlane(budget - 1);
                     round = __builtin_amdgcn_readfirstlane(round - 1);
@@ -301,7 +391,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     if (at_leaf) {
                         RT_W2_COUNT(2, bl);
                         RT_W2_HIST(0, bl);
-                        leaf_step2(s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, shadow, W);
+                    }
+                    bool by_lane = at_leaf;
+                    if (__popcll(bl) <= P.walk_tail)
+                        by_lane = leaf_step_coop(s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, shadow, at_leaf, bl, s_mail[wave], s_res[wave], W);
+                    if (__builtin_amdgcn_ballot_w64(by_lane) != 0ull) {
+                        if (by_lane) leaf_step2(s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, shadow, W);
                     }
                     RT_W2_CLOCK(hist, 9, t_l);
                 } else {
@@ -315,9 +410,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         const unsigned long long t_s = __builtin_amdgcn_s_memtime();
 #endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
-        const bool ready = W.cur == kWalkDone;
+        const bool ready = (W.cur == kWalkDone) & !finished;
         const unsigned long long br = __builtin_amdgcn_ballot_w64(ready);
-        const unsigned long long bw = __builtin_amdgcn_ballot_w64(!ready);
+        const unsigned long long bw = __builtin_amdgcn_ballot_w64(W.cur != kWalkDone);
         const bool go = (__popcll(br) >= P.regen_gate) || (bw == 0ull);
         if (ready && go) {
             RT_W2_COUNT(4, __builtin_amdgcn_ballot_w64(true));
