@@ -588,7 +588,7 @@ def main():
                 for _ in range(8):
                     m1.reset_async(); m1.render_pass(SPP, copy=False)
                 dt = time.perf_counter() - t0
-                in_library = {"path": "rt_create_multi(ngpus=1): RCCL communicator of one, de-interleave kernel, blocking rt_render_pass",
+                in_library = {"path": "rt_create_multi(ngpus=1): one shard rendering straight into the frame (no communicator, no gather, no de-interleave), blocking rt_render_pass",
                               "ms_per_frame": round(dt / 8 * 1e3, 4), "frame_equals_headline": bool(np.array_equal(m1.read_pixels(), last_pixels))}
         except api.RtError as e:
             in_library = {"error": str(e)}

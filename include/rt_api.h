@@ -112,14 +112,15 @@ RT_API int rt_create(rt_ctx **out, int w, int h);
  * `tile_rows` rows (tile t -> device t % ngpus; 0 = the default of 8), every device renders its rows
  * on its own stream, and each frame ends with ONE gather to the first device over RCCL
  * (ncclGroupStart; root: ncclRecv x (n-1); others: ncclSend; ncclGroupEnd; ncclUint32), a
- * de-interleave kernel there and one copy to the host.  Every other call of this header works on
+ * de-interleave kernel there and one copy to the host.  The receives and the de-interleave run on a SECOND stream of
+ * the first device, into one of two receive slots, so that device's render of frame k + 1 overlaps the gather of frame k
+ * (asynchronous frames: rt_render_async; rt_throttle(ctx, 0) and the blocking calls wait for the assembled frame).  Every other call of this header works on
  * such a context as on a plain one and means the whole image: rt_render_pass returns all h rows,
  * rt_get_stats sums the devices, rt_read_colors / rt_read_seeds merge them.  Results are bit-identical
- * to a one-device context by construction (pixels are independent); ngpus = 1 runs the same code (a
- * communicator of one).  One kernel instance renders the whole frame: the first shard measures hierarchy
+ * to a one-device context by construction (pixels are independent); with ngpus = 1 there is nothing to move: no
+ * communicator (RCCL is not loaded), no gather, no de-interleave -- the one shard renders straight into the frame.  One kernel instance renders the whole frame: the first shard measures hierarchy
  * against sweep (rt_scene_choice) and the others follow it.
- * STATUS of the n > 1 RCCL branch: exercised so far only as far as one GPU allows -- the communicator of one, and
- * the rehearsal below, in which device-to-device copies stand in for ncclSend / ncclRecv.  The grouped send / receive
+ * STATUS of the n > 1 RCCL branch: exercised so far only as far as one GPU allows -- the rehearsal below, in which device-to-device copies stand in for ncclSend / ncclRecv.  The grouped send / receive
  * across distinct devices has not run on hardware yet (tests/test_gpu_features.py holds the test, skipped below two
  * devices); treat it as unverified until that test has passed on a multi-GPU node.
  * rt_create_multi_on with ONE device listed ngpus times is that one-GPU rehearsal of the path: RCCL refuses two

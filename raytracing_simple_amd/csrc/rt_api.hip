@@ -1182,7 +1182,7 @@ RT_API int rt_throttle(rt_ctx *c, int max_in_flight, double *ms_per_pass) {
             HIP_TRY(hipSetDevice(s->device));
             HIP_TRY(hipStreamSynchronize(s->last_stream));
         }
-        return RT_OK;
+        return rt::multi_wait_frame(c);
     }
     int rc = select_device(c);
     if (rc != RT_OK) return rc;

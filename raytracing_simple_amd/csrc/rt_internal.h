@@ -165,6 +165,7 @@ int multi_device_pixels(rt_ctx *front, void **dptr, size_t *count);
 int multi_pin_output(rt_ctx *front, uint32_t *out_host, size_t count);
 void *multi_stream(rt_ctx *front);
 int multi_shards(const rt_ctx *front);
+int multi_wait_frame(rt_ctx *front);
 const char *multi_last_kernel(const rt_ctx *front);
 rt_ctx *multi_first_shard(rt_ctx *front);
 rt_ctx *multi_shard(rt_ctx *front, int r);

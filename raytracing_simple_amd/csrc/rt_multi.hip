@@ -90,8 +90,15 @@ struct rt_multi {
     std::vector<int> devices;
     std::vector<rt_ctx *> shard;        // shard[r] = rt_create_sharded(w, h, devices[r], r, n, tile_rows)
     std::vector<rcclComm> comm;         // one per device (ncclCommInitAll), empty when emulated
-    uint32_t *d_gathered = nullptr;     // root: [n][pad_rows][w], rank r's block at r * pad_rows * w
-    uint32_t *d_full = nullptr;         // root: [h][w], the assembled frame
+    // The gather of frame k runs on the root device's SECOND stream into receive slot k % 2, so that the root's render of
+    // frame k + 1 (into the other slot) is not queued behind n - 1 receives and the de-interleave of frame k.
+    uint32_t *d_gathered[2] = { nullptr, nullptr };   // root: [n][pad_rows][w] each, rank r's block at r * pad_rows * w
+    uint32_t *d_full = nullptr;         // root: [h][w], the assembled frame (n = 1: the one shard renders straight into it)
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_rendered = nullptr;   // root's rows of the frame are in its slot (root's render stream)
+    hipEvent_t ev_gathered[2] = { nullptr, nullptr };   // the slot's frame is assembled in d_full: the slot may be rendered into again
+    bool slot_used[2] = { false, false };
+    uint64_t frames = 0;                // frames gathered so far (the next one uses slot frames % 2)
     hipEvent_t ev_ready = nullptr;      // emulation: a shard's render done, on its device
     hipEvent_t ev_copied = nullptr;     // emulation: the root has copied the shards' rows out of their pixel buffers
     bool broken = false;                // a gather failed half-way: the communicators may hold an open or failed group
@@ -132,11 +139,27 @@ int mark_broken(rt_multi *m, int code, const char *what, const char *detail) {
     return fail(code, "%s failed: %s -- the multi-device context is now unusable", what, detail ? detail : "?");
 }
 
-// the frame-end gather + assembly, queued behind the renders; root stream ends up holding everything
+// Before the shards render a frame that will be gathered: the root renders its own rows straight into the receive slot of
+// that frame, which it may do once the slot's previous frame (two frames ago) has been assembled out of it.
+int begin_frame(rt_multi *m) {
+    if (m->n == 1) return RT_OK;
+    const int slot = (int)(m->frames & 1u);
+    rt_ctx *root = m->shard[0];
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    if (m->slot_used[slot]) HIP_TRY(hipStreamWaitEvent(root->stream, m->ev_gathered[slot], 0));
+    return rt_set_pixel_buffer(root, m->d_gathered[slot], (size_t)m->pad_rows * m->w);
+}
+
+// The frame-end gather + assembly, on the root device's gather stream: behind the root's own render (an event) and, through the
+// pairing of ncclRecv with ncclSend, behind every other shard's.  The root's render stream is NOT touched: its next frame starts
+// while this one is received and de-interleaved.
 int gather_and_assemble(rt_multi *m) {
     int rc = refuse_if_broken(m);
     if (rc != RT_OK) return rc;
+    if (m->n == 1) return RT_OK;                        // one device: its rows ARE the frame, rendered straight into d_full
     rt_ctx *root = m->shard[0];
+    const int slot = (int)(m->frames & 1u);
+    uint32_t *gathered = m->d_gathered[slot];
     const size_t block = (size_t)m->pad_rows * (size_t)m->w;
     // every transfer must fit the receive slot it lands in (slot r = pad_rows * w words at r * block)
     for (int r = 1; r < m->n; ++r) {
@@ -144,10 +167,13 @@ int gather_and_assemble(rt_multi *m) {
         if (count > block || m->shard[r]->w != m->w)
             return fail(RT_ERR_STATE, "shard %d would send %zu words into a slot of %zu", r, count, block);
     }
-    if (m->n > 1 && !m->emulated) {
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipEventRecord(m->ev_rendered, root->last_stream));
+    HIP_TRY(hipStreamWaitEvent(m->gather_stream, m->ev_rendered, 0));
+    if (!m->emulated) {
         // One group: root posts n-1 receives, every other device one send.  A call that fails inside the group must
         // not leave it open: the group is always ended, and any failure (there or in ncclGroupEnd) marks the context
-        // unusable -- later calls are refused instead of queueing behind a communicator in an unknown state.
+        // unusable -- the communicators are aborted and later calls refused instead of queueing behind them.
         int r0 = g_rccl.GroupStart();
         if (r0 != 0) return mark_broken(m, RT_ERR_HIP, "ncclGroupStart", g_rccl.GetErrorString(r0));
         int bad = 0;
@@ -157,7 +183,7 @@ int gather_and_assemble(rt_multi *m) {
             const size_t count = (size_t)m->shard[r]->local_rows * (size_t)m->w;
             if (!count) continue;
             if ((bad_hip = hipSetDevice(m->devices[0])) != hipSuccess) break;
-            if ((bad = g_rccl.Recv(m->d_gathered + (size_t)r * block, count, kRcclUint32, r, m->comm[0], root->stream)) != 0) { bad_what = "ncclRecv"; break; }
+            if ((bad = g_rccl.Recv(gathered + (size_t)r * block, count, kRcclUint32, r, m->comm[0], m->gather_stream)) != 0) { bad_what = "ncclRecv"; break; }
             if ((bad_hip = hipSetDevice(m->devices[r])) != hipSuccess) break;
             if ((bad = g_rccl.Send(m->shard[r]->d_pixels, count, kRcclUint32, 0, m->comm[r], m->shard[r]->stream)) != 0) { bad_what = "ncclSend"; break; }
         }
@@ -165,28 +191,36 @@ int gather_and_assemble(rt_multi *m) {
         if (bad) return mark_broken(m, RT_ERR_HIP, bad_what, g_rccl.GetErrorString(bad));
         if (bad_hip != hipSuccess) return mark_broken(m, RT_ERR_HIP, "hipSetDevice inside the gather", hipGetErrorString(bad_hip));
         if (r1 != 0) return mark_broken(m, RT_ERR_HIP, "ncclGroupEnd", g_rccl.GetErrorString(r1));
-    } else if (m->n > 1) {
-        // one-GPU rehearsal: the receive slot is filled by a device-to-device copy on the ROOT's stream, which
-        // first waits for the sending shard's render (what ncclRecv's pairing with ncclSend does on real links)
+    } else {
+        // one-GPU rehearsal: the receive slot is filled by a device-to-device copy on the gather stream, which first waits for
+        // the sending shard's render (what ncclRecv's pairing with ncclSend does on real links)
         for (int r = 1; r < m->n; ++r) {
             const size_t count = (size_t)m->shard[r]->local_rows * (size_t)m->w;
             if (!count) continue;
             HIP_TRY(hipSetDevice(m->devices[r]));
             HIP_TRY(hipEventRecord(m->ev_ready, m->shard[r]->last_stream));
             HIP_TRY(hipSetDevice(m->devices[0]));
-            HIP_TRY(hipStreamWaitEvent(root->stream, m->ev_ready, 0));
-            HIP_TRY(hipMemcpyAsync(m->d_gathered + (size_t)r * block, m->shard[r]->d_pixels, count * sizeof(uint32_t),
-                                   hipMemcpyDeviceToDevice, root->stream));
+            HIP_TRY(hipStreamWaitEvent(m->gather_stream, m->ev_ready, 0));
+            HIP_TRY(hipMemcpyAsync(gathered + (size_t)r * block, m->shard[r]->d_pixels, count * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, m->gather_stream));
         }
-        // ... and a shard's NEXT render must not overwrite its pixel buffer before the root has copied it out (ncclSend
-        // sits on the shard's own stream and orders that by itself; the copy above sits on the root's)
-        HIP_TRY(hipEventRecord(m->ev_copied, root->stream));
+        // ... and a shard's NEXT render must not overwrite its pixel buffer before it has been copied out (ncclSend sits on
+        // the shard's own stream and orders that by itself; the copy above sits on the root's gather stream)
+        HIP_TRY(hipEventRecord(m->ev_copied, m->gather_stream));
         for (int r = 1; r < m->n; ++r)
             if (m->shard[r]->local_rows > 0) HIP_TRY(hipStreamWaitEvent(m->shard[r]->stream, m->ev_copied, 0));
     }
     HIP_TRY(hipSetDevice(m->devices[0]));
-    return rt_deinterleave_rows(m->d_full, m->d_gathered, m->w, m->h, m->n, m->tile_rows, m->pad_rows, m->devices[0], root->stream);
+    rc = rt_deinterleave_rows(m->d_full, gathered, m->w, m->h, m->n, m->tile_rows, m->pad_rows, m->devices[0], m->gather_stream);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(m->ev_gathered[slot], m->gather_stream));
+    m->slot_used[slot] = true;
+    m->frames += 1;
+    return RT_OK;
 }
+
+// the stream the assembled frame is complete on (readers copy from d_full behind it)
+hipStream_t frame_stream(rt_multi *m) { return m->n == 1 ? m->shard[0]->last_stream : m->gather_stream; }
 
 }  // namespace
 
@@ -243,11 +277,11 @@ RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, in
     for (int r = 0; r < ngpus; ++r) m->pad_rows = rows_of(h, r, ngpus, tile_rows) > m->pad_rows ? rows_of(h, r, ngpus, tile_rows) : m->pad_rows;
 
     auto build = [&]() -> int {
-        if (!m->emulated) {
+        if (!m->emulated && ngpus > 1) {               // (one device: nothing to move, no communicator, RCCL is not even loaded)
             int rc = load_rccl();
             if (rc != RT_OK) return rc;
             m->comm.assign(ngpus, nullptr);
-            RCCL_TRY(g_rccl.CommInitAll(m->comm.data(), ngpus, m->devices.data()));      // also for ngpus = 1: a communicator of one
+            RCCL_TRY(g_rccl.CommInitAll(m->comm.data(), ngpus, m->devices.data()));
         }
         for (int r = 0; r < ngpus; ++r) {
             rt_ctx *s = nullptr;
@@ -258,14 +292,21 @@ RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, in
             m->shard.push_back(s);
         }
         HIP_TRY(hipSetDevice(devices[0]));
-        HIP_TRY(hipMalloc(&m->d_gathered, ((size_t)ngpus * m->pad_rows * w + 4) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&m->d_full, ((size_t)w * h + 4) * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(m->d_gathered, 0, (size_t)ngpus * m->pad_rows * w * sizeof(uint32_t)));
         HIP_TRY(hipMemset(m->d_full, 0, (size_t)w * h * sizeof(uint32_t)));
+        if (ngpus == 1)                                 // the one shard's rows are the frame: no slots, no gather, no de-interleave
+            return rt_set_pixel_buffer(m->shard[0], m->d_full, (size_t)w * h);
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipMalloc(&m->d_gathered[k], ((size_t)ngpus * m->pad_rows * w + 4) * sizeof(uint32_t)));
+            HIP_TRY(hipMemset(m->d_gathered[k], 0, (size_t)ngpus * m->pad_rows * w * sizeof(uint32_t)));
+            HIP_TRY(hipEventCreateWithFlags(&m->ev_gathered[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&m->gather_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_rendered, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_copied, hipEventDisableTiming));
-        // the root renders its own rows straight into its receive slot
-        return rt_set_pixel_buffer(m->shard[0], m->d_gathered, (size_t)m->pad_rows * w);
+        // the root renders its own rows straight into the receive slot of the frame (begin_frame sets it per frame)
+        return rt_set_pixel_buffer(m->shard[0], m->d_gathered[0], (size_t)m->pad_rows * w);
     };
     int rc = build();
     if (rc != RT_OK) {
@@ -293,13 +334,20 @@ namespace rt {
 void multi_destroy(rt_ctx *front) {
     rt_multi *m = front->multi;
     if (!m) return;
+    if (m->gather_stream && !m->broken && !m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess)
+        (void)hipStreamSynchronize(m->gather_stream);   // (it reads the shards' buffers: before they go)
     for (rt_ctx *s : m->shard) rt_destroy(s);           // waits for each shard's stream
     if (!m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess) {
         if (m->pinned_out) (void)hipHostUnregister(m->pinned_out);
-        (void)hipFree(m->d_gathered);
+        (void)hipFree(m->d_gathered[0]);
+        (void)hipFree(m->d_gathered[1]);
         (void)hipFree(m->d_full);
         if (m->ev_ready) (void)hipEventDestroy(m->ev_ready);
         if (m->ev_copied) (void)hipEventDestroy(m->ev_copied);
+        if (m->ev_rendered) (void)hipEventDestroy(m->ev_rendered);
+        for (hipEvent_t e : m->ev_gathered)
+            if (e) (void)hipEventDestroy(e);
+        if (m->gather_stream) (void)hipStreamDestroy(m->gather_stream);
     }
     for (rcclComm c : m->comm)
         if (c) (void)g_rccl.CommDestroy(c);
@@ -308,6 +356,14 @@ void multi_destroy(rt_ctx *front) {
 }
 
 int multi_shards(const rt_ctx *front) { return front->multi->n; }
+// host waits for the last gathered frame to be assembled (rt_throttle(ctx, 0) on a multi-device context)
+int multi_wait_frame(rt_ctx *front) {
+    rt_multi *m = front->multi;
+    if (m->n == 1 || !m->gather_stream || m->broken) return RT_OK;
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipStreamSynchronize(m->gather_stream));
+    return RT_OK;
+}
 rt_ctx *multi_first_shard(rt_ctx *front) { return front->multi->shard.empty() ? front : front->multi->shard[0]; }
 rt_ctx *multi_shard(rt_ctx *front, int r) { return front->multi->shard[(size_t)r]; }
 const char *multi_last_kernel(const rt_ctx *front) { return front->multi->shard.empty() ? "" : front->multi->shard[0]->last_kernel; }
@@ -353,6 +409,11 @@ int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking
         int rb = refuse_if_broken(m);
         if (rb != RT_OK) return rb;
     }
+    const bool frame_wanted = m->shard[0]->pixel_write != 0 && n_samples > 0;
+    if (frame_wanted) {
+        int rc = begin_frame(m);
+        if (rc != RT_OK) return rc;
+    }
     // every device starts its rows before any is waited for
     for (int r = 0; r < m->n; ++r) {
         rt_ctx *s = m->shard[r];
@@ -364,16 +425,15 @@ int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking
     }
     front->current_sample = m->shard[0]->current_sample;
     if (n_samples > 0) m->launches += 1;
-    const bool frame_wanted = m->shard[0]->pixel_write != 0 && n_samples > 0;
     if (frame_wanted) {
         int rc = gather_and_assemble(m);
         if (rc != RT_OK) return rc;
     }
     if (!blocking) return RT_OK;
-    rt_ctx *root = m->shard[0];
     HIP_TRY(hipSetDevice(m->devices[0]));
     if (out_host)
-        HIP_TRY(hipMemcpyAsync(out_host, m->d_full, (size_t)m->w * m->h * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
+        HIP_TRY(hipMemcpyAsync(out_host, m->d_full, (size_t)m->w * m->h * sizeof(uint32_t), hipMemcpyDeviceToHost, frame_stream(m)));
+    HIP_TRY(hipStreamSynchronize(frame_stream(m)));
     double worst = 0.0;
     for (int r = 0; r < m->n; ++r) {
         rt_ctx *s = m->shard[r];
@@ -394,12 +454,12 @@ int multi_read_pixels(rt_ctx *front, uint32_t *out_host) {
         int rb = refuse_if_broken(m);
         if (rb != RT_OK) return rb;
     }
-    rt_ctx *root = m->shard[0];
-    const size_t block = (size_t)m->pad_rows * (size_t)m->w;
     // shards whose last launches skipped the pixel store pack their rows now; then the usual gather
     bool stale = false;
     for (rt_ctx *s : m->shard) stale = stale || (!s->pixels_current && s->current_sample > 0);
     if (stale) {
+        int rb = begin_frame(m);                        // (the root packs into the receive slot of the frame about to be gathered)
+        if (rb != RT_OK) return rb;
         std::vector<uint32_t> tmp;
         for (int r = 0; r < m->n; ++r) {
             rt_ctx *s = m->shard[r];
@@ -412,15 +472,13 @@ int multi_read_pixels(rt_ctx *front, uint32_t *out_host) {
         int rc = gather_and_assemble(m);
         if (rc != RT_OK) return rc;
     }
-    (void)block;
-    HIP_TRY(hipSetDevice(m->devices[0]));
     for (int r = 1; r < m->n; ++r) {                    // async renders on the other devices
         HIP_TRY(hipSetDevice(m->devices[r]));
         HIP_TRY(hipStreamSynchronize(m->shard[r]->stream));
     }
     HIP_TRY(hipSetDevice(m->devices[0]));
-    HIP_TRY(hipMemcpyAsync(out_host, m->d_full, (size_t)m->w * m->h * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
-    HIP_TRY(hipStreamSynchronize(root->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, m->d_full, (size_t)m->w * m->h * sizeof(uint32_t), hipMemcpyDeviceToHost, frame_stream(m)));
+    HIP_TRY(hipStreamSynchronize(frame_stream(m)));
     return RT_OK;
 }
 
@@ -486,7 +544,7 @@ int multi_pin_output(rt_ctx *front, uint32_t *out_host, size_t count) {
     rt_multi *m = front->multi;
     HIP_TRY(hipSetDevice(m->devices[0]));
     if (m->pinned_out) {
-        HIP_TRY(hipStreamSynchronize(m->shard[0]->stream));
+        HIP_TRY(hipStreamSynchronize(frame_stream(m)));
         (void)hipHostUnregister(m->pinned_out);
         m->pinned_out = nullptr;
     }

@@ -28,7 +28,7 @@ def _assert_same(got, want):
 
 # ---- multi-device context ----------------------------------------------------------------------------
 @pytest.mark.parametrize("devices,tile_rows,w,h", [
-    ([0], 8, 160, 96),                  # ngpus = 1: the RCCL path itself, a communicator of one
+    ([0], 8, 160, 96),                  # ngpus = 1: nothing to move -- no communicator, no gather: the one shard renders into the frame
     ([0, 0], 8, 160, 96),               # one-GPU rehearsal: shards -> D2D stand-in for the recv -> de-interleave kernel
     ([0, 0, 0], 16, 97, 61),            # ragged: w % 4 != 0 (scalar de-interleave), short last tile, uneven tile counts
     ([0] * 8, 8, 256, 200),
@@ -451,15 +451,21 @@ def test_asynchronous_frames_through_the_rehearsal_gather_are_not_torn():
     sph, orig, target = scenes.demo_plus(16)
     w, h = 1024, 768
     cam = host.compute_camera(orig, target, w, h)
-    with api.RtContext(w, h, devices=[0, 0]) as ctx:
-        ctx.set_scene(sph)
-        ctx.set_camera(cam)
-        done = 0
-        for k in range(40):
-            ctx.render_async(1)
-            done += 1
-            if k in (0, 17, 39):
-                assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, done)["pixels"]), k
+    for devices in ([0, 0], [0, 0, 0]):
+        with api.RtContext(w, h, devices=devices) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            done = 0
+            # Round 4: frame k is gathered on the root's SECOND stream into receive slot k % 2 while the root's render of frame
+            # k + 1 goes into the other slot; a slot is rendered into again only once its previous frame has been assembled
+            # out of it.  The checkpoints fall on both slots, right after a slot's first use and after many reuses.
+            for k in range(40):
+                ctx.render_async(1)
+                done += 1
+                if k in (0, 1, 17, 18, 39):
+                    assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, done)["pixels"]), (devices, k)
+            px = ctx.render_pass(2)                                   # a blocking frame behind the asynchronous ones
+            assert np.array_equal(px, O.render(sph, cam, w, h, done + 2)["pixels"])
 
 
 def test_a_failed_gather_leaves_the_context_in_a_defined_error_state():
