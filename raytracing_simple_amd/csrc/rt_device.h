@@ -50,7 +50,10 @@ struct SceneTables {
 //            of leaves in front of leaf m, wherever that split lies: the device build halves every range (root = pair
 //            n_leaves / 2 - 1), the host build of a full scene upload cuts by surface area (rt_bvh.hip); BvhTables::root says
 //            which pair the walk starts at (a tree of one leaf has no pairs).
-constexpr int kBvhLeaf = 8;
+#ifndef RT_BVH_LEAF
+#define RT_BVH_LEAF 8                   /* spheres per leaf (4 measured in round 4: tools/leaf_size_ab.sh) */
+#endif
+constexpr int kBvhLeaf = RT_BVH_LEAF;
 constexpr uint32_t kBvhLeafRef = 0x8000u;
 struct BvhTables {
     const float4 *blob;     // hdr | slots | index | pairs

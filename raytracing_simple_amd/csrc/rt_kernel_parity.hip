@@ -80,6 +80,13 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs3          /* A/B: the second form's shade phase over the first form's walk loop */
+#define RT_KERNEL_NAME rt_trace_parity_pairs3
+#define RT_OPT_WALK 5
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_pairs2_census
 #define RT_KERNEL_NAME rt_trace_parity_pairs2_census
 #define RT_OPT_WALK 4
@@ -149,6 +156,7 @@ static const Instance kParityInstances[] = {
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { parity_pairs2::rt_trace_parity_pairs2, "rt_trace_parity_pairs2", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs3::rt_trace_parity_pairs3, "rt_trace_parity_pairs3", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs2_census::rt_trace_parity_pairs2_census, "rt_trace_parity_pairs2_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

@@ -146,13 +146,17 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                 cen[3] += 1ull;
             }
             const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-            HitPre p[kBvhLeaf];
+            // (two halves of four: the discriminants of all eight at once are registers the kernel then spills elsewhere)
 #pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) p[k] = hit_pre(s_slots[sl + k], o, d);
+            for (int half = 0; half < kBvhLeaf; half += 4) {
+            HitPre p[4];
 #pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) {
-                if (p[k].det >= 0.f) {
-                    const HitRoots hr = hit_roots(p[k]);
+            for (int k4 = 0; k4 < 4; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int k = half + k4;
+                if (p[k4].det >= 0.f) {
+                    const HitRoots hr = hit_roots(p[k4]);
                     // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
                     // shadow ray (.cl:234-247): the lowest scene index that blocks
                     // The scene index of a slot lies in HBM / L2.  A shadow ray needs it for every blocker (the lowest one
@@ -179,6 +183,7 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                         }
                     }
                 }
+            }
             }
             sp -= 1;
             cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
@@ -283,6 +288,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int rtile = lrow / P.tile_rows;
     const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
+    // through the loop the pixel's place is ONE register, x | y << 16 (the camera ray needs both per sample; images stop at 65535
+    // either way); the local row and the validity are formed again after the loop (as in rt_trace.inc.h)
+    const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
 
     uint32_t s0 = 0, s1 = 0;
     V3 acc = mk(0.f, 0.f, 0.f);
@@ -528,8 +536,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 float j1 = next_random_centred(s0, s1);
                 float j2 = next_random_centred(s0, s1);
                 c_draws += 2;
-                float kcx = ((float)x + j1) * inv_w - 0.5f;
-                float kcy = ((float)y + j2) * inv_h - 0.5f;
+                float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
+                float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
                 V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
                            cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
                 o = add(scale(rd, 0.1f), cam_o);
@@ -575,9 +583,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("; epilogue arguments re-read" : "+s"(qp));
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
-    if (valid && Q.n_samples > 0) {
-        int xe = x, ye = y, le = lrow;
-        asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
+    const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
+    if (valid_e && Q.n_samples > 0) {
+        const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16);
+        int le = tile_by * kTileH + ((int)(threadIdx.x & 63u) >> 3);
+        if (Q.deal) {                                                      // (the local row of a dealt pixel: read again, not kept)
+            const int rows_e = Q.deal_rows, bands = rows_e >> 3, ry_e = tile_by / bands, band = tile_by - ry_e * bands;
+            le = ry_e * rows_e + (int)(Q.deal[(size_t)(ry_e * (int)gridDim.x + tile_bx) * (size_t)(kRegionW * rows_e) + (unsigned)(band * 256 + (int)threadIdx.x)] >> 5);
+        }
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;
         float *colors = Q.colors;
@@ -594,7 +607,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             pc[(size_t)le * (size_t)Q.w + (size_t)xe] = (uint16_t)(rays < 65535u ? rays : 65535u);
         }
     }
-    uint32_t n_done = valid ? (uint32_t)Q.n_samples : 0u;
+    uint32_t n_done = valid_e ? (uint32_t)Q.n_samples : 0u;
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);
