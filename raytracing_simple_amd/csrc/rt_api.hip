@@ -414,6 +414,7 @@ rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
     p.inv_w = 1.f / (float)c->w;          // correctly rounded on the host as on the device (-ffp-contract=off, IEEE division)
     p.inv_h = 1.f / (float)c->h;
     p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
+    p.coop_kmax = c->coop_kmax;
     p.tiles_x = (c->w + 7) / 8;
     p.n_tiles = p.tiles_x * ((c->local_rows + 7) / 8);
     return p;
@@ -1584,7 +1585,7 @@ static int dbg_set_gate(rt_ctx *c, int v) { c->regen_gate = v; return RT_OK; }
 static int dbg_set_matlds(rt_ctx *c, int v) { c->mat_lds_limit = v; return RT_OK; }
 static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT_OK; }
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
-static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v; return RT_OK; }
+static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v & 0xffffff; c->coop_kmax = v >> 24; return RT_OK; }
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
 static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; if (v >> 8) c->order_homes = v >> 8; c->order_valid = false; return RT_OK; }
 static int dbg_set_deal(rt_ctx *c, int v) {       // 0 = off; rows of a region | pixels of a run << 8
@@ -1778,6 +1779,8 @@ RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, ui
     }
     return RT_OK;
 }
+// min_spheres | kmax << 24: scenes of at least min_spheres use the cooperative any-hit instance; kmax: it shares a sweep out only while
+// no more than kmax shadow rays are pending in the wavefront (0 = no limit)
 RT_API int rt_debug_set_coop_min(rt_ctx *c, int min_spheres) {
     if (!c || min_spheres < 0) return fail(RT_ERR_ARG, "min_spheres %d", min_spheres);
     return dbg_apply(c, dbg_set_coop, min_spheres);

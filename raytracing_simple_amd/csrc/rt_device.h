@@ -92,6 +92,7 @@ struct LaunchParams {
     int mat_in_lds;         // material tables staged into LDS as well (fits 64 KiB)
     int n_tiles, tiles_x;   // persistent instances: 8x8 pixel tiles of this rank's rows, and tiles per row
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
+    int coop_kmax;          // cooperative any-hit: with more pending shadow rays than this in the wavefront the lanes sweep for themselves (0 = no limit)
     float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
     const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order

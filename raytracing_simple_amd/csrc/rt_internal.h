@@ -97,6 +97,7 @@ struct rt_ctx {
     int mode = RT_MODE_PARITY;
     int regen_gate = 0;                 // 0 = choose from the scene size
     int mat_lds_limit = 24 * 1024;
+    int coop_kmax = 0;                  // cooperative any-hit only while no more than this many shadow rays are pending in the wavefront (0 = no limit)
     int coop_min = 12;                  // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
     int persist = 0;                    // diagnostics: persistent-wavefront instances
     int n_cus = 256;

@@ -87,6 +87,13 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs4          /* A/B: pairs3 with the walk loop's inner branches taken out (walk_pairs_b) */
+#define RT_KERNEL_NAME rt_trace_parity_pairs4
+#define RT_OPT_WALK 6
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_pairs2_census
 #define RT_KERNEL_NAME rt_trace_parity_pairs2_census
 #define RT_OPT_WALK 4
@@ -157,6 +164,7 @@ static const Instance kParityInstances[] = {
 #if RT_DIAGNOSTICS
     { parity_pairs2::rt_trace_parity_pairs2, "rt_trace_parity_pairs2", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs3::rt_trace_parity_pairs3, "rt_trace_parity_pairs3", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs4::rt_trace_parity_pairs4, "rt_trace_parity_pairs4", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs2_census::rt_trace_parity_pairs2_census, "rt_trace_parity_pairs2_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

@@ -391,7 +391,7 @@ constexpr int kCoopWaveFloats = kCoopSlots * 9;         // per wavefront: 2 floa
 // ray is combined with an LDS atomic min, so the result (and the test count derived from it)
 // equals the sequential sweep.  G counts only the lanes that are present in this call (a wave
 // ballot of the callers).  With G < 2 the lanes sweep for themselves.
-RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d, float max_t, float *scratch) {
+RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d, float max_t, float *scratch, int kmax) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
     const int K = __popcll(m);
     if (K == 0) return n;
@@ -399,7 +399,7 @@ RT_DEV uint32_t coop_any(const float4 *s_geom, uint32_t n, bool want, V3 o, V3 d
     const unsigned long long present = __builtin_amdgcn_ballot_w64(true);
     const int G = __popcll(present) / K;
     unsigned long long unused_roots = 0;
-    if (G < 2) {
+    if (G < 2 || (kmax > 0 && K > kmax)) {
         uint32_t first = n;
         if (want) first = sweep_any(s_geom, n, o, d, max_t, unused_roots);
         return first;
@@ -797,7 +797,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     want = sample_light(s_lightA[j], lb, s0, s1, c_draws, hp, nl, sd, len, numer);
                 }
                 RT_STAMP(4);
-                const uint32_t first = coop_any(s_geom, n, want, hp, sd, len - RT_EPS, s_coop + wave * kCoopWaveFloats);
+                const uint32_t first = coop_any(s_geom, n, want, hp, sd, len - RT_EPS, s_coop + wave * kCoopWaveFloats, P.coop_kmax);
 #if RT_OPT_COOP == 2
                 {   // verification instance: the sequential sweep beside the cooperative one
                     unsigned long long dummy = 0;
