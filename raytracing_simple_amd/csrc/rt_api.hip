@@ -799,8 +799,9 @@ int ensure_scene_capacity(rt_ctx *c, uint32_t count) {
     HIP_TRY(hipMalloc(&ns, (size_t)cap * sizeof(rt_sphere)));
     float4 *nb = nullptr;
     hipError_t e = hipMalloc(&nt, ((size_t)cap * 5 + 1) * sizeof(float4));
-    // blob: hdr 2 + nodes (< cap / 2 + 4) + slots (< cap + 8) + index (< cap / 4 + 3) + pairs (< cap / 2 + 4) float4
-    if (e == hipSuccess) e = hipMalloc(&nb, ((size_t)cap * 3 + 64) * sizeof(float4));
+    // blob: hdr 2 + slots (< cap + 8; up to twice that with the partial leaves of the shaped tree) + index (a quarter of the
+    // slots) + pairs (< cap / 2 + 4) + two material records per slot, in float4
+    if (e == hipSuccess) e = hipMalloc(&nb, ((size_t)cap * 6 + 64) * sizeof(float4));
     if (e != hipSuccess) {
         (void)hipFree(ns);
         (void)hipFree(nt);

@@ -89,7 +89,13 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
         for (unsigned k = 0; k < wave; ++k) { off_a += s_wave_a[k]; off_t += s_wave_t[k]; }
         if (out) {
             const uint32_t j = off_a + before_a;
-            if (j < n_always) { slots[j] = make_float4(px, py, pz, rad * rad); index[j] = i; }
+            if (j < n_always) {
+                slots[j] = make_float4(px, py, pz, rad * rad);
+                index[j] = i;
+                const float *r = reinterpret_cast<const float *>(sph + i);
+                blob[rt::bvh_emis_at(n_leaves, n_slots) + j] = make_float4(r[4], r[5], r[6], r[10]);
+                blob[rt::bvh_colr_at(n_leaves, n_slots) + j] = make_float4(r[7], r[8], r[9], rad);
+            }
             else atomicAdd(&s_bad, 1u);
         }
         if (in) {
@@ -170,8 +176,12 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
         if (ix != 0xffffffffu) {
             const float *r = reinterpret_cast<const float *>(sph + ix);
             slots[n_always + j] = make_float4(r[1], r[2], r[3], r[0] * r[0]);
+            blob[rt::bvh_emis_at(n_leaves, n_slots) + n_always + j] = make_float4(r[4], r[5], r[6], r[10]);
+            blob[rt::bvh_colr_at(n_leaves, n_slots) + n_always + j] = make_float4(r[7], r[8], r[9], r[0]);
         } else {
             slots[n_always + j] = make_float4(qnan, qnan, qnan, qnan);
+            blob[rt::bvh_emis_at(n_leaves, n_slots) + n_always + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            blob[rt::bvh_colr_at(n_leaves, n_slots) + n_always + j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         index[n_always + j] = ix;
     }
@@ -261,6 +271,24 @@ struct HostBox {
     float lo[3], hi[3];
     uint32_t low;
 };
+
+// the material records of every slot, in slot order, behind the pairs (rt_device.h BvhTables): from the finished index section
+void host_fill_materials(float4 *blob, const std::vector<rt_sphere> &sph, uint32_t n_leaves, uint32_t n_slots) {
+    const uint32_t *index = reinterpret_cast<const uint32_t *>(blob + rt::bvh_index_at(n_slots));
+    float4 *emis = blob + rt::bvh_emis_at(n_leaves, n_slots), *colr = blob + rt::bvh_colr_at(n_leaves, n_slots);
+    for (uint32_t j = 0; j < n_slots; ++j) {
+        const uint32_t ix = index[j];
+        if (ix == 0xffffffffu) {
+            emis[j] = colr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const rt_sphere &q = sph[ix];
+        float refl_bits;
+        memcpy(&refl_bits, &q.refl, 4);
+        emis[j] = make_float4(q.e.x, q.e.y, q.e.z, refl_bits);
+        colr[j] = make_float4(q.c.x, q.c.y, q.c.z, q.rad);
+    }
+}
 
 inline double host_box_area(const HostBox &b) {
     const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
@@ -387,6 +415,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     const float ex = root.hi[0] - cx, ey = root.hi[1] - cy, ez = root.hi[2] - cz;
     hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
     hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
+    host_fill_materials(blob, sph, n_leaves, n_slots);
     HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, total4 * sizeof(float4), hipMemcpyHostToDevice, stream));
     if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
     HIP_TRY(hipEventRecord(c->bvh_stage_ev, stream));
@@ -535,7 +564,7 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
     const uint32_t n_leaves = (uint32_t)leaf_first.size();
     const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
     const size_t total4 = rt::bvh_blob_float4s(n_leaves, n_slots);
-    if (too_deep || n_leaves >= rt::kBvhLeafRef || total4 > (size_t)c->scene_cap * 3 + 64) return RT_OK;      // (the allocation of ensure_scene_capacity)
+    if (too_deep || n_leaves >= rt::kBvhLeafRef || total4 > (size_t)c->scene_cap * 6 + 64) return RT_OK;      // (the allocation of ensure_scene_capacity)
     if (c->bvh_stage_cap < total4) {
         if (c->bvh_stage_used) HIP_TRY(hipEventSynchronize(c->bvh_stage_ev));
         if (c->h_bvh_stage) (void)hipHostFree(c->h_bvh_stage);
@@ -576,6 +605,7 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
     const float ex = rb.hi[0] - cx, ey = rb.hi[1] - cy, ez = rb.hi[2] - cz;
     hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
     hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
+    host_fill_materials(blob, sph, n_leaves, n_slots);
     HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, total4 * sizeof(float4), hipMemcpyHostToDevice, stream));
     if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
     HIP_TRY(hipEventRecord(c->bvh_stage_ev, stream));

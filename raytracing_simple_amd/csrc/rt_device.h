@@ -50,13 +50,16 @@ struct SceneTables {
 //            of leaves in front of leaf m, wherever that split lies: the device build halves every range (root = pair
 //            n_leaves / 2 - 1), the host build of a full scene upload cuts by surface area (rt_bvh.hip); BvhTables::root says
 //            which pair the walk starts at (a tree of one leaf has no pairs).
+//   emis[j], colr[j] = the material records of slot j ({ emission, bits(refl) }, { colour, radius }: SceneTables' records in SLOT
+//            order): a closest hit reads its material by the slot the walk ended on -- one round trip to L2 instead of two
+//            (scene index first, then the record by index)
 #ifndef RT_BVH_LEAF
 #define RT_BVH_LEAF 8                   /* spheres per leaf (4 measured in round 4: tools/leaf_size_ab.sh) */
 #endif
 constexpr int kBvhLeaf = RT_BVH_LEAF;
 constexpr uint32_t kBvhLeafRef = 0x8000u;
 struct BvhTables {
-    const float4 *blob;     // hdr | slots | index | pairs
+    const float4 *blob;     // hdr | slots | index | pairs | emis by slot | colr by slot
     uint32_t n_always, n_leaves, n_slots;
     uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1)
     uint32_t root;          // the root's pair (kBvhLeafRef: the tree is one leaf)
@@ -65,7 +68,9 @@ struct BvhTables {
 __host__ __device__ inline uint32_t bvh_slots_at() { return 2u; }
 __host__ __device__ inline uint32_t bvh_index_at(uint32_t n_slots) { return 2u + n_slots; }
 __host__ __device__ inline uint32_t bvh_pairs_at(uint32_t n_slots) { return 2u + n_slots + (n_slots + 3u) / 4u; }
-inline size_t bvh_blob_float4s(uint32_t n_leaves, uint32_t n_slots) { return (size_t)bvh_pairs_at(n_slots) + 4 * (size_t)(n_leaves ? n_leaves - 1 : 0); }
+__host__ __device__ inline uint32_t bvh_emis_at(uint32_t n_leaves, uint32_t n_slots) { return bvh_pairs_at(n_slots) + 4u * (n_leaves ? n_leaves - 1u : 0u); }
+__host__ __device__ inline uint32_t bvh_colr_at(uint32_t n_leaves, uint32_t n_slots) { return bvh_emis_at(n_leaves, n_slots) + n_slots; }
+inline size_t bvh_blob_float4s(uint32_t n_leaves, uint32_t n_slots) { return (size_t)bvh_colr_at(n_leaves, n_slots) + (size_t)n_slots; }
 // LDS of the instance that walks the pairs: hdr | pairs | slots | per-lane stacks (u16) for `threads` lanes
 inline size_t lds_bytes_pairs(uint32_t n_spheres, uint32_t n_lights, bool mat_in_lds, int n_samples, uint32_t n_leaves,
                               uint32_t n_slots, uint32_t stack_depth, int threads) {

@@ -94,6 +94,13 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs5          /* A/B: pairs4 without the step budget, with a branch-free push and ballot-gated roots in the leaf */
+#define RT_KERNEL_NAME rt_trace_parity_pairs5
+#define RT_OPT_WALK 7
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_pairs2_census
 #define RT_KERNEL_NAME rt_trace_parity_pairs2_census
 #define RT_OPT_WALK 4
@@ -165,6 +172,7 @@ static const Instance kParityInstances[] = {
     { parity_pairs2::rt_trace_parity_pairs2, "rt_trace_parity_pairs2", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs3::rt_trace_parity_pairs3, "rt_trace_parity_pairs3", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs4::rt_trace_parity_pairs4, "rt_trace_parity_pairs4", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs5::rt_trace_parity_pairs5, "rt_trace_parity_pairs5", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs2_census::rt_trace_parity_pairs2_census, "rt_trace_parity_pairs2_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

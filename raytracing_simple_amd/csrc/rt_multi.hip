@@ -419,7 +419,10 @@ int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking
         rt_ctx *s = m->shard[r];
         HIP_TRY(hipSetDevice(s->device));
         if (blocking) HIP_TRY(hipEventRecord(s->ev0, s->stream));
-        int rc = rt::render_shard(s, n_samples, blocking);
+        // (never the blocking probe sequence: the shard that measures hierarchy against sweep would wait for its verdict inside
+        // this loop, before the other devices have been given their rows; a measured scene's probes are then whole launches --
+        // this frame and the next three -- as on the asynchronous path)
+        int rc = rt::render_shard(s, n_samples, false);
         if (rc != RT_OK) return rc;
         if (blocking) HIP_TRY(hipEventRecord(s->ev1, s->stream));
     }

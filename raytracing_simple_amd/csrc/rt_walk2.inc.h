@@ -362,7 +362,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
         // ---- T: every walk in flight advances, up to P.walk_steps pair steps; at most P.walk_round of them in a row while
         //      some lane holds a leaf.  Control is the wavefront's: two ballots per step, scalar branches ----
-#if RT_OPT_WALK == 6
+#if RT_OPT_WALK == 7
+        if (W.cur != kWalkDone)
+            walk_pairs_c(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_steps, P.walk_round, W.cur, W.sp,
+                         W.far, W.idx, W.slot);
+#elif RT_OPT_WALK == 6
         if (W.cur != kWalkDone)
             walk_pairs_b(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_steps, P.walk_round, W.cur, W.sp,
                          W.far, W.idx, W.slot);
