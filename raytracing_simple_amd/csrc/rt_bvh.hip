@@ -666,7 +666,8 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
         if (built) {
             uint32_t root = rt::kBvhLeafRef;
             if (sah_leaves > 1) root = c->bvh_sah_root;
-            c->bvh = rt::BvhTables{ c->d_bvh, n_always, sah_leaves, n_always + rt::kBvhLeaf * sah_leaves, sah_depth, root };
+            c->bvh = rt::BvhTables{ c->d_bvh, n_always, sah_leaves, n_always + rt::kBvhLeaf * sah_leaves, sah_depth, root,
+                                    rt::bvh_emis_at(sah_leaves, n_always + rt::kBvhLeaf * sah_leaves) };
             c->bvh_ok = true;
             return RT_OK;
         }
@@ -688,7 +689,8 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     }
     uint32_t depth = 1;
     while ((1u << depth) < n_leaves) depth += 1;
-    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1, n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef };
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1, n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef,
+                            rt::bvh_emis_at(n_leaves, n_always + rt::kBvhLeaf * n_leaves) };
     c->bvh_ok = true;
     return RT_OK;
 }

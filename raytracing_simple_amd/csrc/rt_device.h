@@ -63,6 +63,7 @@ struct BvhTables {
     uint32_t n_always, n_leaves, n_slots;
     uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1)
     uint32_t root;          // the root's pair (kBvhLeafRef: the tree is one leaf)
+    uint32_t emis_at;       // bvh_emis_at(n_leaves, n_slots), formed on the host: the kernel has no scalar registers to spare for it
 };
 // offsets into the blob, in float4 units
 __host__ __device__ inline uint32_t bvh_slots_at() { return 2u; }

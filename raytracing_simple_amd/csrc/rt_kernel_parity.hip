@@ -101,6 +101,20 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs6          /* A/B: pairs5 with the hit's material read by slot */
+#define RT_KERNEL_NAME rt_trace_parity_pairs6
+#define RT_OPT_WALK 8
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs7          /* A/B: pairs6 with the pair step's choice as mask logic and the leaf's tie handling out of line */
+#define RT_KERNEL_NAME rt_trace_parity_pairs7
+#define RT_OPT_WALK 9
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_pairs2_census
 #define RT_KERNEL_NAME rt_trace_parity_pairs2_census
 #define RT_OPT_WALK 4
@@ -173,6 +187,8 @@ static const Instance kParityInstances[] = {
     { parity_pairs3::rt_trace_parity_pairs3, "rt_trace_parity_pairs3", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs4::rt_trace_parity_pairs4, "rt_trace_parity_pairs4", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs5::rt_trace_parity_pairs5, "rt_trace_parity_pairs5", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs6::rt_trace_parity_pairs6, "rt_trace_parity_pairs6", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs7::rt_trace_parity_pairs7, "rt_trace_parity_pairs7", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs2_census::rt_trace_parity_pairs2_census, "rt_trace_parity_pairs2_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

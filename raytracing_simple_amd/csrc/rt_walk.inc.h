@@ -351,6 +351,93 @@ RT_DEV void walk_pairs_c(const float4 *s_pairs, const float4 *s_slots, const uin
 
 
 
+// walk_pairs_c trimmed further (A/B; needs the materials by slot: a closest-hit walk keeps no scene index).  Pair step: which
+// child comes first is mask logic, not selects of materialised booleans.  Leaf step: a closest-hit ray tracks distance and slot
+// only; "some sphere's distance equalled the best so far" is one accumulated mask for the whole leaf, and the rare wavefront
+// that has one settles it afterwards -- the reference's loop (.cl:215-232: strictly nearer wins, scene order breaks ties) is
+// the lexicographic minimum over (distance, scene index), so the spheres of this leaf at exactly the final distance are
+// compared by index with the holder of the slot.
+RT_DEV void walk_pairs_d(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
+                         uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
+                         uint32_t &w_idx, uint32_t &w_slot) {
+    while (cur != kWalkDone) {
+        for (int round = round_len; cur < kBvhLeafRef && round > 0; --round) {
+            const float4 *pp = s_pairs + 4u * cur;
+            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
+            float tn0, tn1;
+            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
+            const uint32_t prune = shadow ? w_idx : 0xffffffffu;
+            const bool m0 = (int)out0 | (int)(__float_as_uint(B0.w) > prune), m1 = (int)out1 | (int)(__float_as_uint(B1.w) > prune);
+            const bool both = !m0 & !m1, none = m0 & m1;
+            const bool second_first = (int)m0 | ((int)!m1 & (int)(tn1 < tn0));      // the second child first: the first is missed, or both are hit and it is nearer
+            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
+            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
+            my_stack[sp * stack_stride] = (uint16_t)far;       // (dead unless `both`: the entry above the top)
+            sp += both ? 1 : 0;
+            if (none) {
+                sp -= 1;
+                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+                sp = sp < 0 ? 0 : sp;
+            } else {
+                cur = near;
+            }
+        }
+        if (cur != kWalkDone && cur >= kBvhLeafRef) {
+            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
+            uint32_t blockers = 0u;
+            bool tie = false;
+#pragma unroll
+            for (int half = 0; half < kBvhLeaf; half += 4) {
+                HitPre p[4];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int k = half + k4;
+                    if (wave_any_nonneg(p[k4].det)) {
+                        const HitRoots hr = hit_roots(p[k4]);
+                        const bool nearer = hr.hit & (hr.t < w_far);
+                        blockers |= nearer ? (1u << k) : 0u;                    // (a shadow ray's blockers; a closest-hit ray ignores the mask)
+                        tie = (int)tie | ((int)hr.hit & (int)(hr.t == w_far));
+                        const bool take = nearer & !shadow;
+                        w_far = take ? hr.t : w_far;
+                        w_slot = take ? sl + (uint32_t)k : w_slot;
+                    }
+                }
+            }
+            if (shadow) {
+                while (blockers != 0u) {                                // the lowest scene index that blocks (.cl:234-247)
+                    const uint32_t k = (uint32_t)__builtin_ctz(blockers);
+                    blockers &= blockers - 1u;
+                    const uint32_t ix = index[sl + k];
+                    w_idx = ix < w_idx ? ix : w_idx;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(tie & !shadow) != 0ull) {
+                if (tie & !shadow) {                                    // the loader doubles spheres: exact ties are real
+                    uint32_t have = index[w_slot];
+                    for (int k = 0; k < kBvhLeaf; ++k) {
+                        const HitPre pk = hit_pre(s_slots[sl + (uint32_t)k], o, d);
+                        if (pk.det >= 0.f) {
+                            const HitRoots hk = hit_roots(pk);
+                            if (hk.hit && hk.t == w_far) {
+                                const uint32_t ix = index[sl + (uint32_t)k];
+                                if (ix < have) {
+                                    have = ix;
+                                    w_slot = sl + (uint32_t)k;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            sp -= 1;
+            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
+            sp = sp < 0 ? 0 : sp;
+        }
+    }
+}
+
 #if RT_OPT_WALK >= 3
 #include "rt_walk2.inc.h"      // the second form of the kernel (its own kernel body); RT_OPT_WALK 4: with its census
 #else

@@ -362,7 +362,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
         // ---- T: every walk in flight advances, up to P.walk_steps pair steps; at most P.walk_round of them in a row while
         //      some lane holds a leaf.  Control is the wavefront's: two ballots per step, scalar branches ----
-#if RT_OPT_WALK == 7
+#if RT_OPT_WALK == 9
+        if (W.cur != kWalkDone)
+            walk_pairs_d(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx, W.slot);
+#elif RT_OPT_WALK == 7 || RT_OPT_WALK == 8
         if (W.cur != kWalkDone)
             walk_pairs_c(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_steps, P.walk_round, W.cur, W.sp,
                          W.far, W.idx, W.slot);
@@ -448,8 +451,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     path_done = true;                                              // miss, .cl:327-330
                 } else {
                     const float4 ge = s_slots[W.slot];
-                    const uint32_t id = W.idx == kWalkIndexOpen ? s_index[W.slot] : W.idx;
                     float4 em4, co4;
+#if RT_OPT_WALK >= 8
+                    // the hit sphere's material by the SLOT the walk ended on (the blob's material sections are in slot order):
+                    // one round trip to L2, where the scene index first and the record by index after it were two
+                    em4 = P.bvh.blob[P.bvh.emis_at + W.slot];
+                    co4 = P.bvh.blob[P.bvh.emis_at + n_slots + W.slot];
+#else
+                    const uint32_t id = W.idx == kWalkIndexOpen ? s_index[W.slot] : W.idx;
                     if (P.mat_in_lds) {
                         em4 = s_emis[id];
                         co4 = s_colr[id];
@@ -458,6 +467,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                         em4 = P.scene.emis[id];
                         co4 = P.scene.colr[id];
                     }
+#endif
                     const V3 em = mk(em4.x, em4.y, em4.z);
                     const V3 col = mk(co4.x, co4.y, co4.z);
                     const int refl = __float_as_int(em4.w);
@@ -589,7 +599,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 {
                     // ---- camera ray, .cl:494-549 (a finished path's next sample; the first sample of the launch); the camera
                     //      (12 floats) and 1/w, 1/h come from LDS, once per sample ----
-                    const float4 c0 = s_cam[0], c1 = s_cam[1], c2 = s_cam[2], c3 = s_cam[3];
+                    const float4 *cam_p = s_cam;
+                    asm volatile("; camera read here, once per sample" : "+v"(cam_p));       // (not hoisted out of the loop into registers that are then spilled)
+                    const float4 c0 = cam_p[0], c1 = cam_p[1], c2 = cam_p[2], c3 = cam_p[3];
                     const float inv_w = c3.z, inv_h = c3.w;
                     const V3 cam_o = mk(c0.x, c0.y, c0.z), cam_d = mk(c0.w, c1.x, c1.y);
                     const V3 cam_x = mk(c1.z, c1.w, c2.x), cam_y = mk(c2.y, c2.z, c2.w);
