@@ -288,6 +288,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int rtile = lrow / P.tile_rows;
     const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
+    // through the loop the pixel's place is ONE register, x | y << 16 (the camera ray needs both per sample; images stop at 65535
+    // either way); the local row and the validity are formed again after the loop (as in rt_trace.inc.h)
+    const uint32_t xy = (uint32_t)x | ((uint32_t)y << 16);
 
     uint32_t s0 = 0, s1 = 0;
     V3 acc = mk(0.f, 0.f, 0.f);
@@ -303,7 +306,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 
     uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
-    unsigned long long c_tests = 0;
+    uint32_t c_tests = 0;               // shadow-ray tests since the last flush into the workgroup's sum (one register, not two: below)
 
     // ---- lane state ---------------------------------------------------------------------------
     enum { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3 };
@@ -440,6 +443,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 // ---- the shadow ray of light lj - 1 has its answer, .cl:297-301 ----
                 const bool blocked = W.idx < n;
                 c_tests += blocked ? W.idx + 1u : n;
+                if ((int)c_tests < 0) {                                             // (rare: the 64-bit sum lives in LDS, the lane keeps 31 bits of it)
+                    atomicAdd(&s_stat[3], (unsigned long long)c_tests);
+                    c_tests = 0u;
+                }
                 if (!blocked) {
                     const float4 lb = s_lightB[lj - 1u];
                     ld = add(ld, scale(mk(lb.x, lb.y, lb.z), l_k));
@@ -608,8 +615,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     float j1 = next_random_centred(s0, s1);
                     float j2 = next_random_centred(s0, s1);
                     c_draws += 2;
-                    float kcx = ((float)x + j1) * inv_w - 0.5f;
-                    float kcy = ((float)y + j2) * inv_h - 0.5f;
+                    float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
+                    float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
                     V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
                                cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
                     o = add(scale(rd, 0.1f), cam_o);
@@ -678,9 +685,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("; epilogue arguments re-read" : "+s"(qp));
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
-    if (valid && Q.n_samples > 0) {
-        int xe = x, ye = y, le = lrow;
-        asm volatile("; indices re-formed after the loop" : "+v"(xe), "+v"(ye), "+v"(le));
+    const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
+    if (valid_e && Q.n_samples > 0) {
+        const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16);
+        int le = tile_by * kTileH + ((int)(threadIdx.x & 63u) >> 3);
+        if (Q.deal) {                                                      // (the local row of a dealt pixel: read again, not kept)
+            const int rows_e = Q.deal_rows, bands = rows_e >> 3, ry_e = tile_by / bands, band = tile_by - ry_e * bands;
+            le = ry_e * rows_e + (int)(Q.deal[(size_t)(ry_e * (int)gridDim.x + tile_bx) * (size_t)(kRegionW * rows_e) + (unsigned)(band * 256 + (int)threadIdx.x)] >> 5);
+        }
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;
         float *colors = Q.colors;
@@ -697,12 +709,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             pc[(size_t)le * (size_t)Q.w + (size_t)xe] = (uint16_t)(rays < 65535u ? rays : 65535u);
         }
     }
-    uint32_t n_done = valid ? (uint32_t)Q.n_samples : 0u;
+    uint32_t n_done = valid_e ? (uint32_t)Q.n_samples : 0u;
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);
     uint32_t t_draws = wave_sum(c_draws);
-    unsigned long long tests64 = c_tests + (unsigned long long)c_closest * n;
+    unsigned long long tests64 = (unsigned long long)c_tests + (unsigned long long)c_closest * n;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
     if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wave_t0[wave]));

@@ -37,11 +37,13 @@ def read_bvh(ctx):
         return None
     at_index = 2 + n_slots
     at_pairs = at_index + (n_slots + 3) // 4
-    n4 = at_pairs + 4 * (n_leaves - 1)
+    at_emis = at_pairs + 4 * (n_leaves - 1)
+    n4 = at_emis + 2 * n_slots                          # ... | pairs | material records by slot (emission + reflection, colour + radius)
     blob = np.zeros(4 * n4, np.float32)
     ctx._check(ctx._lib.rt_debug_read_bvh(ctx._h, blob.ctypes.data_as(C.c_void_p), n4, counts))
     b4 = blob.reshape(n4, 4)
-    return {"hdr": b4[:2], "slots": b4[2:at_index], "index": blob[4 * at_index:].view(np.uint32)[:n_slots], "pairs": b4[at_pairs:],
+    return {"hdr": b4[:2], "slots": b4[2:at_index], "index": blob[4 * at_index:].view(np.uint32)[:n_slots], "pairs": b4[at_pairs:at_emis],
+            "emis": b4[at_emis:at_emis + n_slots], "colr": b4[at_emis + n_slots:at_emis + 2 * n_slots],
             "n_always": n_always, "n_leaves": n_leaves, "stack_depth": depth, "n_slots": n_slots, "root": root}
 
 
@@ -71,6 +73,12 @@ def check_structure(sph, b):
         want = np.array([p[ix, 0], p[ix, 1], p[ix, 2], np.float32(rad[ix]) * np.float32(rad[ix])], np.float32)
         if not np.array_equal(want.view(np.uint32), b["slots"][j].view(np.uint32)):
             bad.append(f"slot {j} != record {ix}")
+        # the material records of the slot: { emission, bits(refl) }, { colour, radius } of that very sphere
+        e, c = np.ascontiguousarray(sph["e"][ix]).astype(np.float32), np.ascontiguousarray(sph["c"][ix]).astype(np.float32)
+        want_e = np.concatenate([e.view(np.uint32), np.array([sph["refl"][ix]], np.int32).view(np.uint32)])
+        want_c = np.concatenate([c.view(np.uint32), np.array([rad[ix]], np.float32).view(np.uint32)])
+        if not (np.array_equal(want_e, b["emis"][j].view(np.uint32)) and np.array_equal(want_c, b["colr"][j].view(np.uint32))):
+            bad.append(f"material records of slot {j} != sphere {ix}")
     # the sibling pairs: from the root every leaf is reached exactly once, every child box holds the
     # spheres below it and knows their lowest scene index
     LEAF = 0x8000
