@@ -53,7 +53,7 @@ RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
  * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, stack depth, root pair } (slots = always + 8 * leaves), all 0 without a hierarchy */
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
 RT_API int rt_debug_set_tree_shape(rt_ctx *ctx, int by_area);        /* 1 (default): a full scene upload builds the hierarchy on the host, its shape chosen by surface area; 0: the device build's fixed shape (what device-resident updates always get) */
-RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* pair steps per lane per loop trip; ready lanes that make a wavefront shade (0 = keep either); forced 0 = hierarchy or plain sweep by measurement (default), 1 = the hierarchy whenever the scene has one */
+RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* steps: ignored since round 4 (it was the per-trip step budget; a walk now runs to its end within the trip); gate: ready lanes that make a wavefront shade (0 = keep); forced 0 = hierarchy or plain sweep by estimate / measurement (default), 1 = the hierarchy whenever the scene has one */
 RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a lane takes in a row before the leaf step of the lanes that hold a leaf (default 3; large = until every lane has one) */
 /* n_rays rays { o.xyz, t_max, d.xyz, shadow != 0 } (8 floats each; the last as a bit pattern) through the hierarchy walk
  * AND the plain sweep, one lane per ray; out4 (4 words per ray) = the walk's answer, then the sweep's -- closest hit:
@@ -61,7 +61,6 @@ RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a la
  * none) and 0.  The two must be equal for every ray whatever its origin and direction. */
 RT_API int rt_debug_walk_rays(rt_ctx *ctx, const float *rays8, uint32_t n_rays, uint32_t *out4);
 RT_API int rt_debug_create_breakdown(double *out8);   /* host ms of the last rt_create of this process: device query, stream + events, allocations, kernel function attributes (code object load on a first context), seed stream generated, its upload, restore kernel + wait, total */
-RT_API int rt_debug_set_walk_tail(rt_ctx *ctx, int lanes);   /* the second form of the walk kernel: leaf steps of no more than `lanes` lanes are done by the wavefront, one sphere test per lane (0: never) */
 RT_API int rt_debug_tree_estimate(rt_ctx *ctx, double *out4);   /* { expected pair steps, expected leaf visits, predicted walk / sweep time per ray, verdict came from the estimate }; returns 1 if the scene has an estimate */
 RT_API int rt_debug_set_choice_estimate(rt_ctx *ctx, int on);  /* 0: the surface-area estimate never decides hierarchy against sweep (every undecided scene is measured) */
 RT_API int rt_debug_bvh_pick(rt_ctx *ctx);   /* 0 = not decided yet, 1 = the hierarchy, 2 = the plain sweep (of this scene, by measurement) */

@@ -446,11 +446,7 @@ bool tables_fit_lds(const rt_ctx *c, int n_samples) {
 }
 
 // the hierarchy's tables fit the LDS budget given to them; otherwise the walk reads them from HBM / L2
-bool bvh_fits_lds(const rt_ctx *c, int n_samples) {
-    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
-    const bool mat = lds_all <= (size_t)c->mat_lds_limit;
-    return pairs_lds(c, mat, n_samples) <= (size_t)c->bvh_lds_limit;
-}
+bool bvh_fits_lds(const rt_ctx *c, int n_samples) { return pairs_lds(c, false, n_samples) <= (size_t)c->bvh_lds_limit; }
 
 // the scene has a hierarchy and the context may use it
 bool bvh_usable(const rt_ctx *c) { return c->bvh_ok && c->wg_waves != 1 && c->persist == 0; }
@@ -476,7 +472,8 @@ int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::LaunchPa
             lds = rt::lds_bytes(0, 0, false, n_samples);
             break;
         case rt::kTabPairsLds:
-            lds = pairs_lds(c, p.mat_in_lds != 0, n_samples);
+            p.mat_in_lds = 0;               // (the walk reads a hit's material by slot from the hierarchy's blob: nothing of it is staged)
+            lds = pairs_lds(c, false, n_samples);
             break;
         case rt::kTabPairsGlobal:
             p.mat_in_lds = 0;
@@ -525,9 +522,7 @@ int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool nat
         role = rt::kRoleSweepGlobal;
         waves = 4;
     }
-    p.walk_steps = c->walk_steps;
     p.walk_round = c->walk_round;
-    p.walk_tail = c->walk_tail;
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {
@@ -1682,7 +1677,6 @@ RT_API int rt_debug_set_tree_shape(rt_ctx *c, int by_area) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     return dbg_apply(c, dbg_set_tree_shape, by_area);
 }
-static int dbg_set_walk_steps(rt_ctx *c, int v) { if (v > 0) c->walk_steps = v; return RT_OK; }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
 static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v; return RT_OK; }
 
@@ -1691,19 +1685,12 @@ RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     return dbg_apply(c, dbg_set_walk_round, steps);
 }
 
-static int dbg_set_walk_tail(rt_ctx *c, int v) { c->walk_tail = v; return RT_OK; }
-// rt_walk2.inc.h: leaf steps that no more than `lanes` lanes take part in are done by the wavefront, one sphere test per lane (0 = never)
-RT_API int rt_debug_set_walk_tail(rt_ctx *c, int lanes) {
-    if (!c || lanes < 0 || lanes > 64) return fail(RT_ERR_ARG, "lanes %d", lanes);
-    return dbg_apply(c, dbg_set_walk_tail, lanes);
-}
 static int dbg_set_walk_forced(rt_ctx *c, int v) { c->walk_forced = v ? 1 : 0; rearm_probe(c); return RT_OK; }
 // rt_walk.inc.h: pair steps per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
 // forced: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = the hierarchy whenever the scene has one
 RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int forced) {
     if (!c || steps < 0 || gate < 0 || gate > 64 || forced < 0 || forced > 1) return fail(RT_ERR_ARG, "steps %d, gate %d, forced %d", steps, gate, forced);
-    int rc = dbg_apply(c, dbg_set_walk_steps, steps);
-    if (rc == RT_OK) rc = dbg_apply(c, dbg_set_walk_gate, gate);
+    int rc = dbg_apply(c, dbg_set_walk_gate, gate);         // (`steps`: the per-trip step budget of rounds 2-3; a walk now runs to its end within the trip)
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_forced, forced);
 }
 // rays8[i] = { o.xyz, t_max, d.xyz, shadow != 0 } through the hierarchy walk and through the plain sweep (csrc/rt_walk.inc.h

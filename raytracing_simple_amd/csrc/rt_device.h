@@ -119,9 +119,7 @@ struct LaunchParams {
     uint32_t seq;
     // instances that walk the hierarchy of a large scene (RT_OPT_BVH) -- at the end: the other instances' argument
     // offsets, and with them their scalar loads and SGPR allocation, are what they were without it
-    int walk_steps;         // rt_walk.inc.h: pair steps a lane may take per loop trip
-    int walk_round;         // ... and in a row before the leaf step of the lanes that hold a leaf
-    int walk_tail;          // rt_walk2.inc.h: a leaf step that no more than this many lanes take part in is done by the wavefront (leaf_step_coop; 0 = never)
+    int walk_round;         // rt_walk.inc.h: pair steps in a row before the leaf step of the lanes that hold a leaf
     BvhTables bvh;
 };
 

@@ -48,8 +48,7 @@ struct rt_ctx {
     int bvh_min = 56;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
-    int walk_steps = 64, walk_gate = 16, walk_round = 3;    // rt_walk.inc.h: node tests per lane per loop trip; ready lanes that make the wavefront shade
-    int walk_tail = 8;                  // rt_walk2.inc.h: leaf steps of this many lanes or fewer are done cooperatively (0 = never)
+    int walk_gate = 16, walk_round = 3; // rt_walk.inc.h: ready lanes that make the wavefront shade; pair steps in a row before a leaf step
     int walk_forced = 0;                // 0 = measured choice (below); diagnostics: 1 = the hierarchy whenever the scene has one
     // hierarchy or plain sweep?  Decided per scene by measurement (rt_api.hip launch()): each form once warm and once
     // timed between events, in the same tile order; whichever took less time per pass renders the rest

@@ -73,55 +73,7 @@
 #include "rt_opts_reset.h"
 
 #if RT_DIAGNOSTICS
-#define RT_NS parity_pairs2          /* the second form of the walk kernel (rt_walk2.inc.h), under A/B */
-#define RT_KERNEL_NAME rt_trace_parity_pairs2
-#define RT_OPT_WALK 3
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs3          /* A/B: the second form's shade phase over the first form's walk loop */
-#define RT_KERNEL_NAME rt_trace_parity_pairs3
-#define RT_OPT_WALK 5
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs4          /* A/B: pairs3 with the walk loop's inner branches taken out (walk_pairs_b) */
-#define RT_KERNEL_NAME rt_trace_parity_pairs4
-#define RT_OPT_WALK 6
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs5          /* A/B: pairs4 without the step budget, with a branch-free push and ballot-gated roots in the leaf */
-#define RT_KERNEL_NAME rt_trace_parity_pairs5
-#define RT_OPT_WALK 7
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs6          /* A/B: pairs5 with the hit's material read by slot */
-#define RT_KERNEL_NAME rt_trace_parity_pairs6
-#define RT_OPT_WALK 8
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs7          /* A/B: pairs6 with the pair step's choice as mask logic and the leaf's tie handling out of line */
-#define RT_KERNEL_NAME rt_trace_parity_pairs7
-#define RT_OPT_WALK 9
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs2_census
-#define RT_KERNEL_NAME rt_trace_parity_pairs2_census
-#define RT_OPT_WALK 4
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs_census    /* the pair walk with a census of what it executes (counters[20..28]) */
+#define RT_NS parity_pairs_census    /* the walk with a census of what it executes (counters[20..29], [8..15]) */
 #define RT_KERNEL_NAME rt_trace_parity_pairs_census
 #define RT_OPT_WALK 2
 #include "rt_trace.inc.h"
@@ -183,13 +135,6 @@ static const Instance kParityInstances[] = {
     { parity_pairs_g::rt_trace_parity_pairs_g, "rt_trace_parity_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, 0 },
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
-    { parity_pairs2::rt_trace_parity_pairs2, "rt_trace_parity_pairs2", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs3::rt_trace_parity_pairs3, "rt_trace_parity_pairs3", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs4::rt_trace_parity_pairs4, "rt_trace_parity_pairs4", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs5::rt_trace_parity_pairs5, "rt_trace_parity_pairs5", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs6::rt_trace_parity_pairs6, "rt_trace_parity_pairs6", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs7::rt_trace_parity_pairs7, "rt_trace_parity_pairs7", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs2_census::rt_trace_parity_pairs2_census, "rt_trace_parity_pairs2_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },

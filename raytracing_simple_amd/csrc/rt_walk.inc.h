@@ -1,5 +1,5 @@
 // rt_walk.inc.h -- the path-trace kernel for large scenes (RT_OPT_WALK), included by rt_trace.inc.h in place of its own
-// kernel body; everything above it there (vector helpers, RNG, the sphere test, the sweeps, sample_light) is shared.
+// kernel body; everything above it there (vector helpers, RNG, the sphere test, the sweeps) is shared.
 //
 // The small spheres hang in a bounding-volume hierarchy (rt_device.h BvhTables, built by rt_bvh.hip) that each lane walks
 // for its own ray; the few large ones are swept by every ray as before.  The hierarchy only selects candidates -- every
@@ -10,17 +10,24 @@
 // draws per pixel -- but the lanes of a wavefront are decoupled once more: a ray's walk is lane state (where it is in the
 // tree, its stack, the bound, the best so far) that survives loop trips:
 //
-//   T  every lane with a walk in flight takes up to P.walk_steps steps of it (walk_pairs below; closest-hit and shadow
-//      rays run the same loop, they differ in how a candidate updates the state);
-//   S  lanes whose walk has ended (or that have no ray) do what comes next for them -- process the hit, sample
-//      the next light and start its shadow ray, add the light's contribution, bounce, finish the sample, start
-//      a camera ray -- once P.regen_gate of them are waiting or nobody is walking, and then join T again.
+//   T  every lane with a walk in flight walks it to its end (walk_pairs below; closest-hit and shadow rays run the same
+//      loop, they differ in how a candidate updates the state);
+//   S  lanes whose walk has ended (or that have no ray) do what comes next for them -- process the hit, sample the next
+//      light or bounce, finish the sample, start a camera ray -- once P.regen_gate of them are waiting or nobody is
+//      walking, and then join T again.  Each piece of work runs ONCE per phase for whoever needs it: the two random draws,
+//      the sine / cosine and the square root that a light sample and a diffuse bounce both begin with are one section for
+//      both (a wavefront's lanes are typically half back from a closest-hit walk -- light sample next -- and half back from
+//      a shadow walk -- bounce next), and every new ray, closest-hit or shadow, starts in one place (always-list sweep, ray
+//      set-up).
 //
 // Nothing here depends on which trip a lane does what: per pixel the sequence of operations and random draws is the
 // reference's.  RT_OPT_WALK 2 is the census instance of the diagnostics build (steps executed, lanes taking part, clock
-// shares: counters[20..28]); with RT_OPT_GLOBAL_TABLES the pairs and slots are read where they lie in HBM / L2.
-// Earlier forms (depth-first nodes with skip links, walked per call or as lane state) were measured and dropped:
-// DESIGN.md section 5 names the commits.
+// shares: counters[20..29], and how many lanes the steps run with: counters[8..15]); with RT_OPT_GLOBAL_TABLES the pairs
+// and slots are read where they lie in HBM / L2.  Round 4 measured this kernel's time to follow the number of instructions
+// a wavefront issues, of every kind: the walk's inner loops are written to keep branches, scalar
+// mask bookkeeping and waits out of them.  Other forms (depth-first nodes with skip links; a walk loop under wave-uniform
+// control with branch-free steps; leaf steps done cooperatively by eight lanes per ray; ending a trip's walk phase early)
+// were measured and dropped: DESIGN.md section 5 names the commits.
 
 // ---- walking the hierarchy ---------------------------------------------------------------------------
 // A sphere can only matter to a ray if the reference's test (hit_pre / hit_roots above, binary32, rounded after
@@ -93,44 +100,51 @@ RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
 }
 
 // ---- the walk over sibling pairs (rt_device.h BvhTables `pairs`), nearer child first ----
-// One step loads a pair (64 bytes), tests both boxes against the ray's stretch, goes on with the nearer of the
+// One pair step loads a pair (64 bytes), tests both boxes against the ray's stretch, goes on with the nearer of the
 // children that are hit and keeps the other on the lane's stack (16 bits per entry, [level][lane]); with neither hit
 // it takes the last kept one.  Which child comes first only decides how soon the bound shrinks: every sphere whose
 // chain of boxes the ray meets is still tested, so the result is the same set of candidates run through the same rule.
 // Shadow rays look for the LOWEST blocking scene index (that is what .cl:234-247 returns at): a subtree that only
-// holds higher indices than the best so far is skipped.  The walk's place (cur, sp) and its result so far (w_far,
-// w_idx, w_slot) are the caller's: `budget` pair steps at most per call, the rest next time.  At most `round_len`
-// pair steps are taken in a row before the leaf step of the lanes that hold a leaf -- a lane that is still looking
-// goes on looking in the next round instead of keeping the others waiting (the number of steps to the next leaf has
-// a long tail).  cen (census instances only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps.
+// holds higher indices than the best so far is skipped -- one compare against a per-ray bound.  At most `round_len` pair
+// steps are taken in a row before the leaf step of the lanes that hold a leaf -- a lane that is still looking goes on
+// looking in the next round instead of keeping the others waiting (the number of steps to the next leaf has a long tail).
+// A leaf step runs the leaf's eight spheres through the reference's test, in two halves of four (all eight discriminants
+// at once are registers the kernel does not have), the root half behind a wave ballot.  What needs memory or is rare
+// leaves the loop over the spheres: the scene indices of a shadow ray's blockers are read after the tests (one wait, not
+// one per blocker), and an exact tie in distance (the .scn loader doubles spheres: real) takes a branch the whole
+// wavefront skips when nobody has one.  The kept sibling is written above the stack's top whether it is kept or not (no
+// branch; `both` only moves the stack pointer: the entry above the top is dead).
+// cen (census instance only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps; hist: steps by lanes.
 constexpr uint32_t kWalkDone = 0xffffffffu;
-constexpr uint32_t kWalkIndexOpen = 0xfffffffeu;        // closest-hit walks: the best slot's scene index has not been read yet
+constexpr uint32_t kWalkIndexOpen = 0xfffffffeu;        // closest-hit walks: the best slot's scene index has not been read
 RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
-                       uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
-                       int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen) {
+                       uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
+                       uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist) {
     const int lane_ = threadIdx.x & 63;
-    while (cur != kWalkDone && budget > 0) {
-        for (int round = round_len; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
-            budget -= 1;
+    while (cur != kWalkDone) {
+        for (int round = round_len; cur < kBvhLeafRef && round > 0; --round) {
             if (cen) {
                 const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
-                if (lane_ == __ffsll((long long)act_) - 1) cen[0] += 1ull;
+                const int n_ = __popcll(act_);
+                if (lane_ == __ffsll((long long)act_) - 1) {
+                    cen[0] += 1ull;
+                    hist[4 + (n_ <= 8 ? 0 : (n_ <= 16 ? 1 : (n_ <= 32 ? 2 : 3)))] += 1ull;
+                }
                 cen[1] += 1ull;
             }
             const float4 *pp = s_pairs + 4u * cur;
             const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
             float tn0, tn1;
             const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
-            const bool m0 = out0 || (shadow && __float_as_uint(B0.w) > w_idx);
-            const bool m1 = out1 || (shadow && __float_as_uint(B1.w) > w_idx);
+            // a shadow walk skips subtrees that hold only scene indices above its lowest blocker so far; a closest-hit walk never does
+            const uint32_t prune = shadow ? w_idx : 0xffffffffu;
+            const bool m0 = (int)out0 | (int)(__float_as_uint(B0.w) > prune), m1 = (int)out1 | (int)(__float_as_uint(B1.w) > prune);
             const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
             const bool both = !m0 & !m1, none = m0 & m1;
             const bool second_first = both ? (tn1 < tn0) : m0;
             const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
-            if (both) {
-                my_stack[sp * stack_stride] = (uint16_t)far;
-                sp += 1;
-            }
+            my_stack[sp * stack_stride] = (uint16_t)far;       // (dead unless `both`: the entry above the top)
+            sp += both ? 1 : 0;
             if (none) {
                 sp -= 1;
                 cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
@@ -142,91 +156,14 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
         if (cur != kWalkDone && cur >= kBvhLeafRef) {
             if (cen) {
                 const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);
-                if (lane_ == __ffsll((long long)act_) - 1) cen[2] += 1ull;
+                const int n_ = __popcll(act_);
+                if (lane_ == __ffsll((long long)act_) - 1) {
+                    cen[2] += 1ull;
+                    hist[n_ <= 8 ? 0 : (n_ <= 16 ? 1 : (n_ <= 32 ? 2 : 3))] += 1ull;
+                }
                 cen[3] += 1ull;
             }
             const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-            // (two halves of four: the discriminants of all eight at once are registers the kernel then spills elsewhere)
-#pragma unroll
-            for (int half = 0; half < kBvhLeaf; half += 4) {
-            HitPre p[4];
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int k = half + k4;
-                if (p[k4].det >= 0.f) {
-                    const HitRoots hr = hit_roots(p[k4]);
-                    // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index;
-                    // shadow ray (.cl:234-247): the lowest scene index that blocks
-                    // The scene index of a slot lies in HBM / L2.  A shadow ray needs it for every blocker (the lowest one
-                    // is the answer and prunes subtrees); a closest-hit ray only to break an exact tie -- a strictly
-                    // nearer hit just takes the slot, and its index is read once, when the walk is over (kWalkIndexOpen).
-                    if (shadow) {
-                        if (hr.hit && hr.t < w_far) {
-                            const uint32_t ix = index[sl + k];
-                            w_idx = ix < w_idx ? ix : w_idx;
-                        }
-                    } else if (hr.hit) {
-                        if (hr.t < w_far) {
-                            w_far = hr.t;
-                            w_slot = sl + (uint32_t)k;
-                            w_idx = kWalkIndexOpen;
-                        } else if (hr.t == w_far) {                     // the loader doubles spheres: exact ties are real
-                            const uint32_t ix = index[sl + k];
-                            const uint32_t have = w_idx == kWalkIndexOpen ? index[w_slot] : w_idx;
-                            w_idx = have;
-                            if (ix < have) {
-                                w_slot = sl + (uint32_t)k;
-                                w_idx = ix;
-                            }
-                        }
-                    }
-                }
-            }
-            }
-            sp -= 1;
-            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-            sp = sp < 0 ? 0 : sp;
-        }
-    }
-}
-
-
-// The same walk with three things taken out of its inner loops (A/B, round 4): a shadow walk's pruning by scene index is one
-// compare against a per-ray bound (the written form made the compiler branch around a fourth LDS read of the pair for it); the
-// scene indices of a leaf's blockers are read after its eight tests (one wait, not one per blocker); an exact tie in distance
-// leaves the straight line through a branch the whole wavefront skips when nobody has one.
-RT_DEV void walk_pairs_b(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
-                         uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
-                         int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot) {
-    while (cur != kWalkDone && budget > 0) {
-        for (int round = round_len; cur < kBvhLeafRef && budget > 0 && round > 0; --round) {
-            budget -= 1;
-            const float4 *pp = s_pairs + 4u * cur;
-            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
-            float tn0, tn1;
-            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
-            const uint32_t prune = shadow ? w_idx : 0xffffffffu;
-            const bool m0 = (int)out0 | (int)(__float_as_uint(B0.w) > prune), m1 = (int)out1 | (int)(__float_as_uint(B1.w) > prune);
-            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
-            const bool both = !m0 & !m1, none = m0 & m1;
-            const bool second_first = both ? (tn1 < tn0) : m0;
-            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
-            if (both) {
-                my_stack[sp * stack_stride] = (uint16_t)far;
-                sp += 1;
-            }
-            if (none) {
-                sp -= 1;
-                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-                sp = sp < 0 ? 0 : sp;
-            } else {
-                cur = near;
-            }
-        }
-        if (cur != kWalkDone && cur >= kBvhLeafRef) {
-            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
             uint32_t blockers = 0u;
 #pragma unroll
             for (int half = 0; half < kBvhLeaf; half += 4) {
@@ -236,13 +173,15 @@ RT_DEV void walk_pairs_b(const float4 *s_pairs, const float4 *s_slots, const uin
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const int k = half + k4;
-                    if (p[k4].det >= 0.f) {
+                    if (wave_any_nonneg(p[k4].det)) {
                         const HitRoots hr = hit_roots(p[k4]);
                         const bool nearer = hr.hit & (hr.t < w_far);
-                        blockers |= (shadow & nearer) ? (1u << k) : 0u;
+                        blockers |= (shadow & nearer) ? (1u << k) : 0u;        // shadow ray (.cl:234-247): a blocker; its index is read below
+                        // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index.  The scene index of a
+                        // slot lies in HBM / L2: a strictly nearer hit just takes the slot (kWalkIndexOpen); only an exact tie reads both
                         const bool tie = !shadow & hr.hit & (hr.t == w_far);
                         if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
-                            if (tie) {                                  // the loader doubles spheres: exact ties are real
+                            if (tie) {
                                 const uint32_t ix = index[sl + (uint32_t)k];
                                 const uint32_t have = w_idx == kWalkIndexOpen ? index[w_slot] : w_idx;
                                 w_idx = have;
@@ -259,7 +198,7 @@ RT_DEV void walk_pairs_b(const float4 *s_pairs, const float4 *s_slots, const uin
                     }
                 }
             }
-            while (blockers != 0u) {                                    // shadow ray: the lowest scene index that blocks (.cl:234-247)
+            while (blockers != 0u) {                                    // the lowest scene index that blocks is the answer (and prunes the rest of the walk)
                 const uint32_t k = (uint32_t)__builtin_ctz(blockers);
                 blockers &= blockers - 1u;
                 const uint32_t ix = index[sl + k];
@@ -272,177 +211,17 @@ RT_DEV void walk_pairs_b(const float4 *s_pairs, const float4 *s_slots, const uin
     }
 }
 
+struct Walk {             // a ray's place in the hierarchy and what it has found (lane state across loop trips)
+    uint32_t cur;           // what the lane looks at next: a pair, kBvhLeafRef | leaf, or kWalkDone
+    int sp;                 // entries on its stack
+    float far;              // closest hit: the best distance so far; shadow ray: its length (fixed)
+    uint32_t idx;           // closest hit: scene index of the best if an exact tie made the walk read it (else kWalkIndexOpen); shadow ray: lowest blocking index so far
+    uint32_t slot;          // closest hit: slot of the best
+};
 
-// walk_pairs_b with three more trims (A/B): no per-lane step budget (a walk runs to its end within the trip: the budget of 64
-// was never reached), the kept sibling written above the top whether it is kept or not (no branch; `both` only moves the
-// stack pointer), and the root half of a leaf's sphere tests behind a wave ballot instead of a per-lane branch.
-RT_DEV void walk_pairs_c(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
-                         uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int budget, int round_len, uint32_t &cur,
-                         int &sp, float &w_far, uint32_t &w_idx, uint32_t &w_slot) {
-    (void)budget;
-    while (cur != kWalkDone) {
-        for (int round = round_len; cur < kBvhLeafRef && round > 0; --round) {
-            const float4 *pp = s_pairs + 4u * cur;
-            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
-            float tn0, tn1;
-            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
-            const uint32_t prune = shadow ? w_idx : 0xffffffffu;
-            const bool m0 = (int)out0 | (int)(__float_as_uint(B0.w) > prune), m1 = (int)out1 | (int)(__float_as_uint(B1.w) > prune);
-            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
-            const bool both = !m0 & !m1, none = m0 & m1;
-            const bool second_first = both ? (tn1 < tn0) : m0;
-            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
-            my_stack[sp * stack_stride] = (uint16_t)far;       // (dead unless `both`: the entry above the top)
-            sp += both ? 1 : 0;
-            if (none) {
-                sp -= 1;
-                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-                sp = sp < 0 ? 0 : sp;
-            } else {
-                cur = near;
-            }
-        }
-        if (cur != kWalkDone && cur >= kBvhLeafRef) {
-            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-            uint32_t blockers = 0u;
-#pragma unroll
-            for (int half = 0; half < kBvhLeaf; half += 4) {
-                HitPre p[4];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int k = half + k4;
-                    if (wave_any_nonneg(p[k4].det)) {
-                        const HitRoots hr = hit_roots(p[k4]);
-                        const bool nearer = hr.hit & (hr.t < w_far);
-                        blockers |= (shadow & nearer) ? (1u << k) : 0u;
-                        const bool tie = !shadow & hr.hit & (hr.t == w_far);
-                        if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
-                            if (tie) {                                  // the loader doubles spheres: exact ties are real
-                                const uint32_t ix = index[sl + (uint32_t)k];
-                                const uint32_t have = w_idx == kWalkIndexOpen ? index[w_slot] : w_idx;
-                                w_idx = have;
-                                if (ix < have) {
-                                    w_slot = sl + (uint32_t)k;
-                                    w_idx = ix;
-                                }
-                            }
-                        }
-                        const bool take = nearer & !shadow;
-                        w_far = take ? hr.t : w_far;
-                        w_slot = take ? sl + (uint32_t)k : w_slot;
-                        w_idx = take ? kWalkIndexOpen : w_idx;
-                    }
-                }
-            }
-            while (blockers != 0u) {                                    // shadow ray: the lowest scene index that blocks (.cl:234-247)
-                const uint32_t k = (uint32_t)__builtin_ctz(blockers);
-                blockers &= blockers - 1u;
-                const uint32_t ix = index[sl + k];
-                w_idx = ix < w_idx ? ix : w_idx;
-            }
-            sp -= 1;
-            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-            sp = sp < 0 ? 0 : sp;
-        }
-    }
-}
-
-
-
-// walk_pairs_c trimmed further (A/B; needs the materials by slot: a closest-hit walk keeps no scene index).  Pair step: which
-// child comes first is mask logic, not selects of materialised booleans.  Leaf step: a closest-hit ray tracks distance and slot
-// only; "some sphere's distance equalled the best so far" is one accumulated mask for the whole leaf, and the rare wavefront
-// that has one settles it afterwards -- the reference's loop (.cl:215-232: strictly nearer wins, scene order breaks ties) is
-// the lexicographic minimum over (distance, scene index), so the spheres of this leaf at exactly the final distance are
-// compared by index with the holder of the slot.
-RT_DEV void walk_pairs_d(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
-                         uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
-                         uint32_t &w_idx, uint32_t &w_slot) {
-    while (cur != kWalkDone) {
-        for (int round = round_len; cur < kBvhLeafRef && round > 0; --round) {
-            const float4 *pp = s_pairs + 4u * cur;
-            const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
-            float tn0, tn1;
-            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
-            const uint32_t prune = shadow ? w_idx : 0xffffffffu;
-            const bool m0 = (int)out0 | (int)(__float_as_uint(B0.w) > prune), m1 = (int)out1 | (int)(__float_as_uint(B1.w) > prune);
-            const bool both = !m0 & !m1, none = m0 & m1;
-            const bool second_first = (int)m0 | ((int)!m1 & (int)(tn1 < tn0));      // the second child first: the first is missed, or both are hit and it is nearer
-            const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
-            const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
-            my_stack[sp * stack_stride] = (uint16_t)far;       // (dead unless `both`: the entry above the top)
-            sp += both ? 1 : 0;
-            if (none) {
-                sp -= 1;
-                cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-                sp = sp < 0 ? 0 : sp;
-            } else {
-                cur = near;
-            }
-        }
-        if (cur != kWalkDone && cur >= kBvhLeafRef) {
-            const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-            uint32_t blockers = 0u;
-            bool tie = false;
-#pragma unroll
-            for (int half = 0; half < kBvhLeaf; half += 4) {
-                HitPre p[4];
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int k = half + k4;
-                    if (wave_any_nonneg(p[k4].det)) {
-                        const HitRoots hr = hit_roots(p[k4]);
-                        const bool nearer = hr.hit & (hr.t < w_far);
-                        blockers |= nearer ? (1u << k) : 0u;                    // (a shadow ray's blockers; a closest-hit ray ignores the mask)
-                        tie = (int)tie | ((int)hr.hit & (int)(hr.t == w_far));
-                        const bool take = nearer & !shadow;
-                        w_far = take ? hr.t : w_far;
-                        w_slot = take ? sl + (uint32_t)k : w_slot;
-                    }
-                }
-            }
-            if (shadow) {
-                while (blockers != 0u) {                                // the lowest scene index that blocks (.cl:234-247)
-                    const uint32_t k = (uint32_t)__builtin_ctz(blockers);
-                    blockers &= blockers - 1u;
-                    const uint32_t ix = index[sl + k];
-                    w_idx = ix < w_idx ? ix : w_idx;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(tie & !shadow) != 0ull) {
-                if (tie & !shadow) {                                    // the loader doubles spheres: exact ties are real
-                    uint32_t have = index[w_slot];
-                    for (int k = 0; k < kBvhLeaf; ++k) {
-                        const HitPre pk = hit_pre(s_slots[sl + (uint32_t)k], o, d);
-                        if (pk.det >= 0.f) {
-                            const HitRoots hk = hit_roots(pk);
-                            if (hk.hit && hk.t == w_far) {
-                                const uint32_t ix = index[sl + (uint32_t)k];
-                                if (ix < have) {
-                                    have = ix;
-                                    w_slot = sl + (uint32_t)k;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            sp -= 1;
-            cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
-            sp = sp < 0 ? 0 : sp;
-        }
-    }
-}
-
-#if RT_OPT_WALK >= 3
-#include "rt_walk2.inc.h"      // the second form of the kernel (its own kernel body); RT_OPT_WALK 4: with its census
-#else
 #undef RT_WALK_COUNT
 #undef RT_WALK_CLOCK
+#undef RT_WALK_HIST
 
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
@@ -457,9 +236,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
     const uint32_t root_ref = n_pairs ? P.bvh.root : kBvhLeafRef;
-    constexpr uint32_t kNone = kWalkDone;
 #if RT_OPT_GLOBAL_TABLES
-    // tables too large for LDS: pairs, slots and lights are read where they lie; staged: hdr | one stack per lane
     const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
     const float4 *s_slots = P.bvh.blob + bvh_slots_at();
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_hdr + 2);
@@ -467,7 +244,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     float4 *s_emis = s_hdr + 2 + stack_f4;        // (never read: the host keeps mat_in_lds off)
     float4 *s_colr = s_emis;
 #else
-    // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane])
+    // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane]) | lights | materials
     float4 *s_pairs = s_hdr + 2;
     float4 *s_slots = s_pairs + 4 * n_pairs;
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
@@ -521,8 +298,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
     __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
     if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
-    // the lane's pixel: its wavefront's 8x8 square, or the pixel of this workgroup's rank in the order by cost of the region
-    // (32 x P.deal_rows pixels) its tile lies in (P.deal; rt_trace.inc.h)
     int x = tile_bx * kTileW + wave * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
     if (P.deal) {
         const int bands = P.deal_rows >> 3, region_y = tile_by / bands, band = tile_by - region_y * bands;
@@ -551,7 +326,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
 
     uint32_t c_closest = 0, c_shadow = 0, c_draws = 0;
-    unsigned long long c_tests = 0;
+    uint32_t c_tests = 0;               // shadow-ray tests since the last flush into the workgroup's sum (one register, not two: below)
 
     // ---- lane state ---------------------------------------------------------------------------
     enum { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3 };
@@ -560,75 +335,82 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     V3 thr = mk(1.f, 1.f, 1.f), rad = mk(0.f, 0.f, 0.f);
     int depth = 0;
     bool after_specular = true;
-    // the walk: next node, distance bound, best sphere so far (scene index and slot)
-    uint32_t cur = kNone;               // what the lane looks at next: a pair, kBvhLeafRef | leaf, or nothing (walk over)
-    int sp = 0;                         // entries on its stack
-    uint32_t w_idx = 0xffffffffu, w_slot = 0;
-    float w_far = 0.f;
+    Walk W{ kWalkDone, 0, 0.f, 0xffffffffu, 0u };
     BvhRay R = bvh_ray(s_hdr, o, d);
     // a diffuse hit being lit: its normal, the light sum, the light in flight and what it adds if unblocked
     V3 nl = mk(0.f, 0.f, 1.f), ld = mk(0.f, 0.f, 0.f);
     uint32_t lj = 0;
     float l_k = 0.f;
-    unsigned long long unused_roots = 0;
+    uint16_t *my_stack = s_stack + tid;
 #if RT_OPT_WALK == 2
-    // census instance: wave-level trips and lane participation of the two phases, and where the clock goes
-    // cen[0/1] pair steps (two box tests each) per wavefront / per lane, [2/3] leaf steps (kBvhLeaf sphere tests each),
-    // [4/5] shade phases, [6/7] clock ticks in the walk / in shading, [8] loop trips, [9] sphere tests of the always-list sweeps
+    // census instance.  cen[0/1] pair steps (two box tests each) per wavefront / per lane, [2/3] leaf steps (kBvhLeaf sphere tests
+    // each), [4/5] shade phases, [6/7] clock ticks in the walk / in shading, [8] loop trips, [9] sphere tests of the always-list
+    // sweeps -> counters[20..29]; hist[0..3] leaf steps with 1-8 / 9-16 / 17-32 / 33-64 lanes, hist[4..7] pair steps likewise -> counters[8..15]
     unsigned long long cen[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#define RT_WALK_COUNT(k)                                                                         \
+    unsigned long long hist[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#define RT_WALK_COUNT(k, mask)                                                                     \
     do {                                                                                         \
-        const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
-        if (lane == __ffsll((long long)act_) - 1) cen[k] += 1ull;                                \
+        if (lane == __ffsll((long long)(mask)) - 1) cen[k] += 1ull;                              \
         cen[(k) + 1] += 1ull;                                                                    \
     } while (0)
-#define RT_WALK_CLOCK(k, t0)                                                                     \
+#define RT_WALK_HIST(base, mask)                                                                   \
+    do {                                                                                         \
+        const int n_ = __popcll(mask);                                                           \
+        if (lane == __ffsll((long long)(mask)) - 1) hist[(base) + (n_ <= 8 ? 0 : (n_ <= 16 ? 1 : (n_ <= 32 ? 2 : 3)))] += 1ull; \
+    } while (0)
+#define RT_WALK_CLOCK(arr, k, t0)                                                                  \
     do {                                                                                         \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
         const unsigned long long act_ = __builtin_amdgcn_ballot_w64(true);                       \
-        if (lane == __ffsll((long long)act_) - 1) cen[k] += now_ - (t0);                         \
+        if (lane == __ffsll((long long)act_) - 1) arr[k] += now_ - (t0);                         \
     } while (0)
 #else
-#define RT_WALK_COUNT(k)
-#define RT_WALK_CLOCK(k, t0)
+#define RT_WALK_COUNT(k, mask)
+#define RT_WALK_HIST(base, mask)
+#define RT_WALK_CLOCK(arr, k, t0)
 #endif
 
     for (;;) {
-        if (st == kNew && s >= s_end) break;
+        // (a lane that has rendered its samples stays in the loop, idle, until its wavefront has: the loop's exit is a scalar branch)
+        const bool finished = st == kNew && s >= s_end;
+        if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) break;
 #if RT_OPT_WALK == 2
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
         const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
 #endif
 
-        // ---- T: walk ----
-        // (walk_pairs above: up to P.walk_steps pair steps of this lane's walk, leaf steps in between)
-        if (cur != kNone) {
+        // ---- T: every walk in flight runs to its end ----
+        if (W.cur != kWalkDone) {
 #if RT_OPT_WALK == 2
-            unsigned long long *cen_p = cen;
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
+                       W.slot, cen, hist);
 #else
-            unsigned long long *cen_p = nullptr;
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
+                       W.slot, nullptr, nullptr);
 #endif
-            walk_pairs(s_pairs, s_slots, s_index, s_stack + tid, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_steps,
-                       P.walk_round, cur, sp, w_far, w_idx, w_slot, cen_p);
         }
 
 #if RT_OPT_WALK == 2
-        RT_WALK_CLOCK(6, t_trip);
+        RT_WALK_CLOCK(cen, 6, t_trip);
         const unsigned long long t_s = __builtin_amdgcn_s_memtime();
 #endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
-        const bool ready = cur == kNone;
+        const bool ready = (W.cur == kWalkDone) & !finished;
         const unsigned long long br = __builtin_amdgcn_ballot_w64(ready);
-        const unsigned long long bw = __builtin_amdgcn_ballot_w64(!ready);
+        const unsigned long long bw = __builtin_amdgcn_ballot_w64(W.cur != kWalkDone);
         const bool go = (__popcll(br) >= P.regen_gate) || (bw == 0ull);
         if (ready && go) {
-            RT_WALK_COUNT(4);
+            RT_WALK_COUNT(4, __builtin_amdgcn_ballot_w64(true));
             bool path_done = false;
-            bool start_closest = false;
+            int start = 0;                  // the ray this lane starts at the end of the phase: 0 none, 1 closest hit, 2 shadow
             if (st == kShadow) {
                 // ---- the shadow ray of light lj - 1 has its answer, .cl:297-301 ----
-                const bool blocked = w_idx < n;
-                c_tests += blocked ? w_idx + 1u : n;
+                const bool blocked = W.idx < n;
+                c_tests += blocked ? W.idx + 1u : n;
+                if ((int)c_tests < 0) {                                             // (rare: the 64-bit sum lives in LDS, the lane keeps 31 bits of it)
+                    atomicAdd(&s_stat[3], (unsigned long long)c_tests);
+                    c_tests = 0u;
+                }
                 if (!blocked) {
                     const float4 lb = s_lightB[lj - 1u];
                     ld = add(ld, scale(mk(lb.x, lb.y, lb.z), l_k));
@@ -636,24 +418,19 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 st = kLights;
             } else if (st == kClosest) {
                 c_closest += 1;
-                if (!(w_far < 1e20f)) {
+                if (!(W.far < 1e20f)) {
                     path_done = true;                                              // miss, .cl:327-330
                 } else {
-                    const float4 ge = s_slots[w_slot];
-                    const uint32_t id = w_idx == kWalkIndexOpen ? s_index[w_slot] : w_idx;
+                    const float4 ge = s_slots[W.slot];
                     float4 em4, co4;
-                    if (P.mat_in_lds) {
-                        em4 = s_emis[id];
-                        co4 = s_colr[id];
-                        asm volatile("; materials from LDS" : "+v"(em4.x));
-                    } else {
-                        em4 = P.scene.emis[id];
-                        co4 = P.scene.colr[id];
-                    }
+                    // the hit sphere's material by the SLOT the walk ended on (the blob's material sections are in slot order):
+                    // one round trip to L2, where the scene index first and the record by index after it were two
+                    em4 = P.bvh.blob[P.bvh.emis_at + W.slot];
+                    co4 = P.bvh.blob[P.bvh.emis_at + n_slots + W.slot];
                     const V3 em = mk(em4.x, em4.y, em4.z);
                     const V3 col = mk(co4.x, co4.y, co4.z);
                     const int refl = __float_as_int(em4.w);
-                    const V3 hp = add(o, scale(d, w_far));                         // .cl:338-340
+                    const V3 hp = add(o, scale(d, W.far));                         // .cl:338-340
                     const V3 nrm = unit(sub(hp, mk(ge.x, ge.y, ge.z)));            // .cl:345-347
                     const float dp = dot(nrm, d);
                     nl = scale(nrm, -1.f * cl_sign(dp));                           // .cl:354-355
@@ -703,58 +480,65 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                         o = hp;
                         depth += 1;
                         if (depth >= kMaxDepth) path_done = true;                  // .cl:320
-                        else start_closest = true;
+                        else start = 1;
                     }
                 }
             }
-            // ---- next-event estimation, .cl:249-303: the lights one by one, each with its two draws ----
+            // ---- next-event estimation, .cl:249-303 (the lights one by one, each with its two draws), then the cosine-weighted
+            //      bounce, .cl:383-411 (two draws as well).  Either begins with two random numbers, the sine and cosine of 2 pi
+            //      times one of them and the square root of a value formed from the other: that part is ONE section for the lanes
+            //      about to sample a light and the lanes about to bounce.  Per pixel the operations and their order are the
+            //      reference's (sample_light of rt_trace.inc.h and its bounce, term for term) ----
             while (st == kLights) {
-                if (lj == n_lights) {
+                const bool bounce = lj == n_lights;
+                const float f0 = __uint_as_float(next_random_word(s0, s1));        // first draw, in [2, 4)
+                const float f1 = __uint_as_float(next_random_word(s0, s1));        // second draw
+                c_draws += 2;
+                // light: u1 -> z = 1 - 2 u1 = 3 - f0 (.cl:204), u2 -> phi = 2 pi u2 (.cl:208); bounce: r1 = 2 pi u (.cl:384), r2 (.cl:385)
+                const float turn = __builtin_fmaf(bounce ? f0 : f1, 0.5f, -1.0f);
+                const float zc = 3.0f - f0;
+                const float r2 = __builtin_fmaf(f1, 0.5f, -1.0f);
+                const float under = bounce ? r2 : fmaxf(0.f, 1.f - zc * zc);
+                const float root = rt_sqrt_unit(under);                            // bounce: r2s = sqrt(r2); light: sqrt(max(0, 1 - z z))
+                float sphi, cphi;
+#if RT_FAST
+                fm_sincos_turns(turn, sphi, cphi);
+#else
+                dm_sincosf_pos((2.f * RT_PI) * turn, sphi, cphi);
+#endif
+                if (bounce) {
                     rad = add(rad, mul(thr, ld));                                  // .cl:377-378
-                    // cosine-weighted bounce, .cl:383-411
-                    float u = next_random(s0, s1);
-                    float r2 = next_random(s0, s1);
-                    c_draws += 2;
-                    float r2s = rt_sqrt_unit(r2);
                     V3 w = nl;
                     V3 a = (fabsf(w.x) > .1f) ? mk(0.f, 1.f, 0.f) : mk(1.f, 0.f, 0.f);
                     V3 uu = unit(cross(a, w));
                     V3 vv = cross(w, uu);
-                    float s1v, c1v;
-#if RT_FAST
-                    fm_sincos_turns(u, s1v, c1v);
-#else
-                    dm_sincosf_pos((2.f * RT_PI) * u, s1v, c1v);
-#endif
-                    V3 nd = add(scale(uu, c1v * r2s), scale(vv, s1v * r2s));
+                    V3 nd = add(scale(uu, cphi * root), scale(vv, sphi * root));
                     nd = add(nd, scale(w, rt_sqrt_unit(1 - r2)));
                     d = nd;
                     depth += 1;
                     st = kNew;                                                     // (leaves the light loop)
                     if (depth >= kMaxDepth) path_done = true;
-                    else start_closest = true;
-                    break;
-                }
-                const float4 lb = s_lightB[lj];
-                V3 sd;
-                float len, numer;
-                const bool want = sample_light(s_lightA[lj], lb, s0, s1, c_draws, o, nl, sd, len, numer);
-                lj += 1u;
-                if (want) {
-                    // ---- shadow ray, any hit, .cl:234-247: the large spheres now, the tree in the trips to come ----
-                    c_shadow += 1;
-                    l_k = rt_div(numer, len * len);                                // .cl:297 (used only if nothing blocks)
-                    d = sd;
-                    w_far = len - RT_EPS;
-                    const uint32_t first_large = sweep_any(s_slots, n_always, o, d, w_far, unused_roots);
-                    w_idx = first_large < n_always ? s_index[first_large] : n;
-#if RT_OPT_WALK == 2
-                    cen[9] += first_large < n_always ? first_large + 1u : n_always;
-#endif
-                    R = bvh_ray(s_hdr, o, d);
-                    cur = root_ref;
-                    sp = 0;
-                    st = kShadow;
+                    else start = 1;
+                } else {
+                    const float4 la = s_lightA[lj], lb = s_lightB[lj];
+                    lj += 1u;
+                    const V3 us = mk(root * cphi, root * sphi, zc);                // .cl:203-213
+                    const V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
+                    V3 sd = sub(on_light, o);
+                    float len;
+                    sd = scale(sd, sqrt_and_rcp(dot(sd, sd), len));
+                    float wo = dot(sd, us);
+                    const float wi = dot(sd, nl);
+                    if (!(wo > 0.f) && wi > 0.f) {                                 // .cl:283-296: this side of the light, facing it
+                        wo = -wo;
+                        // ---- shadow ray, any hit, .cl:234-247: the large spheres at the end of this phase, the tree in the trips to come ----
+                        c_shadow += 1;
+                        l_k = rt_div(lb.w * wi * wo, len * len);                   // .cl:297 (used only if nothing blocks)
+                        d = sd;
+                        W.far = len - RT_EPS;
+                        st = kShadow;
+                        start = 2;
+                    }
                 }
             }
             if (path_done) {
@@ -768,58 +552,83 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 }
                 s += 1;
                 st = kNew;
-                start_closest = false;
+                start = 0;
             }
-            if (st == kNew && !start_closest && s < s_end) {
-                // ---- camera ray, .cl:494-549.  The camera (12 floats) and 1/w, 1/h come from LDS here, once per sample
-                // (broadcast reads), instead of occupying 14 scalar registers through the loop: the loop overfills the scalar
-                // file and its spills go to lanes of a vector register the allocator then lacks ----
-                const float4 c0 = s_cam[0], c1 = s_cam[1], c2 = s_cam[2], c3 = s_cam[3];
-                const float inv_w = c3.z, inv_h = c3.w;
-                const V3 cam_o = mk(c0.x, c0.y, c0.z), cam_d = mk(c0.w, c1.x, c1.y);
-                const V3 cam_x = mk(c1.z, c1.w, c2.x), cam_y = mk(c2.y, c2.z, c2.w);
-                float j1 = next_random_centred(s0, s1);
-                float j2 = next_random_centred(s0, s1);
-                c_draws += 2;
-                float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
-                float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
-                V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
-                           cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
-                o = add(scale(rd, 0.1f), cam_o);
-                d = unit(rd);
-                thr = mk(1.f, 1.f, 1.f);
-                rad = mk(0.f, 0.f, 0.f);
-                depth = 0;
-                after_specular = true;
-                start_closest = true;
+            if (st == kNew && start == 0 && s < s_end) {
+                {
+                    // ---- camera ray, .cl:494-549 (a finished path's next sample; the first sample of the launch); the camera
+                    //      (12 floats) and 1/w, 1/h come from LDS, once per sample ----
+                    const float4 *cam_p = s_cam;
+                    asm volatile("; camera read here, once per sample" : "+v"(cam_p));       // (not hoisted out of the loop into registers that are then spilled)
+                    const float4 c0 = cam_p[0], c1 = cam_p[1], c2 = cam_p[2], c3 = cam_p[3];
+                    const float inv_w = c3.z, inv_h = c3.w;
+                    const V3 cam_o = mk(c0.x, c0.y, c0.z), cam_d = mk(c0.w, c1.x, c1.y);
+                    const V3 cam_x = mk(c1.z, c1.w, c2.x), cam_y = mk(c2.y, c2.z, c2.w);
+                    float j1 = next_random_centred(s0, s1);
+                    float j2 = next_random_centred(s0, s1);
+                    c_draws += 2;
+                    float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
+                    float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
+                    V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
+                               cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
+                    o = add(scale(rd, 0.1f), cam_o);
+                    d = unit(rd);
+                    thr = mk(1.f, 1.f, 1.f);
+                    rad = mk(0.f, 0.f, 0.f);
+                    depth = 0;
+                    after_specular = true;
+                    start = 1;
+                }
             }
-            if (start_closest) {
-                // ---- closest hit, .cl:215-232: the large spheres now, the tree in the trips to come ----
-                float t = 1e20f;
-                uint32_t slot = 0;
-                sweep_closest(s_slots, n_always, o, d, t, slot, unused_roots);
+            if (start != 0) {
+                // ---- a new ray, closest hit (.cl:215-232) or shadow (.cl:234-247): the large spheres now, in scene order, the
+                //      tree in the trips to come.  A shadow ray keeps the first of them that blocks, a closest-hit ray the nearest ----
+                const bool shadow = start == 2;
+                float t = shadow ? W.far : 1e20f;
+                uint32_t slot = 0, first = n_always;
+                for (uint32_t i = 0; i < n_always; ++i) {
+                    const HitPre p0 = hit_pre(s_slots[i], o, d);
+                    if (wave_any_nonneg(p0.det)) {
+                        const HitRoots h0 = hit_roots(p0);
+                        const bool nearer = h0.hit & (h0.t < t);
+                        first = (shadow & nearer & (first == n_always)) ? i : first;
+                        const bool take = nearer & !shadow;
+                        t = take ? h0.t : t;
+                        slot = take ? i : slot;
+                    }
+                }
 #if RT_OPT_WALK == 2
-                cen[9] += n_always;
+                cen[9] += shadow ? (first < n_always ? first + 1u : n_always) : n_always;
 #endif
-                w_far = t;
-                w_slot = slot;
-                w_idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;       // (the always-list winner's index is read if it stays the winner)
+                if (shadow) {
+                    W.idx = first < n_always ? s_index[first] : n;
+                } else {
+                    W.far = t;
+                    W.slot = slot;
+                    W.idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;           // (the always-list winner's index is read if it stays the winner)
+                    st = kClosest;
+                }
                 R = bvh_ray(s_hdr, o, d);
-                cur = root_ref;
-                sp = 0;
-                st = kClosest;
+                W.cur = root_ref;
+                W.sp = 0;
             }
         }
 #if RT_OPT_WALK == 2
-        RT_WALK_CLOCK(7, t_s);
+        RT_WALK_CLOCK(cen, 7, t_s);
 #endif
     }
 #if RT_OPT_WALK == 2
     for (int k = 0; k < 10; ++k) {
-        unsigned long long v = cen[k];
+        unsigned long long v = cen[k], h = hist[k];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) atomicAdd(&P.counters[20 + k], v);
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_xor(v, off, 64);
+            h += __shfl_xor(h, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&P.counters[20 + k], v);
+            atomicAdd(&P.counters[8 + k], h);
+        }
     }
 #endif
 
@@ -857,7 +666,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);
     uint32_t t_draws = wave_sum(c_draws);
-    unsigned long long tests64 = c_tests + (unsigned long long)c_closest * n;
+    unsigned long long tests64 = (unsigned long long)c_tests + (unsigned long long)c_closest * n;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
     if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wave_t0[wave]));
@@ -872,7 +681,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
-#endif   // RT_OPT_WALK < 3
 
 #if RT_OPT_WALK == 1 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
 // Diagnostics (rt_debug_walk_rays): arbitrary rays through the walk AND through the plain sweep over the full table,
@@ -921,8 +729,7 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
             const uint32_t first_large = sweep_any(s_slots, n_always, o, d, ra.w, roots);
             w_idx = first_large < n_always ? g_index[first_large] : n;
             w_far = ra.w;
-            walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, true, 0x7fffffff, 3, cur, sp, w_far, w_idx,
-                       w_slot, nullptr);
+            walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, true, 3, cur, sp, w_far, w_idx, w_slot, nullptr, nullptr);
             const uint32_t ref = sweep_any(P.scene.geom, n, o, d, ra.w, roots);
             res = make_uint4(w_idx, 0u, ref, 0u);
         } else {
@@ -932,8 +739,7 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
             w_far = t;
             w_slot = slot;
             w_idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;
-            walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, false, 0x7fffffff, 3, cur, sp, w_far, w_idx,
-                       w_slot, nullptr);
+            walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, false, 3, cur, sp, w_far, w_idx, w_slot, nullptr, nullptr);
             if (w_idx == kWalkIndexOpen) w_idx = g_index[w_slot];
             float t_ref = 1e20f;
             uint32_t id_ref = 0;

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Census of the hierarchy walk: what the wavefronts of one frame execute, step by step.
 
-    python tools/walk_census.py [c3,c256,...] [census instance, default rt_trace_parity_pairs2_census]
+    python tools/walk_census.py [c3,c256,...]
 
 Per configuration one JSON line: wave-level pair / leaf steps and shade phases, lanes taking part in each, loop trips,
-the clock shares of walk and shading, and (second form only) how many lanes the leaf and pair steps run with."""
+the clock shares of walk and shading, and how many lanes the leaf and pair steps run with."""
 import json
 import os
 import sys
@@ -17,7 +17,7 @@ from ab_bench import CONFIGS  # noqa: E402
 import bvh_check  # noqa: E402
 
 names = (sys.argv[1] if len(sys.argv) > 1 else "c3").split(",")
-inst = sys.argv[2] if len(sys.argv) > 2 else "rt_trace_parity_pairs2_census"
+inst = sys.argv[2] if len(sys.argv) > 2 else "rt_trace_parity_pairs_census"
 product = inst.replace("_census", "")
 lib = api.load_library(diag=True)
 for name in names:
@@ -47,7 +47,5 @@ for name in names:
            "pair_steps_per_ray": round(c[1] / max(st["closest_rays"] + st["shadow_rays"], 1), 2),
            "leaf_steps_per_ray": round(c[3] / max(st["closest_rays"] + st["shadow_rays"], 1), 2),
            "clock_share_walk": round(c[6] / max(c[6] + c[7], 1), 3), "always_tests": c[9]}
-    if "pairs2" in inst:
-        rec.update({"leaf_steps_by_lanes_1_8_16_32_64": hs[0:4], "pair_steps_by_lanes_1_8_16_32_64": hs[4:8],
-                    "clock_share_pair_steps": round(hs[8] / max(c[6] + c[7], 1), 3), "clock_share_leaf_steps": round(hs[9] / max(c[6] + c[7], 1), 3)})
+    rec.update({"leaf_steps_by_lanes_1_8_16_32_64": hs[0:4], "pair_steps_by_lanes_1_8_16_32_64": hs[4:8]})
     print(json.dumps(rec), flush=True)

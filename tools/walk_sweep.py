@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The hierarchy walk's trip budget and shading gate (rt_debug_set_walk) with the deal of pixels by cost warm:
-python tools/walk_sweep.py [c3|c256|...] -- frame time, min of 4, frames compared with the first setting's."""
+"""The hierarchy walk's shading gate and pair steps in a row (rt_debug_set_walk, rt_debug_set_walk_round) with the deal of pixels
+by cost warm:  python tools/walk_sweep.py [c3|c256|...] -- frame time, min of 4, frames compared with the first setting's."""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,8 +13,9 @@ sph, orig, target = maker()
 cam = host.compute_camera(orig, target, w, h)
 lib = api.load_library(diag=True)
 base = None
-grid = [(64, 16, 3), (64, 32, 3), (64, 48, 3), (24, 16, 3), (24, 32, 3), (16, 16, 3), (16, 32, 3), (12, 24, 3), (8, 16, 3), (8, 32, 3), (64, 16, 2), (64, 16, 4), (64, 16, 6), (64, 8, 3)]
-for steps, gate, rnd in grid:
+grid = [(16, 3), (8, 3), (24, 3), (32, 3), (48, 3), (16, 2), (16, 4), (16, 6), (32, 4), (8, 2)]
+for gate, rnd in grid:
+    steps = 0
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(lib.rt_debug_set_walk(ctx._h, steps, gate, 1))
         ctx._check(lib.rt_debug_set_walk_round(ctx._h, rnd))
@@ -28,4 +29,4 @@ for steps, gate, rnd in grid:
                 best = ms if best is None else min(best, ms)
         if base is None:
             base = px
-        print(json.dumps({"config": name, "steps": steps, "gate": gate, "round": rnd, "ms": round(best, 3), "same_frame": bool(np.array_equal(px, base))}), flush=True)
+        print(json.dumps({"config": name, "gate": gate, "round": rnd, "ms": round(best, 3), "same_frame": bool(np.array_equal(px, base))}), flush=True)
