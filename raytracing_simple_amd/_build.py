@@ -32,6 +32,9 @@ UNITS = [
     ("rt_kernel_parity.hip", ["-ffp-contract=off"]),
     ("rt_kernel_fast.hip", ["-ffp-contract=fast"]),
     ("rt_api.hip", ["-ffp-contract=off"]),
+    ("rt_launch.hip", ["-ffp-contract=off"]),
+    ("rt_scene.hip", ["-ffp-contract=off"]),
+    ("rt_debug.hip", ["-ffp-contract=off"]),
     ("rt_multi.hip", ["-ffp-contract=off"]),
     ("rt_bvh.hip", ["-ffp-contract=off"]),
     ("rt_host.cpp", ["-ffp-contract=off"]),

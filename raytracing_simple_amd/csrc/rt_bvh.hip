@@ -436,7 +436,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
 // leaves are made only where they pay); 8 spheres or fewer are a leaf.  Leaves are numbered in the order the recursion emits
 // them, every subtree holds a contiguous range of them, and the pair of a node sits at (first leaf of its right child) - 1 --
 // the numbering of the fixed shape, which never depended on where the split lies.  The root's pair goes out through
-// BvhTables::root since it is no longer n_leaves / 2 - 1.  Against the fixed shape, on C3's rays (tools/sim_tree_shape.cpp): pair
+// BvhTables::root since it is no longer n_leaves / 2 - 1.  Against the fixed shape, on C3's rays (a host model, profiles/r03y_tree_shape_model.txt): pair
 // steps per ray -15 % (shadow rays -28 %), leaf visits -7 %.  Returns RT_OK with *built = false when the result does not fit
 // the tables' allocation or the stack budget (the caller then takes the fixed shape).
 constexpr uint32_t kSahMaxTree = 4096;          // the build stays a few milliseconds (rt_set_scene with it: 1.2 ms for 1024 spheres, 5.9 for 4096,

@@ -112,7 +112,7 @@ struct LaunchParams {
     uint16_t *pixel_cost;   // per local pixel (lrow * w + x): loop trips this launch spent on it, saturated -- one per closest-hit ray in the sweep
                             // kernels, one per ray (closest-hit or shadow) in the hierarchy walk --, or null
     // diagnostics build only (null in the product library): launch sequence number and the buffers the
-    // instrumented instance logs device wall-clock intervals into (tools/gather_stress.py, tools/wave_timeline.py)
+    // instrumented instance logs device wall-clock intervals into (tools/gather_stress.py)
     unsigned long long *timelog;   // [seq][8]: min start, max end of the launch (s_memrealtime, 100 MHz), kind, tag, ...
     unsigned long long tl_tag;
     unsigned long long *wavelog;   // [workgroup*4 + wave][3]: start, end, xcc_id << 32 | HW_ID

@@ -48,7 +48,8 @@ struct rt_ctx {
     int bvh_min = 56;                   // scenes with at least this many spheres inside the tree use it (0 = never)
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
-    int walk_gate = 16, walk_round = 3; // rt_walk.inc.h: ready lanes that make the wavefront shade; pair steps in a row before a leaf step
+    int walk_gate = 16, walk_round = 4; // rt_walk.inc.h: ready lanes that make the wavefront shade; pair steps in a row before a leaf step
+                                        // (round 4, this kernel: 2 / 3 / 4 / 6 in a row = 5.42 / 5.37 / 5.22 / 5.45 ms on C3, profiles/r04k_walk_sweep.jsonl)
     int walk_forced = 0;                // 0 = measured choice (below); diagnostics: 1 = the hierarchy whenever the scene has one
     // hierarchy or plain sweep?  Decided per scene by measurement (rt_api.hip launch()): each form once warm and once
     // timed between events, in the same tile order; whichever took less time per pass renders the rest
@@ -82,7 +83,7 @@ struct rt_ctx {
     int order_homes = 1;                // heavy-first order: the tiles of a region go to workgroup numbers equal modulo this (8 = one XCD per region:
                                         // a fifth less traffic, 1 % more time -- measured, not the default); 1 = plain order
     int deal_group = 8;                 // horizontally adjacent pixels that stay together (a run on adjacent lanes: coalesced loads and stores).
-                                        // Chosen on passes the costs have NOT seen (tools/deal_progressive.py, tools/ab_bench.py --unseen): single
+                                        // Chosen on passes the costs have NOT seen (profiles/r03u_deal_on_unseen_passes.jsonl, tools/ab_bench.py --unseen): single
                                         // pixels win only when the very frame the costs were measured on is rendered again; runs of 4 and 8 are
                                         // level there, and runs of 8 keep the launch's traffic at 1.16 x what it produces (runs of 4: 1.48 x)
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
@@ -141,6 +142,28 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
             return rt::fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                             __FILE__, __LINE__);                                               \
     } while (0)
+
+// ---- rt_api.hip: the context's device and the order of its work ----
+int select_device(const rt_ctx *c);
+int chain(rt_ctx *c, hipStream_t stream);          // `stream` waits for whatever the context queued last elsewhere (ALL its work runs in issue order)
+int wait_all(rt_ctx *c);                            // host waits for everything the context has queued
+const double *create_breakdown();                   // host ms of the last rt_create by phase (rt_debug_create_breakdown)
+
+// ---- rt_launch.hip: one launch of the render kernel ----
+constexpr size_t kLdsMax = 152 * 1024;              // what the kernels' dynamic-LDS attribute allows
+LaunchParams make_params(rt_ctx *c, int n_samples);
+const Instance *instances(bool fast, int *count);
+bool tables_fit_lds(const rt_ctx *c, int n_samples);
+void probe_poll(rt_ctx *c, bool wait);              // hierarchy against sweep: the measurement's verdict, if its events have completed
+void rearm_probe(rt_ctx *c);                        // a new scene: undecided again
+void rearm_probe_if_changed(rt_ctx *c);             // after a device-resident update rebuilt the hierarchy
+double estimate_ratio(const rt_ctx *c);             // predicted walk / sweep time per ray from the uploaded tree's surface areas
+int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false);
+
+// ---- rt_scene.hip: records, tables, staging ----
+void free_scene(rt_ctx *c);
+int ensure_scene_capacity(rt_ctx *c, uint32_t count);
+int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *spheres, uint32_t n_total, hipStream_t stream, bool full_upload);
 
 // the hierarchy of large scenes (rt_bvh.hip): per-device set-up of the build kernel; build on `stream` for the scene the
 // context's host mirror holds (sets c->bvh / c->bvh_ok; nothing is read back)

@@ -1,0 +1,526 @@
+// rt_launch.hip -- what one launch of the render kernel is made of: which kernel instance (rt_device.h Instance: arithmetic mode x
+// role x workgroup shape), its tables and LDS, the scheduling data it runs with (heavy-first tile order, pixels dealt to
+// wavefronts by cost) and, for scenes that have a hierarchy, whether it is walked or the plain sweep runs -- settled by a
+// surface-area estimate at rt_set_scene, by measurement inside the estimate's band.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "rt_internal.h"
+
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
+#endif
+
+using rt::fail;
+
+// Heavy-first order of the tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a counting sort over
+// 1024 cost classes (largest first; the order inside a class does not matter).
+// With n_home > 1 (rt_debug_set_tile_order; NOT the default: it saves a fifth of the launch's traffic and costs 1 % of its time)
+// the order also keeps the tiles of a REGION (region_tx x region_ty tiles: the 32 x 32 pixels whose lanes the
+// deal by cost mixes) on one XCD: workgroups are dealt to the 8 XCDs round-robin (block b and b + 8 share one: observed, not
+// promised -- only traffic depends on it), so every region gets a home ((column + 3 x row) mod n_home), each home's tiles are sorted
+// heavy first on their own, and position n_home * k + h takes the k-th tile of home h.  The wavefronts of a region then store
+// their scattered pixels, colours and seeds through ONE L2, where the partial lines meet before they leave, and read the
+// region's seeds and deal from it.  (Homes hold equally many tiles up to a region or two; the tiles beyond the shortest
+// list's length -- the cheapest ones -- follow at the end.)
+__global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t grid_x,
+                                                             uint32_t region_tx, uint32_t region_ty, uint32_t n_home) {
+    constexpr unsigned kMaxHome = 8;
+    __shared__ unsigned s_max;
+    __shared__ unsigned s_hist[kMaxHome][1024];
+    __shared__ unsigned s_len[kMaxHome], s_tail[kMaxHome], s_min;
+    const unsigned tid = threadIdx.x;
+    constexpr unsigned kCap = 0x1FFFFFu;            // 21 ms of ticks: cost * 1023 stays inside 32 bits
+    if (n_home < 1u || n_home > kMaxHome) n_home = 1u;
+    auto home_of = [&](uint32_t i) -> unsigned {
+        if (n_home == 1u) return 0u;
+        const uint32_t ty = i / grid_x, tx = i - ty * grid_x;
+        return (tx / region_tx + 3u * (ty / region_ty)) % n_home;       // (neighbours across AND down get different homes: a tall or a wide expensive object is spread over all of them)
+    };
+    auto key_of = [&](uint32_t i) -> unsigned { return cost[i] < kCap ? cost[i] : kCap; };
+    if (tid == 0) s_max = 1u;
+    for (unsigned h = 0; h < kMaxHome; ++h) s_hist[h][tid] = 0u;
+    __syncthreads();
+    unsigned m = 0;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned c_ = key_of(i);
+        m = c_ > m ? c_ : m;
+    }
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const unsigned top = s_max;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned c_ = key_of(i);
+        atomicAdd(&s_hist[home_of(i)][1023u - c_ * 1023u / top], 1u);
+    }
+    __syncthreads();
+    if (tid < kMaxHome) {               // exclusive prefix over the classes of one home, most expensive class first
+        unsigned run = 0;
+        for (int k = 0; k < 1024; ++k) {
+            const unsigned c_ = s_hist[tid][k];
+            s_hist[tid][k] = run;
+            run += c_;
+        }
+        s_len[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned lo = 0xffffffffu;
+        for (unsigned h = 0; h < n_home; ++h) lo = s_len[h] < lo ? s_len[h] : lo;
+        s_min = lo;
+        unsigned run = lo * n_home;
+        for (unsigned h = 0; h < n_home; ++h) {
+            s_tail[h] = run;
+            run += s_len[h] - lo;
+        }
+    }
+    __syncthreads();
+    const unsigned shortest = s_min;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const unsigned c_ = key_of(i);
+        const unsigned h = home_of(i);
+        const unsigned k = atomicAdd(&s_hist[h][1023u - c_ * 1023u / top], 1u);
+        order[k < shortest ? k * n_home + h : s_tail[h] + (k - shortest)] = i;
+    }
+}
+
+// The deal of a region's pixels to its wavefronts (rt_device.h LaunchParams::deal): ONE workgroup per region of 32 x deal_rows
+// pixels sorts them by the cost the last launch left for them (rays traced; descending, ties by position) -- a bitonic sort
+// in LDS -- and writes their positions (dy * 32 + dx) in that order.  What is sorted are runs of `group` horizontally adjacent
+// pixels (1, 2, 4 or 8; key = the run's summed cost; 8 by default): a run stays on adjacent lanes, so the launch's loads and
+// stores of seeds, colours and pixels still come in segments of 8 * group .. 12 * group bytes instead of single words (with
+// single pixels the launch wrote 3.5 times the bytes it produces).  What the previous launch cost predicts the next launch only
+// as far as a pixel's EXPECTED cost goes -- single pixels sorted by the realised cost are an exact fit for the same frame rendered
+// again (same random numbers) and a slight loss on new passes; runs of 4 and 8 gain on both (profiles/r03u_deal_on_unseen_passes.jsonl).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
+// (its workgroups do not all exist: ranks must not move out of their square).
+__global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *__restrict__ cost, uint16_t *__restrict__ deal, int w, int rows,
+                                                              int regions_x, int deal_rows, int group) {
+    __shared__ uint32_t s_key[rt::kRegionW * rt::kMaxDealRows];
+    const int tid = threadIdx.x, nt = blockDim.x, n = rt::kRegionW * deal_rows;       // n pixels: a power of two
+    const int ng = n / group;                                                          // runs: a power of two as well
+    const int region = blockIdx.x, ry = region / regions_x, rx = region - ry * regions_x;
+    const int x0 = rx * rt::kRegionW, y0 = ry * deal_rows;
+    const bool whole = (x0 + rt::kRegionW <= w) && (y0 + deal_rows <= rows);
+    if (!whole) {
+        // identity: rank (band b, wavefront q, lane l) -> the pixel (q * 8 + (l & 7), b * 8 + (l >> 3)) of the wavefront's own square
+        for (int r = tid; r < n; r += nt) {
+            const int b = r >> 8, q = (r >> 6) & 3, l = r & 63;
+            deal[(size_t)region * n + r] = (uint16_t)(((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7)));
+        }
+        return;
+    }
+    for (int i = tid; i < ng; i += nt) {
+        const int p0 = i * group, dx = p0 & 31, dy = p0 >> 5;                          // (a run never crosses a row: 32 % group == 0)
+        uint32_t c_ = 0;
+        for (int j = 0; j < group; ++j) c_ += cost[(size_t)(y0 + dy) * (size_t)w + (size_t)(x0 + dx + j)];
+        s_key[i] = (c_ << 12) | (uint32_t)(4095 - i);       // descending sort of the key = heaviest run first, then lowest position
+    }
+    __syncthreads();
+    for (int k = 2; k <= ng; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < ng; i += nt) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = s_key[i], b = s_key[l];
+                    if ((a < b) == ((i & k) == 0)) { s_key[i] = b; s_key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < ng; i += nt) {
+        const uint32_t p0 = (4095u - (s_key[i] & 4095u)) * (uint32_t)group;
+        for (int j = 0; j < group; ++j) deal[(size_t)region * n + (size_t)i * group + j] = (uint16_t)(p0 + (uint32_t)j);
+    }
+}
+
+namespace rt {
+
+rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
+    rt::LaunchParams p{};
+    p.scene = c->scene;
+    p.cam = c->cam;
+    p.seeds = c->d_seeds;
+    p.seeds_in = c->seeds_default ? c->d_seeds0 : c->d_seeds;
+    p.colors = c->d_colors;
+    p.pixels = c->d_pixels_ext ? c->d_pixels_ext : c->d_pixels;
+    p.counters = c->d_counters;
+    p.stats = c->d_stats;
+    p.w = c->w;
+    p.h = c->h;
+    p.first_sample = c->current_sample;
+    p.n_samples = n_samples;
+    p.rank = c->rank;
+    p.nranks = c->nranks;
+    p.tile_rows = c->tile_rows;
+    p.local_rows = c->local_rows;
+    p.skip_pixels = c->pixel_write ? 0 : 1;
+    p.inv_w = 1.f / (float)c->w;          // correctly rounded on the host as on the device (-ffp-contract=off, IEEE division)
+    p.inv_h = 1.f / (float)c->h;
+    p.regen_gate = c->regen_gate > 0 ? c->regen_gate : (c->scene.n_spheres <= 512 ? 8 : 1);
+    p.coop_kmax = c->coop_kmax;
+    p.tiles_x = (c->w + 7) / 8;
+    p.n_tiles = p.tiles_x * ((c->local_rows + 7) / 8);
+    return p;
+}
+
+
+// ---- which instance, and what it needs (rt_device.h Instance; the rows live next to the instantiations) ----
+
+const rt::Instance *instances(bool fast, int *count) { return fast ? rt::fast_instances(count) : rt::parity_instances(count); }
+
+// the row with this role and workgroup shape (null: this library has none)
+static const rt::Instance *find_role(bool fast, int role, int waves) {
+    int n = 0;
+    const rt::Instance *t = instances(fast, &n);
+    for (int k = 0; k < n; ++k)
+        if (t[k].role == role && t[k].waves == waves) return &t[k];
+    return nullptr;
+}
+
+// LDS the hierarchy's staged tables take for this scene
+static size_t pairs_lds(const rt_ctx *c, bool mat, int n_samples) {
+    return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
+}
+
+// the plain sweep's tables (geometry and lights) fit LDS for this launch
+bool tables_fit_lds(const rt_ctx *c, int n_samples) {
+    return rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, false, n_samples) <= kLdsMax;
+}
+
+// the hierarchy's tables fit the LDS budget given to them; otherwise the walk reads them from HBM / L2
+static bool bvh_fits_lds(const rt_ctx *c, int n_samples) { return pairs_lds(c, false, n_samples) <= (size_t)c->bvh_lds_limit; }
+
+// the scene has a hierarchy and the context may use it
+static bool bvh_usable(const rt_ctx *c) { return c->bvh_ok && c->wg_waves != 1 && c->persist == 0; }
+
+// What the instance needs from the context, checked against what the context has: the ONE place that sizes the
+// dynamic LDS and hands out the hierarchy.  An instance whose tables the context lacks is refused (RT_ERR_STATE),
+// whatever route selected it -- the measured choice, a forced form, or a diagnostics mode.
+static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::LaunchParams &p, size_t *lds_out) {
+    const bool needs_bvh = inst.tables == rt::kTabPairsLds || inst.tables == rt::kTabPairsGlobal;
+    p.bvh = rt::BvhTables{};
+    if (needs_bvh) {
+        if (!c->bvh_ok || !c->bvh.blob)
+            return fail(RT_ERR_STATE, "%s walks a hierarchy and the scene has none (fewer than %d small spheres?)", inst.name, c->bvh_min);
+        p.bvh = c->bvh;
+    }
+    size_t lds = 0;
+    switch (inst.tables) {
+        case rt::kTabSweepLds:
+            lds = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
+            break;
+        case rt::kTabSweepGlobal:
+            p.mat_in_lds = 0;
+            lds = rt::lds_bytes(0, 0, false, n_samples);
+            break;
+        case rt::kTabPairsLds:
+            p.mat_in_lds = 0;               // (the walk reads a hit's material by slot from the hierarchy's blob: nothing of it is staged)
+            lds = pairs_lds(c, false, n_samples);
+            break;
+        case rt::kTabPairsGlobal:
+            p.mat_in_lds = 0;
+            lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256);
+            break;
+        default:
+            return fail(RT_ERR_STATE, "%s: unknown table kind %d", inst.name, inst.tables);
+    }
+    if (lds > kLdsMax) return fail(RT_ERR_ARG, "%s needs %zu B of LDS for this scene (limit %zu)", inst.name, lds, kLdsMax);
+    *lds_out = lds;
+    return RT_OK;
+}
+
+// `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one), 2 = the plain sweep
+static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool natural_order = false) {
+    if (!c->have_scene || !c->have_cam)
+        return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
+    if (n_samples < 0) return fail(RT_ERR_ARG, "n_samples < 0");
+    if (n_samples > 0x7fffffff - c->current_sample)
+        return fail(RT_ERR_ARG, "pass counter would overflow (%d + %d)", c->current_sample, n_samples);
+    if (n_samples == 0 || c->local_rows == 0) return RT_OK;
+    int rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+
+    rt::LaunchParams p = make_params(c, n_samples);
+    const size_t lds_all = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, true, n_samples);
+    // materials ride along in LDS only while that keeps at least 6 workgroups per CU resident
+    // (160 KiB / 24 KiB); larger scenes read them from L2 once per hit
+    p.mat_in_lds = lds_all <= (size_t)c->mat_lds_limit;
+    const size_t lds_sweep = rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, p.mat_in_lds != 0, n_samples);
+
+    // which instance: arithmetic mode x role x workgroup shape.  Single-wavefront workgroups (8x8 tiles) keep the wave
+    // slots of a CU full (a 4-wavefront workgroup waits for four free slots at once) and give the heavy-first order a
+    // finer granule; each stages its own copy of the tables, so only while 24 copies fit a CU.
+    bool fast = c->mode == RT_MODE_FAST;
+    const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+    const bool w1 = c->wg_waves == 1 || (c->wg_waves == 0 && lds_sweep + (coop ? 1536u : 256u) <= 6 * 1024);   // + the instance's static LDS
+    int role = coop ? rt::kRoleCoop : rt::kRolePlain, waves = w1 ? 1 : 4;
+    if (form != 2 && bvh_usable(c)) {
+        // large scenes: the walk over the hierarchy, from LDS while its tables leave room for five workgroups per CU
+        role = bvh_fits_lds(c, n_samples) ? rt::kRolePairs : rt::kRolePairsGlobal;
+        waves = 4;
+        if (c->regen_gate <= 0) p.regen_gate = c->walk_gate;
+    } else if (!tables_fit_lds(c, n_samples)) {
+        // no hierarchy (or it lost the measurement) and a table beyond LDS: the plain sweep over the table in HBM / L2
+        role = rt::kRoleSweepGlobal;
+        waves = 4;
+    }
+    p.walk_round = c->walk_round;
+    const rt::Instance *inst = nullptr;
+#if RT_DIAGNOSTICS
+    if (c->persist != 0 && c->mode < 100) {
+        role = coop ? rt::kRolePersistCoop : rt::kRolePersist;
+        waves = 4;
+    } else if (c->mode >= 100) {           // a row of the table by number (rt_set_mode checked the range)
+        fast = c->mode >= 200;
+        int n = 0;
+        const rt::Instance *t = instances(fast, &n);
+        inst = &t[c->mode - (fast ? 200 : 100)];
+    }
+#endif
+    if (!inst) inst = find_role(fast, role, waves);
+    if (!inst) return fail(RT_ERR_STATE, "this library holds no %s instance of role %d with %d wavefronts per workgroup", fast ? "fast" : "parity", role, waves);
+    size_t lds_use = 0;
+    rc = bind_tables(c, *inst, n_samples, p, &lds_use);
+    if (rc != RT_OK) return rc;
+    const bool persist = (inst->flags & rt::kInstPersistent) != 0;
+
+    const int tile_w = 8 * inst->waves;
+    dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
+    // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
+    // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)
+    const uint32_t n_tiles = grid.x * grid.y;
+    const bool instance_logs_cost = (inst->flags & rt::kInstNoTileCost) == 0;
+    if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
+        // pixels dealt to wavefronts by cost: every launch leaves the rays it traced per pixel; once a long launch has,
+        // the 256 pixels of each 32x8 region are sorted by them (on the device, once per scene and camera) and later
+        // launches hand rank r of a region to wavefront r / 64, lane r % 64.  The tile costs measured under the old
+        // deal no longer describe the workgroups: the heavy-first order is sorted again from the next launch's.
+        if (c->use_deal && c->d_pixel_cost && !persist) {
+            // only launches of 8 passes and more leave per-pixel costs (fewer are mostly noise, and the pricing launches and the
+            // adapter's small batches would overwrite a good plane with them); the unit is the form's own -- loop trips of the
+            // sweep kernels, rays of the walk -- so costs written by the other form are not sorted from
+            const int form_now = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal) ? 1 : 2;
+            if (c->pixel_cost_valid && c->pixel_cost_form != form_now) c->pixel_cost_valid = false;
+            if (n_samples >= 8) p.pixel_cost = c->d_pixel_cost;
+            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 4 && !natural_order) {
+                const int regions_x = (c->w + rt::kRegionW - 1) / rt::kRegionW, regions_y = (c->local_rows + c->deal_rows - 1) / c->deal_rows;
+                hipLaunchKernelGGL(rt_order_pixels_kernel, dim3((unsigned)(regions_x * regions_y)), dim3((unsigned)std::min(rt::kRegionW * c->deal_rows, 1024)), 0, stream,
+                                   c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows, c->deal_group);
+                HIP_TRY(hipGetLastError());
+                c->deal_valid = true;
+                c->cost_valid = c->order_valid = false;
+            }
+            if (c->deal_valid) {
+                p.deal = c->d_deal;
+                p.deal_rows = c->deal_rows;
+            }
+        }
+        if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
+        p.tile_cost = c->d_tile_cost;
+        if (c->cost_valid && !c->order_valid && n_samples >= 8 && !natural_order) {
+            // (a region: 32 pixels across = 4 single-wavefront tiles or one 4-wavefront tile; the deal's rows down)
+            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles, grid.x,
+                               inst->waves == 1 ? 4u : 1u, (uint32_t)(c->deal_rows / rt::kTileH), (uint32_t)c->order_homes);
+            HIP_TRY(hipGetLastError());
+            c->order_valid = true;
+            c->order_age = 0;
+        }
+        if (c->order_valid && !natural_order) p.order = c->d_order;
+    }
+    if (persist) {
+        // just enough workgroups to fill the machine; the tile queue (counters[30]) does the rest
+        size_t per_cu = lds_use > 0 ? (160 * 1024) / (lds_use + 6 * 1024) : 6;
+        if (per_cu > 6) per_cu = 6;
+        if (per_cu < 1) per_cu = 1;
+        size_t blocks = (size_t)c->n_cus * per_cu;
+        const size_t needed = ((size_t)p.n_tiles + 3) / 4;
+        if (blocks > needed) blocks = needed;
+        grid = dim3((unsigned)blocks, 1, 1);
+        HIP_TRY(hipMemsetAsync(c->d_counters + 30, 0, sizeof(unsigned long long), stream));
+    }
+#if RT_DIAGNOSTICS
+    if (inst->role == rt::kRoleTimelog && c->d_timelog && c->timelog_used < c->timelog_cap) {
+        p.timelog = c->d_timelog;
+        p.seq = c->timelog_used++;
+        p.tl_tag = c->timelog_tag;
+        p.wavelog = ((size_t)grid.x * grid.y * 4 <= c->wavelog_cap) ? c->d_wavelog : nullptr;
+    }
+#endif
+    const hipError_t e = rt::launch_instance(*inst, p, grid, lds_use, stream);
+    if (e != hipSuccess)
+        return fail(RT_ERR_HIP, "kernel launch failed: %s (%s, grid %ux%u, lds %zu B)", hipGetErrorString(e), inst->name, grid.x, grid.y, lds_use);
+    c->current_sample += n_samples;
+    c->launches += 1;
+    c->last_kernel = inst->name;
+    c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal) ? 1 : 2;
+    if (p.tile_cost && n_samples >= 4) {
+        c->cost_valid = true;
+        c->cost_tiles = n_tiles;
+    }
+    if (p.pixel_cost) {
+        c->pixel_cost_valid = true;
+        c->pixel_cost_form = c->last_form;
+    }
+    c->seeds_default = false;           // this launch has written every seed pair the context renders
+    c->pixels_current = c->pixel_write != 0;
+    return RT_OK;
+}
+
+// Hierarchy or plain sweep for this scene?  The walk wins by 5x on a thousand spheres scattered over a plane and
+// loses on a box packed with overlapping glass -- so it is measured, once per scene: four launches in the same
+// (natural) tile order -- the hierarchy warm, the hierarchy timed, the sweep warm, the sweep timed, each timed one
+// between two events -- and when both timings have arrived (asked without blocking) the form that took less time per
+// pass renders the rest.  A blocking call with enough passes splits off 1 + 2 + 1 + 2 passes for the probes and waits
+// for the verdict before it queues the rest (progressive passes equal one launch bit for bit).  The verdict is kept
+// for the scene; device-resident updates keep it until the tree has changed size by a quarter or 256 updates have
+// gone by (rearm_probe_if_changed).  In a multi-device context only the first shard measures; the others follow it.
+constexpr int kProbeSteps = 4;          // hierarchy warm, hierarchy timed, sweep warm, sweep timed
+
+void probe_poll(rt_ctx *c, bool wait) {
+    if (c->bvh_pick != 0 || c->probe_state < kProbeSteps) return;
+    if (wait) {
+        if (hipEventSynchronize(c->probe_ev[3]) != hipSuccess) return;
+    } else if (hipEventQuery(c->probe_ev[3]) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    float a = 0.f, b = 0.f;
+    if (hipEventElapsedTime(&a, c->probe_ev[0], c->probe_ev[1]) != hipSuccess || hipEventElapsedTime(&b, c->probe_ev[2], c->probe_ev[3]) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    const double ta = (double)a / c->probe_samples[0], tb = (double)b / c->probe_samples[1];
+    c->probe_ms[0] = ta;
+    c->probe_ms[1] = tb;
+    c->bvh_pick = ta <= 1.05 * tb ? 1 : 2;      // (a dead band of 5 % towards the usual winner: no flipping on a tie)
+    c->pick_estimated = false;
+    c->probe_tree = c->bvh_n_tree;
+    c->probe_always = c->bvh.n_always;
+    c->probe_updates = 0;
+}
+
+static int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
+    const int k = c->probe_state;               // 0, 1: hierarchy (warm, timed); 2, 3: plain sweep (warm, timed)
+    const bool timed = (k & 1) != 0;
+    const int arm = k >> 1;
+    int rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+    if (timed) HIP_TRY(hipEventRecord(c->probe_ev[2 * arm], stream));
+    rc = launch_form(c, n_samples, stream, arm == 0 ? 1 : 2, true);
+    if (rc != RT_OK) return rc;
+    if (timed) {
+        HIP_TRY(hipEventRecord(c->probe_ev[2 * arm + 1], stream));
+        c->probe_samples[arm] = n_samples;
+    }
+    c->probe_state = k + 1;
+    return RT_OK;
+}
+
+void rearm_probe(rt_ctx *c) {
+    c->bvh_pick = 0;
+    c->pick_estimated = false;
+    c->probe_state = 0;
+    c->probe_ms[0] = c->probe_ms[1] = 0.0;
+    c->probe_updates = 0;
+}
+
+// after a device-resident update rebuilt the hierarchy: is the verdict still about this tree?
+void rearm_probe_if_changed(rt_ctx *c) {
+    if (c->bvh_pick == 0 && c->probe_state == 0) return;
+    if (!c->bvh_ok) {
+        rearm_probe(c);
+        return;
+    }
+    const uint32_t tree = c->bvh_n_tree, always = c->bvh.n_always;        // spheres, not padded slots: the shaped tree of an upload has partial leaves
+    auto moved = [](uint32_t now, uint32_t then) { return 4u * (now > then ? now - then : then - now) > then + 8u; };
+    if (moved(tree, c->probe_tree) || moved(always, c->probe_always) || ++c->probe_updates >= 256) {
+        rearm_probe(c);
+        c->bvh_est_valid = false;               // (the areas were the uploaded tree's: the changed scene is measured)
+    }
+}
+
+// A long launch that would walk its tiles in image order although their costs can be had -- the first frame of a scene or camera,
+// and the frame after it, whose deal of pixels changes what a tile is -- renders 4 of its passes first (they are passes of the
+// frame like any other: progressive launches equal one launch bit for bit), which prices the tiles, and the rest heavy first.
+// A renderer that draws one frame per scene would otherwise never leave image order ("Heavy tiles first").
+constexpr int kPricePasses = 4, kPriceFrom = 24;
+static int launch_priced(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
+    const bool explicit_mode = form == 0;
+    const bool will_deal = c->use_deal && c->pixel_cost_valid && !c->deal_valid;
+    if (!explicit_mode && c->use_order && c->d_tile_cost && n_samples >= kPriceFrom && ((!c->order_valid && !c->cost_valid) || will_deal)) {
+        const int rc = launch_form(c, kPricePasses, stream, form);
+        if (rc != RT_OK) return rc;
+        n_samples -= kPricePasses;
+    }
+    return launch_form(c, n_samples, stream, form);
+}
+
+// The same question answered WITHOUT a launch, from the surface areas of the tree the host built at rt_set_scene (rt_bvh.hip):
+// a random line through the root box is expected to visit  P = sum of area(inner node) / area(root)  pairs (and leaves in
+// proportion), each ray sweeps the always-list besides, and the plain sweep tests all n spheres.  Predicted time per ray of
+// the walk over that of the sweep, in units of one sphere test of the sweep:
+//     ratio = (kEstPair * P + kEstAlways * n_always) / (n + kEstSweepFixed)
+// The three weights are a least-squares fit (log ratio) to the probe's own timings of both forms on 32 scenes of four
+// families -- spheres scattered on a plane, a closed box packed with mirror / glass spheres, a cloud in the air, the Demo
+// scene plus scattered spheres; 64 to 1400 spheres -- tools/choice_calibration.py, profiles/r04k_choice_calibration.jsonl
+// (this round's walk kernel): rms error 11 %, 9 % at worst between 0.55 and 1.8.  (A term for the expected leaf visits fitted to zero: they go with P.)
+// Outside a band around 1 the estimate decides and nothing is measured -- a new scene's first frame then costs what a frame
+// costs; inside it the four probe launches run as before.
+constexpr double kEstPair = 18.7, kEstAlways = 8.9, kEstSweepFixed = 17.9;
+constexpr double kEstBandLo = 0.75, kEstBandHi = 1.33;
+double estimate_ratio(const rt_ctx *c) {
+    return (kEstPair * c->bvh_est_pairs + kEstAlways * (double)c->bvh.n_always) / ((double)c->scene.n_spheres + kEstSweepFixed);
+}
+
+int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
+    const bool measured = c->walk_forced == 0 && c->mode < 100;
+    if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c))
+        return measured ? launch_priced(c, n_samples, stream, 2) : launch_form(c, n_samples, stream, 0);
+    // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
+    // scene measured, open or packed, and one pass of the sweep at 1080p costs 2.6 ms at 1024 spheres,
+    // 28 ms at 4096, 138 ms at 8192, seconds beyond LDS
+    if (c->bvh_n_tree >= 1500u || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
+    if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
+        return launch_priced(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);
+    probe_poll(c, false);
+    if (c->bvh_pick == 0 && c->probe_state == 0 && c->use_estimate && c->bvh_est_valid) {
+        const double r = estimate_ratio(c);
+        c->est_ratio = r;
+        if (r < kEstBandLo || r > kEstBandHi) {
+            c->bvh_pick = r < 1.0 ? 1 : 2;
+            c->pick_estimated = true;
+            c->probe_tree = c->bvh_n_tree;
+            c->probe_always = c->bvh.n_always;
+            c->probe_updates = 0;
+        }
+    }
+    if (c->bvh_pick != 0) return launch_priced(c, n_samples, stream, c->bvh_pick);
+    if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 1);    // probes in flight: the usual winner meanwhile
+    if (may_block && n_samples >= 16) {
+        int done = 0;
+        while (c->probe_state < kProbeSteps) {
+            const int k = (c->probe_state & 1) ? 2 : 1;
+            const int rc = launch_probe(c, k, stream);
+            if (rc != RT_OK) return rc;
+            done += k;
+        }
+        probe_poll(c, true);
+        return launch_priced(c, n_samples - done, stream, c->bvh_pick ? c->bvh_pick : 1);
+    }
+    return launch_probe(c, n_samples, stream);
+}
+
+// a shard's launch on its own stream, for the multi-device context (rt_multi.hip)
+int render_shard(rt_ctx *c, int n_samples, bool may_block) {
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    return launch(c, n_samples, c->stream, may_block);
+}
+
+}  // namespace rt

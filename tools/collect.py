@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""After `gpurun -- bash tools/r03_session.sh P TAG`: summarise gpurun_out/TAG/prof_* into profiles/r03p_* and
-profiles/pmc_traffic.json (what bench.py reads for `roofline.traffic` / `roofline.executed`).  python tools/r03_collect.py TAG"""
+"""After `gpurun -- bash tools/session.sh P TAG`: summarise gpurun_out/TAG/prof_* into profiles/<prefix>_* and profiles/pmc_traffic.json
+(what bench.py reads for `roofline.traffic` / `roofline.executed`, each record stamped with the build id of the library it was
+measured on).   python tools/collect.py TAG PREFIX      e.g.  python tools/collect.py r04p r04p"""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03final"
+tag, prefix = sys.argv[1], sys.argv[2]
 KERNEL = {("c2", "parity"): "rt_trace_parity_w1", ("c2", "fast"): "rt_trace_fast_w1", ("c16", "parity"): "rt_trace_parity_coop_w1",
           ("c3", "parity"): "rt_trace_parity_pairs", ("c5", "parity"): "rt_trace_parity_coop_w1"}
 LABEL = {"c2": "C2: Demo, 1920x1080, 64 spp", "c16": "north-star target: 16 spheres, 1920x1080, 64 spp", "c3": "C3: 1024 spheres, 1920x1080, 16 spp",
@@ -17,6 +18,6 @@ for (wl, mode), kern in KERNEL.items():
         print("missing", src)
         continue
     env = dict(os.environ, RT_PMC_KEY=wl)
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), src, mode, f"r03p_{wl}_{mode}", kern, LABEL[wl]],
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profile.py"), src, mode, f"{prefix}_{wl}_{mode}", kern, LABEL[wl]],
                    env=env, check=True, stdout=subprocess.DEVNULL)
-    print("profiles/r03p_%s_%s.{md,json}" % (wl, mode))
+    print("profiles/%s_%s_%s.{md,json}" % (prefix, wl, mode))

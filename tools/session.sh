@@ -1,11 +1,12 @@
 #!/bin/bash
-# Round-3 measurement session on the GPU box (run through gpurun).  Outputs under gpurun_out/<tag>/; tools/r03_collect.py
-# (run afterwards, in the repository) turns them into profiles/r03*.
-#   A   suite, bench lines (default, fast, the other workloads), in-process A/B tables, native hosts, 2-rank rehearsal
+# A round's measurement session on the GPU box (run through gpurun).  Outputs under gpurun_out/<tag>/; tools/collect.py (run
+# afterwards, in the repository) turns part P into profiles/<round>p_* and profiles/pmc_traffic.json.
+#   A   suite, bench lines (default, fast, the other workloads), in-process A/B table, native hosts, 2-rank rehearsal
 #   P   rocprofv3 --kernel-trace --stats + separate --pmc passes of bench.py for every kernel the bench line names:
 #       C2 (parity, fast), the 16-sphere target, C3, C5
+#   M   the in-library multi-device rehearsal under --kernel-trace (the gather of frame k against the render of frame k + 1)
 set -u
-PART=${1:-A}; TAG=${2:-r03final}; O=gpurun_out/$TAG; mkdir -p $O
+PART=${1:-A}; TAG=${2:-session}; O=gpurun_out/$TAG; mkdir -p $O
 if [ "$PART" = "A" ]; then
     python -m pytest tests -m gpu -q --timeout 900 --maxfail=12 -p no:cacheprovider > $O/pytest.log 2>&1; rc=$?
     tail -3 $O/pytest.log
@@ -15,16 +16,19 @@ if [ "$PART" = "A" ]; then
     for wl in c16 c3 c4 c5; do
         python bench.py --workload $wl --steps 6 --warmup 3 >> $O/bench_other_workloads.jsonl 2>> $O/bench_other.err
     done
-    python tools/ab_bench.py --configs c2,c16,c64,c256,c3,c5,c4 --modes 0,1 --orders 1 --rounds 5 > $O/ab_all_configs.jsonl 2>&1
+    python tools/ab_bench.py --configs c2,c16,c64,c256,c3,c5,c4 --modes 0,1 --rounds 5 > $O/ab_all_configs.jsonl 2>&1
     cut -c1-220 $O/ab_all_configs.jsonl
-    RT_DEALS=0,32 python tools/deal_ab.py c2,c16,c64,c256,c3,c5 5 > $O/ab_pixel_deal.jsonl 2>&1
     raytracing_simple_amd/rt_bench 2 1 0 --w 1920 --h 1080 --spp 64 --oneshot 8 | tee $O/rt_bench_oneshot.json
     raytracing_simple_amd/rt_inflight 1 20 | tee $O/rt_inflight.jsonl; raytracing_simple_amd/rt_inflight 2 20 | tee -a $O/rt_inflight.jsonl
     RT_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_n2_rehearsal.json 2> $O/bench_n2.err; tail -c 300 $O/bench_n2_rehearsal.json
-else
+elif [ "$PART" = "P" ]; then
     for spec in "c2 parity" "c2 fast" "c16 parity" "c3 parity" "c5 parity"; do
         set -- $spec
         bash tools/profile_gpu.sh $TAG/prof_$1_$2 $2 $1 > $O/prof_$1_$2.log 2>&1; tail -1 $O/prof_$1_$2.log
     done
+else
+    export TMPDIR=/tmp; R=$(pwd); cd /tmp
+    timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/$O/multi_trace -- python3 $R/tools/multi_overlap.py > $R/$O/multi_overlap.log 2>&1
+    cd $R; python3 tools/multi_overlap.py --summarise $O/multi_trace | tee $O/multi_overlap.json
 fi
 echo "part $PART done"

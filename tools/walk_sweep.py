@@ -13,7 +13,7 @@ sph, orig, target = maker()
 cam = host.compute_camera(orig, target, w, h)
 lib = api.load_library(diag=True)
 base = None
-grid = [(16, 3), (8, 3), (24, 3), (32, 3), (48, 3), (16, 2), (16, 4), (16, 6), (32, 4), (8, 2)]
+grid = [(16, 4), (16, 3), (16, 5), (24, 4), (32, 4), (48, 4), (32, 5), (8, 4)]
 for gate, rnd in grid:
     steps = 0
     with api.RtContext(w, h, diag=True) as ctx:
