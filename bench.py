@@ -138,11 +138,15 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
                                   "or up to its first blocker): 20 FLOP x rt_stats.sphere_tests"})
     if mode == "parity":        # parity mode may not fuse a multiply with an add: its ceiling is the issue rate at one FLOP per instruction
         out["frac_unfused"] = round(out["achieved"] / FP32_UNFUSED_PEAK_TFLOPS, 5)
-    if choice is not None and choice.get("picked") is not None:
+    if choice is not None and choice.get("picked") is not None and choice["hierarchy_ms_per_pass"] > 0:
         out["measured_choice"] = {"picked": choice["picked"], "hierarchy_ms_per_pass": round(choice["hierarchy_ms_per_pass"], 4),
                                   "sweep_ms_per_pass": round(choice["sweep_ms_per_pass"], 4),
                                   "note": "the library timed each form on this scene, warm, in the same tile order (rt_scene_choice); the sweep is the "
                                           "wave-ballot any-hit instance (rt_trace_*_coop)"}
+    elif choice is not None and choice.get("picked") is not None:
+        out["estimated_choice"] = {"picked": choice["picked"],
+                                   "note": "settled at rt_set_scene from the surface areas of the tree the host built (predicted walk / sweep time per ray outside "
+                                           "0.75 .. 1.33): nothing was measured, the scene's first frame cost what a frame costs (first_frame)"}
     out["hbm"] = {"algorithmic_bytes_per_launch": alg_bytes, "achieved": round(alg_bytes / sec / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 6)}
     pm = pmc_record(workload, mode)
@@ -585,8 +589,9 @@ def main():
                 for _ in range(2):
                     m1.reset_async(); m1.render_pass(SPP, copy=False)
                 t0 = time.perf_counter()
-                for _ in range(8):
-                    m1.reset_async(); m1.render_pass(SPP, copy=False)
+                for _ in range(8):                   # queued like the headline's frames (one stream: frame k + 1 starts when frame k is complete)
+                    m1.reset_async(); m1.render_async(SPP)
+                m1.throttle(0)
                 dt = time.perf_counter() - t0
                 in_library = {"path": "rt_create_multi(ngpus=1): one shard rendering straight into the frame (no communicator, no gather, no de-interleave), blocking rt_render_pass",
                               "ms_per_frame": round(dt / 8 * 1e3, 4), "frame_equals_headline": bool(np.array_equal(m1.read_pixels(), last_pixels))}

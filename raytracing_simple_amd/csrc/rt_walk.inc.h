@@ -116,7 +116,6 @@ RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
 // branch; `both` only moves the stack pointer: the entry above the top is dead).
 // cen (census instance only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps; hist: steps by lanes.
 constexpr uint32_t kWalkDone = 0xffffffffu;
-constexpr uint32_t kWalkIndexOpen = 0xfffffffeu;        // closest-hit walks: the best slot's scene index has not been read
 RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
                        uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist) {
@@ -164,7 +163,13 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                 cen[3] += 1ull;
             }
             const uint32_t sl = n_always + (uint32_t)kBvhLeaf * (cur & (kBvhLeafRef - 1u));
-            uint32_t blockers = 0u;
+            // One mask of the leaf's spheres whose scene index will be needed -- the index lies in HBM / L2 and is read after the
+            // eight tests, one wait for all.  Shadow ray (.cl:234-247): the spheres that block; the lowest index among them is
+            // the answer.  Closest hit (.cl:215-232: strictly nearer wins, scene order breaks ties, i.e. the lexicographic
+            // minimum over (distance, scene index)): the spheres at exactly the best distance so far -- a strictly nearer hit
+            // takes the slot and clears the mask, so what is left at the end ties with the final best (the .scn loader doubles
+            // spheres: such ties are real, and rare).
+            uint32_t need = 0u;
 #pragma unroll
             for (int half = 0; half < kBvhLeaf; half += 4) {
                 HitPre p[4];
@@ -175,34 +180,29 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                     const int k = half + k4;
                     if (wave_any_nonneg(p[k4].det)) {
                         const HitRoots hr = hit_roots(p[k4]);
-                        const bool nearer = hr.hit & (hr.t < w_far);
-                        blockers |= (shadow & nearer) ? (1u << k) : 0u;        // shadow ray (.cl:234-247): a blocker; its index is read below
-                        // closest hit (.cl:215-232): a smaller distance, or the same from a lower scene index.  The scene index of a
-                        // slot lies in HBM / L2: a strictly nearer hit just takes the slot (kWalkIndexOpen); only an exact tie reads both
-                        const bool tie = !shadow & hr.hit & (hr.t == w_far);
-                        if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
-                            if (tie) {
-                                const uint32_t ix = index[sl + (uint32_t)k];
-                                const uint32_t have = w_idx == kWalkIndexOpen ? index[w_slot] : w_idx;
-                                w_idx = have;
-                                if (ix < have) {
-                                    w_slot = sl + (uint32_t)k;
-                                    w_idx = ix;
-                                }
-                            }
-                        }
+                        const bool nearer = hr.hit & (hr.t < w_far), level = hr.hit & (hr.t == w_far);
                         const bool take = nearer & !shadow;
+                        need = take ? 0u : need;
+                        need |= (shadow ? nearer : level) ? (1u << k) : 0u;
                         w_far = take ? hr.t : w_far;
                         w_slot = take ? sl + (uint32_t)k : w_slot;
-                        w_idx = take ? kWalkIndexOpen : w_idx;
                     }
                 }
             }
-            while (blockers != 0u) {                                    // the lowest scene index that blocks is the answer (and prunes the rest of the walk)
-                const uint32_t k = (uint32_t)__builtin_ctz(blockers);
-                blockers &= blockers - 1u;
-                const uint32_t ix = index[sl + k];
-                w_idx = ix < w_idx ? ix : w_idx;
+            if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {
+                if (need != 0u) {
+                    uint32_t best = shadow ? w_idx : index[w_slot];
+                    do {
+                        const uint32_t k = (uint32_t)__builtin_ctz(need);
+                        need &= need - 1u;
+                        const uint32_t ix = index[sl + k];
+                        if (ix < best) {
+                            best = ix;
+                            w_slot = shadow ? w_slot : sl + k;
+                        }
+                    } while (need != 0u);
+                    w_idx = shadow ? best : w_idx;
+                }
             }
             sp -= 1;
             cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
@@ -215,13 +215,29 @@ struct Walk {             // a ray's place in the hierarchy and what it has foun
     uint32_t cur;           // what the lane looks at next: a pair, kBvhLeafRef | leaf, or kWalkDone
     int sp;                 // entries on its stack
     float far;              // closest hit: the best distance so far; shadow ray: its length (fixed)
-    uint32_t idx;           // closest hit: scene index of the best if an exact tie made the walk read it (else kWalkIndexOpen); shadow ray: lowest blocking index so far
+    uint32_t idx;           // shadow ray: the lowest blocking scene index so far (a closest-hit walk keeps no index: the material is read by slot)
     uint32_t slot;          // closest hit: slot of the best
 };
 
 #undef RT_WALK_COUNT
 #undef RT_WALK_CLOCK
 #undef RT_WALK_HIST
+
+// Where a lane's path stands, in ONE register (the kernel has none to spare): what it does next (2 bits), the path's depth
+// (4 bits), "the last bounce was specular" (1 bit), the light being sampled (24 bits).
+struct PathCtl {
+    uint32_t v;
+    RT_DEV uint32_t st() const { return v & 3u; }
+    RT_DEV void set_st(uint32_t x) { v = (v & ~3u) | x; }
+    RT_DEV uint32_t depth() const { return (v >> 2) & 15u; }
+    RT_DEV void deeper() { v += 4u; }
+    RT_DEV bool after_specular() const { return (v & 64u) != 0u; }
+    RT_DEV void set_after_specular(bool b) { v = b ? (v | 64u) : (v & ~64u); }
+    RT_DEV uint32_t light() const { return v >> 8; }
+    RT_DEV void next_light() { v += 256u; }
+    RT_DEV void first_light() { v &= 0xffu; }
+    RT_DEV void new_path() { v = (v & 3u) | 64u; }        // depth 0, after_specular, light 0
+};
 
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
@@ -329,17 +345,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     uint32_t c_tests = 0;               // shadow-ray tests since the last flush into the workgroup's sum (one register, not two: below)
 
     // ---- lane state ---------------------------------------------------------------------------
-    enum { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3 };
-    int st = kNew;
+    enum : uint32_t { kNew = 0, kClosest = 1, kShadow = 2, kLights = 3 };
+    PathCtl ctl{ kNew | 64u };                           // (nothing to do yet; after_specular as a new path has it)
     V3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 1.f);     // the ray in flight: the path's, or the shadow ray (o = hit point)
     V3 thr = mk(1.f, 1.f, 1.f), rad = mk(0.f, 0.f, 0.f);
-    int depth = 0;
-    bool after_specular = true;
     Walk W{ kWalkDone, 0, 0.f, 0xffffffffu, 0u };
     BvhRay R = bvh_ray(s_hdr, o, d);
     // a diffuse hit being lit: its normal, the light sum, the light in flight and what it adds if unblocked
     V3 nl = mk(0.f, 0.f, 1.f), ld = mk(0.f, 0.f, 0.f);
-    uint32_t lj = 0;
     float l_k = 0.f;
     uint16_t *my_stack = s_stack + tid;
 #if RT_OPT_WALK == 2
@@ -372,7 +385,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
     for (;;) {
         // (a lane that has rendered its samples stays in the loop, idle, until its wavefront has: the loop's exit is a scalar branch)
-        const bool finished = st == kNew && s >= s_end;
+        const bool finished = ctl.st() == kNew && s >= s_end;
         if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) break;
 #if RT_OPT_WALK == 2
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
@@ -382,10 +395,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         // ---- T: every walk in flight runs to its end ----
         if (W.cur != kWalkDone) {
 #if RT_OPT_WALK == 2
-            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
                        W.slot, cen, hist);
 #else
-            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, st == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
                        W.slot, nullptr, nullptr);
 #endif
         }
@@ -403,8 +416,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             RT_WALK_COUNT(4, __builtin_amdgcn_ballot_w64(true));
             bool path_done = false;
             int start = 0;                  // the ray this lane starts at the end of the phase: 0 none, 1 closest hit, 2 shadow
-            if (st == kShadow) {
-                // ---- the shadow ray of light lj - 1 has its answer, .cl:297-301 ----
+            if (ctl.st() == kShadow) {
+                // ---- the shadow ray of light ctl.light() - 1 has its answer, .cl:297-301 ----
                 const bool blocked = W.idx < n;
                 c_tests += blocked ? W.idx + 1u : n;
                 if ((int)c_tests < 0) {                                             // (rare: the 64-bit sum lives in LDS, the lane keeps 31 bits of it)
@@ -412,11 +425,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     c_tests = 0u;
                 }
                 if (!blocked) {
-                    const float4 lb = s_lightB[lj - 1u];
+                    const float4 lb = s_lightB[ctl.light() - 1u];
                     ld = add(ld, scale(mk(lb.x, lb.y, lb.z), l_k));
                 }
-                st = kLights;
-            } else if (st == kClosest) {
+                ctl.set_st(kLights);
+            } else if (ctl.st() == kClosest) {
                 c_closest += 1;
                 if (!(W.far < 1e20f)) {
                     path_done = true;                                              // miss, .cl:327-330
@@ -435,19 +448,19 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     const float dp = dot(nrm, d);
                     nl = scale(nrm, -1.f * cl_sign(dp));                           // .cl:354-355
                     if (!((em.x == 0.f) && (em.z == 0.f))) {                       // .cl:358-368
-                        if (after_specular) rad = add(rad, mul(thr, scale(em, fabsf(dp))));
+                        if (ctl.after_specular()) rad = add(rad, mul(thr, scale(em, fabsf(dp))));
                         path_done = true;
                     } else if (refl == RT_DIFF) {                                  // .cl:370-373
-                        after_specular = false;
+                        ctl.set_after_specular(false);
                         thr = mul(thr, col);
                         o = hp;
                         ld = mk(0.f, 0.f, 0.f);
-                        lj = 0;
-                        st = kLights;
+                        ctl.first_light();
+                        ctl.set_st(kLights);
                     } else {
                         // mirror / glass, .cl:413-489 (as in rt_trace.inc.h)
                         const V3 rfl = sub(d, scale(nrm, 2.f * dp));
-                        after_specular = true;
+                        ctl.set_after_specular(true);
                         if (refl == RT_SPEC) {
                             thr = mul(thr, col);
                             d = rfl;
@@ -478,8 +491,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                             }
                         }
                         o = hp;
-                        depth += 1;
-                        if (depth >= kMaxDepth) path_done = true;                  // .cl:320
+                        ctl.deeper();
+                        if (ctl.depth() >= (uint32_t)kMaxDepth) path_done = true;  // .cl:320
                         else start = 1;
                     }
                 }
@@ -489,8 +502,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             //      times one of them and the square root of a value formed from the other: that part is ONE section for the lanes
             //      about to sample a light and the lanes about to bounce.  Per pixel the operations and their order are the
             //      reference's (sample_light of rt_trace.inc.h and its bounce, term for term) ----
-            while (st == kLights) {
-                const bool bounce = lj == n_lights;
+            while (ctl.st() == kLights) {
+                const bool bounce = ctl.light() == n_lights;
                 const float f0 = __uint_as_float(next_random_word(s0, s1));        // first draw, in [2, 4)
                 const float f1 = __uint_as_float(next_random_word(s0, s1));        // second draw
                 c_draws += 2;
@@ -515,13 +528,13 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     V3 nd = add(scale(uu, cphi * root), scale(vv, sphi * root));
                     nd = add(nd, scale(w, rt_sqrt_unit(1 - r2)));
                     d = nd;
-                    depth += 1;
-                    st = kNew;                                                     // (leaves the light loop)
-                    if (depth >= kMaxDepth) path_done = true;
+                    ctl.deeper();
+                    ctl.set_st(kNew);                                              // (leaves the light loop)
+                    if (ctl.depth() >= (uint32_t)kMaxDepth) path_done = true;
                     else start = 1;
                 } else {
-                    const float4 la = s_lightA[lj], lb = s_lightB[lj];
-                    lj += 1u;
+                    const float4 la = s_lightA[ctl.light()], lb = s_lightB[ctl.light()];
+                    ctl.next_light();
                     const V3 us = mk(root * cphi, root * sphi, zc);                // .cl:203-213
                     const V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
                     V3 sd = sub(on_light, o);
@@ -536,7 +549,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                         l_k = rt_div(lb.w * wi * wo, len * len);                   // .cl:297 (used only if nothing blocks)
                         d = sd;
                         W.far = len - RT_EPS;
-                        st = kShadow;
+                        ctl.set_st(kShadow);
                         start = 2;
                     }
                 }
@@ -551,10 +564,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     acc = mk((acc.x * k1 + rad.x) * k2, (acc.y * k1 + rad.y) * k2, (acc.z * k1 + rad.z) * k2);
                 }
                 s += 1;
-                st = kNew;
+                ctl.set_st(kNew);
                 start = 0;
             }
-            if (st == kNew && start == 0 && s < s_end) {
+            if (ctl.st() == kNew && start == 0 && s < s_end) {
                 {
                     // ---- camera ray, .cl:494-549 (a finished path's next sample; the first sample of the launch); the camera
                     //      (12 floats) and 1/w, 1/h come from LDS, once per sample ----
@@ -575,8 +588,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     d = unit(rd);
                     thr = mk(1.f, 1.f, 1.f);
                     rad = mk(0.f, 0.f, 0.f);
-                    depth = 0;
-                    after_specular = true;
+                    ctl.new_path();
                     start = 1;
                 }
             }
@@ -605,8 +617,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 } else {
                     W.far = t;
                     W.slot = slot;
-                    W.idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;           // (the always-list winner's index is read if it stays the winner)
-                    st = kClosest;
+                    ctl.set_st(kClosest);
                 }
                 R = bvh_ray(s_hdr, o, d);
                 W.cur = root_ref;
@@ -738,9 +749,9 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
             sweep_closest(s_slots, n_always, o, d, t, slot, roots);
             w_far = t;
             w_slot = slot;
-            w_idx = (t < 1e20f) ? kWalkIndexOpen : 0xffffffffu;
+            w_idx = 0xffffffffu;
             walk_pairs(s_pairs, s_slots, g_index, s_stack + tid, kThreads, n_always, o, d, R, false, 3, cur, sp, w_far, w_idx, w_slot, nullptr, nullptr);
-            if (w_idx == kWalkIndexOpen) w_idx = g_index[w_slot];
+            w_idx = g_index[w_slot];                    // (read for a miss too: slot 0 then; the result below ignores it)
             float t_ref = 1e20f;
             uint32_t id_ref = 0;
             sweep_closest(P.scene.geom, n, o, d, t_ref, id_ref, roots);
