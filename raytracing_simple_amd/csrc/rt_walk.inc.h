@@ -170,6 +170,31 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             // takes the slot and clears the mask, so what is left at the end ties with the final best (the .scn loader doubles
             // spheres: such ties are real, and rare).
             uint32_t need = 0u;
+            uint32_t leaf_cnt = 0u;         // (census: spheres of the leaf whose discriminant is non-negative for this lane)
+#if RT_OPT_LEAF_TWO_PASS
+            // Two passes.  First the discriminants of all eight (hit_pre: 16 operations each), keeping only WHICH are non-negative --
+            // the ray's line passes through few of a leaf's spheres; then the spheres of that mask, one per round, the whole test
+            // again with its root half.  The rounds a wavefront takes are the largest number of such spheres any lane has (two or
+            // three), where the root half used to run eight times -- some lane's sphere k has a non-negative discriminant nearly
+            // always.  The same candidates in the same order through the same arithmetic: nothing observable changes.
+            uint32_t cand = 0u;
+#pragma unroll
+            for (int k = 0; k < kBvhLeaf; ++k) {
+                const HitPre p = hit_pre(s_slots[sl + (uint32_t)k], o, d);
+                cand |= (p.det >= 0.f) ? (1u << k) : 0u;
+            }
+            while (cand != 0u) {
+                const uint32_t k = (uint32_t)__builtin_ctz(cand);
+                cand &= cand - 1u;
+                const HitRoots hr = hit_roots(hit_pre(s_slots[sl + k], o, d));
+                const bool nearer = hr.hit & (hr.t < w_far), level = hr.hit & (hr.t == w_far);
+                const bool take = nearer & !shadow;
+                need = take ? 0u : need;
+                need |= (shadow ? nearer : level) ? (1u << k) : 0u;
+                w_far = take ? hr.t : w_far;
+                w_slot = take ? sl + k : w_slot;
+            }
+#else
 #pragma unroll
             for (int half = 0; half < kBvhLeaf; half += 4) {
                 HitPre p[4];
@@ -178,8 +203,14 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const int k = half + k4;
+                    if (cen) leaf_cnt += p[k4].det >= 0.f ? 1u : 0u;
                     if (wave_any_nonneg(p[k4].det)) {
                         const HitRoots hr = hit_roots(p[k4]);
+                        if (cen) {
+                            if (lane_ == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) hist[10] += 1ull;
+                            hist[11] += hr.hit ? 1ull : 0ull;
+                            hist[12] += (hr.hit & (hr.t < w_far)) ? 1ull : 0ull;
+                        }
                         const bool nearer = hr.hit & (hr.t < w_far), level = hr.hit & (hr.t == w_far);
                         const bool take = nearer & !shadow;
                         need = take ? 0u : need;
@@ -188,6 +219,12 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                         w_slot = take ? sl + (uint32_t)k : w_slot;
                     }
                 }
+            }
+#endif
+            if (cen) {
+                hist[8] += (unsigned long long)leaf_cnt;
+                for (uint32_t j = 1; j <= (uint32_t)kBvhLeaf; ++j)
+                    if (__builtin_amdgcn_ballot_w64(leaf_cnt >= j) != 0ull && lane_ == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) hist[9] += 1ull;
             }
             if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {
                 if (need != 0u) {
@@ -239,6 +276,9 @@ struct PathCtl {
     RT_DEV void new_path() { v = (v & 3u) | 64u; }        // depth 0, after_specular, light 0
 };
 
+#if RT_OPT_WALK == 3
+#include "rt_walk_share.inc.h"      // the lanes of a wavefront share the rays' walks (its own kernel body)
+#else
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
     constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
@@ -360,7 +400,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // each), [4/5] shade phases, [6/7] clock ticks in the walk / in shading, [8] loop trips, [9] sphere tests of the always-list
     // sweeps -> counters[20..29]; hist[0..3] leaf steps with 1-8 / 9-16 / 17-32 / 33-64 lanes, hist[4..7] pair steps likewise -> counters[8..15]
     unsigned long long cen[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    unsigned long long hist[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long hist[13] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // [8] lanes' non-negative discriminants per leaf step, [9] the largest such count per leaf step, [10] root halves executed, [11] hits, [12] nearer hits -> counters[16..19], [31]
 #define RT_WALK_COUNT(k, mask)                                                                     \
     do {                                                                                         \
         if (lane == __ffsll((long long)(mask)) - 1) cen[k] += 1ull;                              \
@@ -641,6 +681,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             atomicAdd(&P.counters[8 + k], h);
         }
     }
+    for (int k = 10; k < 13; ++k) {
+        unsigned long long h = hist[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) h += __shfl_xor(h, off, 64);
+        if (lane == 0) atomicAdd(&P.counters[k == 12 ? 31 : 8 + k], h);
+    }
 #endif
 
     // ---- epilogue: as in rt_trace.inc.h ----
@@ -692,6 +738,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
+
+#endif   // RT_OPT_WALK != 3
 
 #if RT_OPT_WALK == 1 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
 // Diagnostics (rt_debug_walk_rays): arbitrary rays through the walk AND through the plain sweep over the full table,

@@ -48,4 +48,9 @@ for name in names:
            "leaf_steps_per_ray": round(c[3] / max(st["closest_rays"] + st["shadow_rays"], 1), 2),
            "clock_share_walk": round(c[6] / max(c[6] + c[7], 1), 3), "always_tests": c[9]}
     rec.update({"leaf_steps_by_lanes_1_8_16_32_64": hs[0:4], "pair_steps_by_lanes_1_8_16_32_64": hs[4:8]})
+    # inside a leaf step: spheres (of 8) whose discriminant is non-negative per lane, the largest such count in the wavefront, root halves the
+    # wavefront executes (some lane's sphere k has one), hits, hits nearer than the best so far
+    rec.update({"nonneg_per_lane_leaf": round(raw[16] / max(c[3], 1), 2), "largest_nonneg_per_leaf_step": round(raw[17] / max(c[2], 1), 2),
+                "root_halves_per_leaf_step": round(raw[18] / max(c[2], 1), 2), "hits_per_lane_leaf": round(raw[19] / max(c[3], 1), 2),
+                "nearer_per_lane_leaf": round(raw[31] / max(c[3], 1), 2)})
     print(json.dumps(rec), flush=True)
