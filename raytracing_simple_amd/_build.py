@@ -40,7 +40,7 @@ UNITS = [
     ("rt_host.cpp", ["-ffp-contract=off"]),
     ("rt_build_id.cpp", []),
 ]
-DEPS = ["rt_device.h", "rt_internal.h", "rt_detmath.h", "rt_trace.inc.h", "rt_walk.inc.h", "rt_walk_share.inc.h", "rt_sched.inc.h", "rt_opts_reset.h",
+DEPS = ["rt_device.h", "rt_internal.h", "rt_detmath.h", "rt_trace.inc.h", "rt_walk.inc.h", "rt_sched.inc.h", "rt_opts_reset.h",
         os.path.join("..", "..", "include", "rt_api.h"), os.path.join("..", "..", "include", "rt_debug.h")]
 
 

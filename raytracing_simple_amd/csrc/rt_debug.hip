@@ -277,7 +277,7 @@ RT_API int rt_debug_set_tree_shape(rt_ctx *c, int by_area) {
     return dbg_apply(c, dbg_set_tree_shape, by_area);
 }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
-static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v & 0xff; if (v >> 8) c->walk_take = v >> 8; return RT_OK; }
+static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v; return RT_OK; }
 
 RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     if (!c || steps < 1) return fail(RT_ERR_ARG, "steps %d", steps);

@@ -82,9 +82,6 @@ inline size_t lds_bytes_pairs(uint32_t n_spheres, uint32_t n_lights, bool mat_in
     return (b + 15) & ~(size_t)15;
 }
 
-// ... of the form whose lanes share the walks (kInstSharedWalk): + the scene index of every slot, u16
-inline size_t lds_bytes_shared_walk_extra(uint32_t n_slots) { return (((size_t)n_slots * 2) + 15) & ~(size_t)15; }
-
 struct LaunchParams {
     SceneTables scene;
     rt_camera cam;
@@ -123,7 +120,6 @@ struct LaunchParams {
     // instances that walk the hierarchy of a large scene (RT_OPT_BVH) -- at the end: the other instances' argument
     // offsets, and with them their scalar loads and SGPR allocation, are what they were without it
     int walk_round;         // rt_walk.inc.h: pair steps in a row before the leaf step of the lanes that hold a leaf
-    int walk_take;          // rt_walk_share.inc.h: lanes of a wavefront with nothing to walk that start a take-over phase (65 and more: never)
     BvhTables bvh;
 };
 
@@ -167,7 +163,6 @@ enum InstanceFlags : uint8_t {
     kInstPersistent = 1,    // the grid only fills the machine; tiles come from the queue at counters[30]
     kInstNoTileCost = 2,    // neither reads the heavy-first order nor leaves per-tile costs
     kInstStaticCoop = 4,    // carries the cooperative any-hit mailbox (1.5 KiB of static LDS per wavefront)
-    kInstSharedWalk = 8,    // rt_walk_share.inc.h: stages the scene index of every slot as well (u16) and carries 3 KiB of static LDS
 };
 struct Instance {
     void (*fn)(const LaunchParams);

@@ -79,29 +79,6 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS parity_pairs_tp        /* A/B: the leaf step in two passes (discriminants of all eight, then the spheres whose line is met) */
-#define RT_KERNEL_NAME rt_trace_parity_pairs_tp
-#define RT_OPT_WALK 1
-#define RT_OPT_LEAF_TWO_PASS 1
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs_share     /* A/B: the lanes of a wavefront share the rays' walks (rt_walk_share.inc.h) */
-#define RT_KERNEL_NAME rt_trace_parity_pairs_share
-#define RT_OPT_WALK 3
-#define RT_OPT_MINWAVES 4
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_pairs_share_census
-#define RT_KERNEL_NAME rt_trace_parity_pairs_share_census
-#define RT_OPT_WALK 3
-#define RT_OPT_WALK_CENSUS 1
-#define RT_OPT_MINWAVES 4
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
 #define RT_NS parity_coop_check      /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coop_check
 #define RT_OPT_COOP 2
@@ -159,9 +136,6 @@ static const Instance kParityInstances[] = {
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs_tp::rt_trace_parity_pairs_tp, "rt_trace_parity_pairs_tp", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_pairs_share::rt_trace_parity_pairs_share, "rt_trace_parity_pairs_share", 4, kTabPairsLds, kRoleNone, kInstSharedWalk },
-    { parity_pairs_share_census::rt_trace_parity_pairs_share_census, "rt_trace_parity_pairs_share_census", 4, kTabPairsLds, kRoleNone, kInstSharedWalk },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },
     { parity_coop_census::rt_trace_parity_coop_census, "rt_trace_parity_coop_census", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

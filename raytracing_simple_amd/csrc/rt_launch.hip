@@ -223,10 +223,6 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
         case rt::kTabPairsLds:
             p.mat_in_lds = 0;               // (the walk reads a hit's material by slot from the hierarchy's blob: nothing of it is staged)
             lds = pairs_lds(c, false, n_samples);
-            if (inst.flags & rt::kInstSharedWalk) {
-                if (c->scene.n_spheres > 65535u) return fail(RT_ERR_STATE, "%s keeps scene indices in 16 bits", inst.name);
-                lds += rt::lds_bytes_shared_walk_extra(c->bvh.n_slots);
-            }
             break;
         case rt::kTabPairsGlobal:
             p.mat_in_lds = 0;
@@ -279,7 +275,6 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
         waves = 4;
     }
     p.walk_round = c->walk_round;
-    p.walk_take = c->walk_take;
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {

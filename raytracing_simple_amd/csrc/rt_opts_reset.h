@@ -8,8 +8,6 @@
 #undef RT_OPT_WG_WAVES
 #undef RT_OPT_COOP
 #undef RT_OPT_WALK
-#undef RT_OPT_WALK_CENSUS
-#undef RT_OPT_LEAF_TWO_PASS
 #undef RT_OPT_GLOBAL_TABLES
 #undef RT_OPT_MINWAVES
 #undef RT_OPT_PERSIST

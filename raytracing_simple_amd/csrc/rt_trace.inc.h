@@ -43,8 +43,7 @@
 //   RT_OPT_COOP           1: shadow rays of a wavefront share the idle lanes (coop_any; scenes of 12 spheres and more);
 //                         2: verification instance, the sequential sweep runs beside it (diagnostics)
 //   RT_OPT_WALK           1: large scenes -- the small spheres hang in a hierarchy that each lane walks for its own ray
-//                         (rt_walk.inc.h, its own kernel body); 2: the same with a census of its steps (diagnostics);
-//                         3: the lanes of a wavefront share the rays' walks (rt_walk_share.inc.h; RT_OPT_WALK_CENSUS 1: with a census)
+//                         (rt_walk.inc.h, its own kernel body); 2: the same with a census of its steps (diagnostics)
 //   RT_OPT_GLOBAL_TABLES  tables that do not fit LDS are read where they lie in HBM / L2
 //   RT_OPT_MINWAVES       launch bound: wavefronts per SIMD the register allocation must allow
 // Diagnostics build only:
@@ -60,12 +59,6 @@
 #endif
 #ifndef RT_OPT_WALK
 #define RT_OPT_WALK 0
-#endif
-#ifndef RT_OPT_LEAF_TWO_PASS
-#define RT_OPT_LEAF_TWO_PASS 0
-#endif
-#ifndef RT_OPT_WALK_CENSUS
-#define RT_OPT_WALK_CENSUS 0
 #endif
 #ifndef RT_OPT_GLOBAL_TABLES
 #define RT_OPT_GLOBAL_TABLES 0

@@ -85,14 +85,45 @@ RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
 // the derivation above, which is inside the grown box by that margin, is between the computed planes on every axis and
 // its parameter inside [tn, tf].  Minimum and maximum drop NaN operands (a direction component of 0 against a plane
 // through the origin): that axis then does not constrain.
-RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far, float &t_near) {
+// (minimum and maximum as the instructions themselves -- v_min_f32 / v_max_f32 / v_min3 / v_max3 return the operand that is a
+// number when one is not -- without the canonicalising copies the compiler puts in front of fminf / fmaxf)
+RT_DEV float lean_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RT_DEV float lean_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RT_DEV float lean_max_neg(float a, float b) {          // max(a, -b)
+    float r;
+    asm("v_max_f32 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RT_DEV float lean_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+RT_DEV float lean_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// `t_hi` = t_far + R.tback: the far end of the stretch of the ray the box has to meet (formed once per round of steps, not per box)
+RT_DEV bool bvh_misses_upto(const BvhRay &R, float4 A, float4 B, float t_hi, float &t_near) {
     const float x0 = __builtin_fmaf(A.x, R.inv.x, R.clo.x), x1 = __builtin_fmaf(B.x, R.inv.x, R.chi.x);
     const float y0 = __builtin_fmaf(A.y, R.inv.y, R.clo.y), y1 = __builtin_fmaf(B.y, R.inv.y, R.chi.y);
     const float z0 = __builtin_fmaf(A.z, R.inv.z, R.clo.z), z1 = __builtin_fmaf(B.z, R.inv.z, R.chi.z);
-    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), -R.tback));
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), t_far + R.tback));
+    const float tn = lean_max3(lean_min(x0, x1), lean_min(y0, y1), lean_max_neg(lean_min(z0, z1), R.tback));
+    const float tf = lean_min3(lean_max(x0, x1), lean_max(y0, y1), lean_min(lean_max(z0, z1), t_hi));
     t_near = tn;                        // where the ray enters the grown box (an ordering hint, nothing more)
     return tn > tf;
+}
+RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far, float &t_near) {
+    return bvh_misses_upto(R, A, B, t_far + R.tback, t_near);
 }
 RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
     float unused;
@@ -120,6 +151,8 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
                        uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist) {
     const int lane_ = threadIdx.x & 63;
+    uint32_t kind_m = shadow ? 0xffffffffu : 0u;        // all ones: a shadow ray (as a value the compiler does not see through)
+    asm("" : "+v"(kind_m));
     while (cur != kWalkDone) {
         for (int round = round_len; cur < kBvhLeafRef && round > 0; --round) {
             if (cen) {
@@ -134,13 +167,14 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             const float4 *pp = s_pairs + 4u * cur;
             const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
             float tn0, tn1;
-            const bool out0 = bvh_misses(R, A0, B0, w_far, tn0), out1 = bvh_misses(R, A1, B1, w_far, tn1);
+            const float t_hi = w_far + R.tback;
+            const bool out0 = bvh_misses_upto(R, A0, B0, t_hi, tn0), out1 = bvh_misses_upto(R, A1, B1, t_hi, tn1);
             // a shadow walk skips subtrees that hold only scene indices above its lowest blocker so far; a closest-hit walk never does
             const uint32_t prune = shadow ? w_idx : 0xffffffffu;
             const bool m0 = (int)out0 | (int)(__float_as_uint(B0.w) > prune), m1 = (int)out1 | (int)(__float_as_uint(B1.w) > prune);
             const uint32_t r0 = __float_as_uint(A0.w), r1 = __float_as_uint(A1.w);
             const bool both = !m0 & !m1, none = m0 & m1;
-            const bool second_first = both ? (tn1 < tn0) : m0;
+            const bool second_first = (int)m0 | ((int)(tn1 < tn0) & (int)!m1);      // (= both ? tn1 < tn0 : m0, as mask logic)
             const uint32_t near = second_first ? r1 : r0, far = second_first ? r0 : r1;
             my_stack[sp * stack_stride] = (uint16_t)far;       // (dead unless `both`: the entry above the top)
             sp += both ? 1 : 0;
@@ -171,30 +205,6 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             // spheres: such ties are real, and rare).
             uint32_t need = 0u;
             uint32_t leaf_cnt = 0u;         // (census: spheres of the leaf whose discriminant is non-negative for this lane)
-#if RT_OPT_LEAF_TWO_PASS
-            // Two passes.  First the discriminants of all eight (hit_pre: 16 operations each), keeping only WHICH are non-negative --
-            // the ray's line passes through few of a leaf's spheres; then the spheres of that mask, one per round, the whole test
-            // again with its root half.  The rounds a wavefront takes are the largest number of such spheres any lane has (two or
-            // three), where the root half used to run eight times -- some lane's sphere k has a non-negative discriminant nearly
-            // always.  The same candidates in the same order through the same arithmetic: nothing observable changes.
-            uint32_t cand = 0u;
-#pragma unroll
-            for (int k = 0; k < kBvhLeaf; ++k) {
-                const HitPre p = hit_pre(s_slots[sl + (uint32_t)k], o, d);
-                cand |= (p.det >= 0.f) ? (1u << k) : 0u;
-            }
-            while (cand != 0u) {
-                const uint32_t k = (uint32_t)__builtin_ctz(cand);
-                cand &= cand - 1u;
-                const HitRoots hr = hit_roots(hit_pre(s_slots[sl + k], o, d));
-                const bool nearer = hr.hit & (hr.t < w_far), level = hr.hit & (hr.t == w_far);
-                const bool take = nearer & !shadow;
-                need = take ? 0u : need;
-                need |= (shadow ? nearer : level) ? (1u << k) : 0u;
-                w_far = take ? hr.t : w_far;
-                w_slot = take ? sl + k : w_slot;
-            }
-#else
 #pragma unroll
             for (int half = 0; half < kBvhLeaf; half += 4) {
                 HitPre p[4];
@@ -214,13 +224,15 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                         const bool nearer = hr.hit & (hr.t < w_far), level = hr.hit & (hr.t == w_far);
                         const bool take = nearer & !shadow;
                         need = take ? 0u : need;
-                        need |= (shadow ? nearer : level) ? (1u << k) : 0u;
+                        // (a shadow ray wants its blockers, a closest-hit ray the spheres level with its best: the lane's kind picks between
+                        // two bit values -- one v_bfi -- where a select between the two CONDITIONS costs the compiler five operations)
+                        const uint32_t nb = nearer ? (1u << k) : 0u, lb = level ? (1u << k) : 0u;
+                        need |= (nb & kind_m) | (lb & ~kind_m);
                         w_far = take ? hr.t : w_far;
                         w_slot = take ? sl + (uint32_t)k : w_slot;
                     }
                 }
             }
-#endif
             if (cen) {
                 hist[8] += (unsigned long long)leaf_cnt;
                 for (uint32_t j = 1; j <= (uint32_t)kBvhLeaf; ++j)
@@ -276,9 +288,6 @@ struct PathCtl {
     RT_DEV void new_path() { v = (v & 3u) | 64u; }        // depth 0, after_specular, light 0
 };
 
-#if RT_OPT_WALK == 3
-#include "rt_walk_share.inc.h"      // the lanes of a wavefront share the rays' walks (its own kernel body)
-#else
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
     constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
@@ -738,8 +747,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
-
-#endif   // RT_OPT_WALK != 3
 
 #if RT_OPT_WALK == 1 && RT_DIAGNOSTICS && defined(RT_WALK_RAYS_KERNEL_NAME)
 // Diagnostics (rt_debug_walk_rays): arbitrary rays through the walk AND through the plain sweep over the full table,
