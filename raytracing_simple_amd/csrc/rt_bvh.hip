@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -32,6 +33,7 @@ __device__ inline unsigned bvh_ordered(float f) {          // unsigned order = f
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ inline float bvh_unordered(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__device__ inline uint32_t bvh_complaints(uint32_t bad) { return (bad < 0xffu ? bad : 0xffu) << 24; }     // (top byte of the header's last word; bits 16..23: levels of a tree shaped on the device)
 __device__ inline float bvh_down(float v) { return v - (fabsf(v) * 0x1p-22f + 1e-30f); }
 __device__ inline float bvh_up(float v) { return v + (fabsf(v) * 0x1p-22f + 1e-30f); }
 
@@ -219,10 +221,10 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
             const float ex = hi[0] - cx, ey = hi[1] - cy, ez = hi[2] - cz;
             hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
             const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
-            hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float(s_bad));
+            hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float((n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef) | bvh_complaints(s_bad)));
         } else {
             hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-            hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(s_bad));
+            hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rt::kBvhLeafRef | bvh_complaints(s_bad)));
         }
     }
     // ---- 5. the sibling pairs (rt_device.h BvhTables `pairs`): one thread per inner node ----
@@ -249,6 +251,274 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
             const uint32_t ref = (cb - ca == 1) ? (rt::kBvhLeafRef | ca) : (ca + cb) / 2 - 1;
             pairs[4 * (size_t)(m - 1) + 2 * side] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(ref));
             pairs[4 * (size_t)(m - 1) + 2 * side + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(low));
+        }
+    }
+}
+
+// The same tables with the tree's SHAPE chosen by surface area ON THE DEVICE (device-resident updates, and uploads whose host
+// build would stall the caller for milliseconds): ONE workgroup, the same sort per level, but a node's range of leaves is cut
+// where  area(left) * leaves(left) + area(right) * leaves(right)  is smallest instead of in the middle.  Cuts fall between WHOLE
+// leaves (every leaf full but the last), so the leaf count, the slot count and every offset into the blob are what the host
+// computes from the sphere count alone -- nothing is read back.  What the host cannot know travels with the tree: the root's
+// pair in the header; the depth is bounded instead (a node at level k may hold at most 2^(depth_cap - k) leaves, so the stacks are
+// sized for depth_cap).  Against the host's build by surface area (any cut, three axes): one axis per node (the longest of its
+// box), no partial leaves -- the model of round 3 put cuts at whole leaves within 2 % of any cut on C3 (profiles/r03y_*).
+//   per level:  keys (node's first leaf | coordinate along the node's axis | scene index) -> bitonic sort -> leaf boxes ->
+//               segmented prefix / suffix unions of the leaf boxes inside every node (Hillis-Steele, 7 words per box) ->
+//               one thread per cut evaluates its cost, ds_min_u64 per node picks -> the pair record of the cut, the children's
+//               ranges, axes and references.  Inner node (a, b) cut at c has its pair at c - 1, as in every other build.
+constexpr uint32_t kSahDeviceMaxTree = 8192;        // 1024 leaves: a thread per leaf (up to 512 leaves the unions towards both ends of a node are formed at once)
+__device__ inline float bvh_area7(const float *b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+__device__ inline unsigned bvh_longest(const float *b) {
+    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+    unsigned axis = 0;
+    float e = ex;
+    if (ey > e) { axis = 1; e = ey; }
+    if (ez > e) axis = 2;
+    return axis;
+}
+__global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere *sph, uint32_t n, float r_cut, uint32_t n_always, uint32_t n_tree,
+                                                                uint32_t n_pad, uint32_t depth_cap, float4 *blob) {
+    extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, then the per-leaf arrays below
+    __shared__ unsigned s_rmin, s_rmax, s_rb[6];
+    __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad, s_any, s_root, s_levels;
+    const unsigned tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t L = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
+    const uint32_t n_slots = n_always + rt::kBvhLeaf * L;
+    float4 *hdr = blob, *slots = blob + rt::bvh_slots_at();
+    uint32_t *index = reinterpret_cast<uint32_t *>(blob + rt::bvh_index_at(n_slots));
+    float4 *pairs = blob + rt::bvh_pairs_at(n_slots);
+    float *s_pre = reinterpret_cast<float *>(s_keys + n_pad);       // [7][L]: lo.xyz, hi.xyz, bits(lowest scene index): unions from the node's first leaf up to this one
+    float *s_suf = s_pre + 7 * L;                                   // ... from this leaf to the node's last
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_suf + 7 * L);      // per node (by its first leaf): bits(cost) << 32 | cut
+    uint16_t *s_na = reinterpret_cast<uint16_t *>(s_best + L), *s_nb = s_na + L;             // per leaf: the range of leaves of the node it is in
+    uint16_t *s_refl = s_nb + L, *s_refr = s_refl + L;                                       // per cut: the references of the pair's two children
+    uint8_t *s_side = reinterpret_cast<uint8_t *>(s_refr + L), *s_axis = s_side + L;         // per leaf: its node is the left (0) / right (1) child, or the root (2); per node: the axis
+    if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; s_root = rt::kBvhLeafRef; s_levels = 0; }
+    if (tid < 3) { s_rb[tid] = 0xffffffffu; s_rb[3 + tid] = 0u; }
+    for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
+    for (uint32_t l = tid; l < L; l += 1024) { s_na[l] = 0; s_nb[l] = (uint16_t)L; s_side[l] = 2; s_axis[l] = 0; s_refl[l] = s_refr[l] = 0xffffu; }
+    __syncthreads();
+    // ---- 1. radius range of the tree's spheres, and their box (the root's, whatever the order: it also gives the root's axis) ----
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const float *r = reinterpret_cast<const float *>(sph + i);
+        if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
+            const float ar = fabsf(r[0]);
+            atomicMin(&s_rmin, __float_as_uint(ar));
+            atomicMax(&s_rmax, __float_as_uint(ar));
+            for (int a3 = 0; a3 < 3; ++a3) {
+                atomicMin(&s_rb[a3], bvh_ordered(bvh_down(r[1 + a3] - ar)));
+                atomicMax(&s_rb[3 + a3], bvh_ordered(bvh_up(r[1 + a3] + ar)));
+            }
+        }
+    }
+    // ---- 2. the always list in scene order, the tree's spheres in scene order for a start (as in rt_bvh_build_kernel) ----
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + tid;
+        bool out = false, in = false;
+        float rad = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+        if (i < n) {
+            const float *r = reinterpret_cast<const float *>(sph + i);
+            rad = r[0]; px = r[1]; py = r[2]; pz = r[3];
+            out = bvh_outside(rad, px, py, pz, r_cut);
+            in = !out;
+        }
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(out), mt = __builtin_amdgcn_ballot_w64(in);
+        const uint32_t before_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
+        const uint32_t before_t = __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
+        if ((tid & 63) == 0) { s_wave_a[wave] = (uint32_t)__popcll(ma); s_wave_t[wave] = (uint32_t)__popcll(mt); }
+        __syncthreads();
+        uint32_t off_a = s_base_a, off_t = s_base_t;
+        for (unsigned k = 0; k < wave; ++k) { off_a += s_wave_a[k]; off_t += s_wave_t[k]; }
+        if (out) {
+            const uint32_t j = off_a + before_a;
+            if (j < n_always) {
+                slots[j] = make_float4(px, py, pz, rad * rad);
+                index[j] = i;
+                const float *r = reinterpret_cast<const float *>(sph + i);
+                blob[rt::bvh_emis_at(L, n_slots) + j] = make_float4(r[4], r[5], r[6], r[10]);
+                blob[rt::bvh_colr_at(L, n_slots) + j] = make_float4(r[7], r[8], r[9], rad);
+            }
+            else atomicAdd(&s_bad, 1u);
+        }
+        if (in) {
+            const uint32_t j = off_t + before_t;
+            if (j < n_tree) s_keys[j] = i;
+            else atomicAdd(&s_bad, 1u);
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int k = 0; k < 16; ++k) { s_base_a += s_wave_a[k]; s_base_t += s_wave_t[k]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float rb[6];
+        for (int k = 0; k < 6; ++k) rb[k] = bvh_unordered(s_rb[k]);
+        s_axis[0] = (uint8_t)bvh_longest(rb);
+    }
+    __syncthreads();
+    // ---- 2b. level by level: order every node's spheres along its axis, cut its range of leaves by surface area ----
+    constexpr unsigned long long kIdxMask = (1ull << 18) - 1;
+    const bool both_at_once = L <= 512u;                 // threads 0..511 form the unions towards a node's first leaf while 512..1023 form those towards its last
+    for (uint32_t level = 0;; ++level) {
+        for (uint32_t j = tid; j < n_tree; j += 1024) {
+            const uint32_t l = j / rt::kBvhLeaf, a = s_na[l];
+            const bool single = (uint32_t)s_nb[l] - a == 1u;
+            const uint32_t ix = (uint32_t)(s_keys[j] & kIdxMask);
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            const unsigned axis = s_axis[a];
+            const float c3 = axis == 0 ? r[1] : (axis == 1 ? r[2] : r[3]);
+            const unsigned coord = single ? j : bvh_ordered(c3);        // a node of one leaf keeps its order
+            s_keys[j] = ((unsigned long long)a << 50) | ((unsigned long long)coord << 18) | ix;
+        }
+        for (uint32_t l = tid; l < L; l += 1024) s_best[l] = ~0ull;
+        if (tid == 0) s_any = 0;
+        __syncthreads();
+        for (uint32_t k = 2; k <= n_pad; k <<= 1) {             // bitonic sort, ascending (the padding keys stay behind)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < n_pad; i += 1024) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long ka = s_keys[i], kb = s_keys[l];
+                        if ((ka > kb) == ((i & k) == 0)) { s_keys[i] = kb; s_keys[l] = ka; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // leaf boxes (rounded outwards) and the lowest scene index in the leaf: the start of both scans
+        if (tid < L) {
+            float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+            uint32_t low = 0xffffffffu;
+            for (int k = 0; k < rt::kBvhLeaf; ++k) {
+                const uint32_t j = rt::kBvhLeaf * tid + (uint32_t)k;
+                if (j >= n_tree) break;
+                const uint32_t ix = (uint32_t)(s_keys[j] & kIdxMask);
+                const float *r = reinterpret_cast<const float *>(sph + ix);
+                const float ar = fabsf(r[0]);
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    lo[a3] = fminf(lo[a3], bvh_down(r[1 + a3] - ar));
+                    hi[a3] = fmaxf(hi[a3], bvh_up(r[1 + a3] + ar));
+                }
+                low = ix < low ? ix : low;
+            }
+            for (int a3 = 0; a3 < 3; ++a3) {
+                s_pre[a3 * L + tid] = s_suf[a3 * L + tid] = lo[a3];
+                s_pre[(3 + a3) * L + tid] = s_suf[(3 + a3) * L + tid] = hi[a3];
+            }
+            s_pre[6 * L + tid] = s_suf[6 * L + tid] = __uint_as_float(low);
+        }
+        __syncthreads();
+        // segmented scans: s_pre[.][l] = union of the node's leaves up to l, s_suf[.][l] = from l on
+        for (int pass = 0; pass < (both_at_once ? 1 : 2); ++pass) {
+            const uint32_t scan_l = both_at_once ? (tid & 511u) : tid;
+            const bool scan_up = both_at_once ? tid >= 512u : pass == 1;
+            float *s_mine = scan_up ? s_suf : s_pre;
+            const bool mine = scan_l < L;
+            const uint32_t a = mine ? s_na[scan_l] : 0u, b = mine ? s_nb[scan_l] : 0u;
+            float v[7];
+            if (mine)
+                for (int k = 0; k < 7; ++k) v[k] = s_mine[k * L + scan_l];
+            for (uint32_t dist = 1; dist < L; dist <<= 1) {
+                const uint32_t other = scan_up ? scan_l + dist : scan_l - dist;
+                const bool ok = mine && (scan_up ? other < b : (scan_l >= dist && other >= a));
+                if (ok) {
+                    for (int k = 0; k < 3; ++k) v[k] = fminf(v[k], s_mine[k * L + other]);
+                    for (int k = 3; k < 6; ++k) v[k] = fmaxf(v[k], s_mine[k * L + other]);
+                    const uint32_t q = __float_as_uint(s_mine[6 * L + other]), w = __float_as_uint(v[6]);
+                    v[6] = __uint_as_float(q < w ? q : w);
+                }
+                __syncthreads();
+                if (ok)
+                    for (int k = 0; k < 7; ++k) s_mine[k * L + scan_l] = v[k];
+                __syncthreads();
+            }
+        }
+        // every cut's cost; the cheapest per node (ties: the lower cut)
+        if (tid < L) {
+            const uint32_t c = tid, a = s_na[c], b = s_nb[c];
+            const uint32_t room = depth_cap > level + 1u ? depth_cap - level - 1u : 0u;
+            const uint32_t most = room >= 16u ? 0xffffu : (1u << room);         // leaves a child may hold and still end within depth_cap
+            if (c > a && c - a <= most && b - c <= most) {
+                float lb[6], rb[6];
+                for (int k = 0; k < 6; ++k) { lb[k] = s_pre[k * L + c - 1]; rb[k] = s_suf[k * L + c]; }
+                const float cost = bvh_area7(lb) * (float)(c - a) + bvh_area7(rb) * (float)(b - c);
+                atomicMin(&s_best[a], ((unsigned long long)__float_as_uint(cost) << 32) | c);
+            }
+        }
+        __syncthreads();
+        if (tid < L) {
+            const uint32_t l = tid, a = s_na[l], b = s_nb[l];
+            if (b - a > 1u) {
+                const unsigned long long k = s_best[a];
+                const uint32_t c = k == ~0ull ? a + (b - a) / 2u : (uint32_t)k;
+                if (l == c) {
+                    float lb[7], rb[7];
+                    for (int q = 0; q < 7; ++q) { lb[q] = s_pre[q * L + c - 1]; rb[q] = s_suf[q * L + c]; }
+                    pairs[4 * (size_t)(c - 1) + 0] = make_float4(lb[0], lb[1], lb[2], 0.f);
+                    pairs[4 * (size_t)(c - 1) + 1] = make_float4(lb[3], lb[4], lb[5], lb[6]);
+                    pairs[4 * (size_t)(c - 1) + 2] = make_float4(rb[0], rb[1], rb[2], 0.f);
+                    pairs[4 * (size_t)(c - 1) + 3] = make_float4(rb[3], rb[4], rb[5], rb[6]);
+                    s_refl[c] = (uint16_t)(c - a == 1u ? (rt::kBvhLeafRef | a) : 0xffffu);
+                    s_refr[c] = (uint16_t)(b - c == 1u ? (rt::kBvhLeafRef | c) : 0xffffu);
+                    const unsigned sd = s_side[l];
+                    if (sd == 2u) s_root = c - 1u;
+                    else if (sd == 0u) s_refl[b] = (uint16_t)(c - 1u);           // (a left child's parent was cut at the child's end, a right child's at its start)
+                    else s_refr[a] = (uint16_t)(c - 1u);
+                    s_axis[a] = (uint8_t)bvh_longest(lb);
+                    s_axis[c] = (uint8_t)bvh_longest(rb);
+                    s_levels = level + 1u;
+                }
+                if (l < c) { s_nb[l] = (uint16_t)c; s_side[l] = 0; if (c - a > 1u) s_any = 1u; }
+                else { s_na[l] = (uint16_t)c; s_side[l] = 1; if (b - c > 1u) s_any = 1u; }
+            }
+        }
+        __syncthreads();
+        if (s_any == 0u) break;
+        __syncthreads();            // (s_any is cleared at the top of the next level)
+    }
+    // ---- 3. records in leaf order; padding records never hit (NaN centre: every comparison of the test is false) ----
+    const float qnan = __uint_as_float(0x7fc00000u);
+    for (uint32_t j = tid; j < rt::kBvhLeaf * L; j += 1024) {
+        const uint32_t ix = j < n_tree ? (uint32_t)(s_keys[j] & kIdxMask) : 0xffffffffu;
+        if (ix != 0xffffffffu) {
+            const float *r = reinterpret_cast<const float *>(sph + ix);
+            slots[n_always + j] = make_float4(r[1], r[2], r[3], r[0] * r[0]);
+            blob[rt::bvh_emis_at(L, n_slots) + n_always + j] = make_float4(r[4], r[5], r[6], r[10]);
+            blob[rt::bvh_colr_at(L, n_slots) + n_always + j] = make_float4(r[7], r[8], r[9], r[0]);
+        } else {
+            slots[n_always + j] = make_float4(qnan, qnan, qnan, qnan);
+            blob[rt::bvh_emis_at(L, n_slots) + n_always + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            blob[rt::bvh_colr_at(L, n_slots) + n_always + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        index[n_always + j] = ix;
+    }
+    // ---- 4. the pairs' references (each child entered its own when it was cut), the header ----
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t c = 1 + tid; c < L; c += 1024) {
+        float4 r0 = pairs[4 * (size_t)(c - 1) + 0], r2 = pairs[4 * (size_t)(c - 1) + 2];
+        r0.w = __uint_as_float((uint32_t)s_refl[c]);
+        r2.w = __uint_as_float((uint32_t)s_refr[c]);
+        pairs[4 * (size_t)(c - 1) + 0] = r0;
+        pairs[4 * (size_t)(c - 1) + 2] = r2;
+    }
+    if (tid == 0) {
+        const uint32_t last = (L > 1 ? s_root : rt::kBvhLeafRef) | ((s_levels & 0xffu) << 16) | bvh_complaints(s_bad);
+        if (L) {
+            float rb[6];
+            for (int k = 0; k < 6; ++k) rb[k] = bvh_unordered(s_rb[k]);
+            const float cx = 0.5f * rb[0] + 0.5f * rb[3], cy = 0.5f * rb[1] + 0.5f * rb[4], cz = 0.5f * rb[2] + 0.5f * rb[5];
+            const float ex = rb[3] - cx, ey = rb[4] - cy, ez = rb[5] - cz;
+            hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
+            const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
+            hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float(last));
+        } else {
+            hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(last));
         }
     }
 }
@@ -414,7 +684,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     const float cx = 0.5f * root.lo[0] + 0.5f * root.hi[0], cy = 0.5f * root.lo[1] + 0.5f * root.hi[1], cz = 0.5f * root.lo[2] + 0.5f * root.hi[2];
     const float ex = root.hi[0] - cx, ey = root.hi[1] - cy, ez = root.hi[2] - cz;
     hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
-    hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
+    hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), bits_float(n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef));
     host_fill_materials(blob, sph, n_leaves, n_slots);
     HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, total4 * sizeof(float4), hipMemcpyHostToDevice, stream));
     if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
@@ -439,8 +709,8 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
 // BvhTables::root since it is no longer n_leaves / 2 - 1.  Against the fixed shape, on C3's rays (a host model, profiles/r03y_tree_shape_model.txt): pair
 // steps per ray -15 % (shadow rays -28 %), leaf visits -7 %.  Returns RT_OK with *built = false when the result does not fit
 // the tables' allocation or the stack budget (the caller then takes the fixed shape).
-constexpr uint32_t kSahMaxTree = 4096;          // the build stays a few milliseconds (rt_set_scene with it: 1.2 ms for 1024 spheres, 5.9 for 4096,
-                                                // 13 for 8192, 30 for 16384 against 0.4 / 1.2 / 2.2 / 3.2 with the device build: tools/tree_build_time.py)
+constexpr uint32_t kSahMaxTree = rt::kAlwaysWalkFrom - 1;   // the host shapes the trees whose surface areas the choice of form is estimated from (1.2 ms at 1024
+                                                // spheres); from kAlwaysWalkFrom on nothing is estimated and the device shapes the tree (rt_bvh_build_sah_kernel)
 constexpr uint32_t kSahMinTree = 128;           // below 16 leaves the halved shape is as good (64 spheres: 6.95 against 7.03 ms) and one level shallower
 constexpr uint32_t kSahMaxDepth = 30;
 struct SahOut {
@@ -604,7 +874,7 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
     const float cx = 0.5f * rb.lo[0] + 0.5f * rb.hi[0], cy = 0.5f * rb.lo[1] + 0.5f * rb.hi[1], cz = 0.5f * rb.lo[2] + 0.5f * rb.hi[2];
     const float ex = rb.hi[0] - cx, ey = rb.hi[1] - cy, ez = rb.hi[2] - cz;
     hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
-    hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), 0.f);
+    hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), bits_float(n_leaves > 1 ? root.ref : rt::kBvhLeafRef));
     host_fill_materials(blob, sph, n_leaves, n_slots);
     HIP_TRY(hipMemcpyAsync(c->d_bvh, blob, total4 * sizeof(float4), hipMemcpyHostToDevice, stream));
     if (!c->bvh_stage_ev) HIP_TRY(hipEventCreate(&c->bvh_stage_ev));
@@ -612,7 +882,6 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
     c->bvh_stage_used = true;
     *n_leaves_out = n_leaves;
     *depth_out = root.depth;
-    c->bvh_sah_root = root.ref;
     *built = true;
     const double a_root = area(rb);
     if (n_leaves == 1) area_leaf = a_root;
@@ -627,6 +896,8 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_alway
 namespace rt {
 
 hipError_t prepare_bvh_build() {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rt_bvh_build_sah_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(rt_bvh_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
 
@@ -658,15 +929,13 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
     c->bvh_n_tree = n_tree;
     // a full upload (rt_set_scene: the call blocks and the host has every record): the shape by surface area, on the host
-    if (full_upload && c->bvh_sah && n_tree >= kSahMinTree && n_tree <= kSahMaxTree) {
+    if (full_upload && c->bvh_sah == 1 && n_tree >= kSahMinTree && n_tree <= kSahMaxTree) {
         uint32_t sah_leaves = 0, sah_depth = 0;
         bool built = false;
         const int rc = build_on_host_sah(c, n_total, r_cut, n_always, n_tree, stream, &sah_leaves, &sah_depth, &built);
         if (rc != RT_OK) return rc;
         if (built) {
-            uint32_t root = rt::kBvhLeafRef;
-            if (sah_leaves > 1) root = c->bvh_sah_root;
-            c->bvh = rt::BvhTables{ c->d_bvh, n_always, sah_leaves, n_always + rt::kBvhLeaf * sah_leaves, sah_depth, root,
+            c->bvh = rt::BvhTables{ c->d_bvh, n_always, sah_leaves, n_always + rt::kBvhLeaf * sah_leaves, sah_depth,
                                     rt::bvh_emis_at(sah_leaves, n_always + rt::kBvhLeaf * sah_leaves) };
             c->bvh_ok = true;
             return RT_OK;
@@ -675,6 +944,24 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     // a full upload of a small tree: the fixed shape built on the host (the same tree the device builds: same splits, same
     // boxes), because the host then knows the surface areas the choice between hierarchy and sweep is estimated from
     const bool host_small = full_upload && n_tree < kSahMinTree;
+    // device-resident updates, and uploads too large for the host to shape in passing: the shape by surface area, on the device
+    if (c->bvh_sah && n_tree >= kSahMinTree && n_tree <= kSahDeviceMaxTree) {
+        uint32_t n_pad = 2;
+        while (n_pad < n_tree) n_pad *= 2;
+        uint32_t depth_cap = 1;
+        while ((1u << depth_cap) < n_leaves) depth_cap += 1;
+        uint32_t margin = 2;                                    // (levels more than the halved shape needs: room for uneven cuts; 1, 2 and 3 give C3 the same tree, profiles/r04p_*)
+#if RT_DIAGNOSTICS
+        if (const char *e = getenv("RT_SAH_DEPTH_MARGIN")) margin = (uint32_t)atoi(e);
+#endif
+        depth_cap += margin;
+        const size_t lds = (size_t)n_pad * 8 + (size_t)n_leaves * 74;
+        hipLaunchKernelGGL(rt_bvh_build_sah_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, depth_cap, c->d_bvh);
+        HIP_TRY(hipGetLastError());
+        c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth_cap + 1, rt::bvh_emis_at(n_leaves, n_always + rt::kBvhLeaf * n_leaves) };
+        c->bvh_ok = true;
+        return RT_OK;
+    }
     if (n_tree <= kDeviceBuildMax && !host_small) {
         uint32_t n_pad = 2;
         while (n_pad < n_tree) n_pad *= 2;
@@ -689,8 +976,7 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     }
     uint32_t depth = 1;
     while ((1u << depth) < n_leaves) depth += 1;
-    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1, n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef,
-                            rt::bvh_emis_at(n_leaves, n_always + rt::kBvhLeaf * n_leaves) };
+    c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth + 1, rt::bvh_emis_at(n_leaves, n_always + rt::kBvhLeaf * n_leaves) };
     c->bvh_ok = true;
     return RT_OK;
 }

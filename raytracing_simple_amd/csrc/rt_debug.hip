@@ -267,11 +267,12 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
     return rc != RT_OK ? rc : rt::build_bvh(c, c->scene.n_spheres, c->stream, true);
 }
 static int dbg_set_tree_shape(rt_ctx *c, int v) {
-    c->bvh_sah = v ? 1 : 0;
+    c->bvh_sah = v < 0 ? 0 : (v > 2 ? 2 : v);
     return dbg_set_bvh_min(c, c->bvh_min);          // (rebuilds the current scene's tables, re-arms the probe)
 }
-// 1: full scene uploads build the hierarchy on the host with its shape chosen by surface area (the default); 0: the device build
-// and its fixed shape for them too (what device-resident updates always use).  Takes effect at once.
+// The hierarchy's shape.  1 (default): by surface area -- uploads whose choice of form is estimated (below 1500 tree spheres) on the host,
+// larger uploads and every device-resident update on the device; 2: on the device for every upload too; 0: the fixed (halved) shape
+// everywhere.  Takes effect at once.
 RT_API int rt_debug_set_tree_shape(rt_ctx *c, int by_area) {
     if (!c) return fail(RT_ERR_ARG, "ctx is null");
     return dbg_apply(c, dbg_set_tree_shape, by_area);
@@ -358,7 +359,11 @@ RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, ui
     if (rc != RT_OK) return rc;
     counts4[0] = counts4[1] = counts4[2] = counts4[3] = 0;
     if (!c->bvh_ok) return RT_OK;
-    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.stack_depth; counts4[3] = c->bvh.root;
+    float4 hdr[2];                          // (the root pair travels in the header: a tree shaped on the device has it where only the device knows)
+    HIP_TRY(hipMemcpy(hdr, c->d_bvh, sizeof hdr, hipMemcpyDeviceToHost));
+    uint32_t last;
+    memcpy(&last, &hdr[1].w, 4);
+    counts4[0] = c->bvh.n_always; counts4[1] = c->bvh.n_leaves; counts4[2] = c->bvh.stack_depth; counts4[3] = last & 0xffffu;
     const size_t need = rt::bvh_blob_float4s(c->bvh.n_leaves, c->bvh.n_slots);
     if (blob_out) {
         if (cap_float4 < need) return fail(RT_ERR_ARG, "blob needs %zu float4", need);

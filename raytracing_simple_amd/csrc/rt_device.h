@@ -40,7 +40,7 @@ struct SceneTables {
 // It only decides WHICH spheres a ray is tested against: every test that is made is the reference's arithmetic, and
 // the selection rule (smallest distance, lowest scene index among equals; lowest blocking index for shadow rays) is
 // the reference's loop order restated, so frames and counters do not change.  One blob in HBM:
-//   hdr[0] = { root box centre, half diagonal }   hdr[1] = { min |rad|, max |rad|, 1 / (2 min |rad|), - }
+//   hdr[0] = { root box centre, half diagonal }   hdr[1] = { min |rad|, max |rad|, 1 / (2 min |rad|), bits(root pair | complaints << 16) }
 //   slots[j] = { p, rad*rad } for j < n_always: the spheres that stay outside the tree (large or non-finite), in
 //            scene order, swept by every ray as before; then kBvhLeaf per leaf, in leaf order (padded with NaN records)
 //   index[j] = scene index of slot j (u32; read from HBM / L2 for accepted candidates only)
@@ -49,7 +49,7 @@ struct SceneTables {
 //            child first and keeps the other on a per-lane stack.  Inner node m - 1 is the one that splits its range
 //            of leaves in front of leaf m, wherever that split lies: the device build halves every range (root = pair
 //            n_leaves / 2 - 1), the host build of a full scene upload cuts by surface area (rt_bvh.hip); BvhTables::root says
-//            which pair the walk starts at (a tree of one leaf has no pairs).
+//            which pair the walk starts at -- it travels in the header (hdr[1].w), because a tree shaped on the device has it where the host cannot see it (a tree of one leaf has no pairs: kBvhLeafRef).
 //   emis[j], colr[j] = the material records of slot j ({ emission, bits(refl) }, { colour, radius }: SceneTables' records in SLOT
 //            order): a closest hit reads its material by the slot the walk ended on -- one round trip to L2 instead of two
 //            (scene index first, then the record by index)
@@ -61,8 +61,7 @@ constexpr uint32_t kBvhLeafRef = 0x8000u;
 struct BvhTables {
     const float4 *blob;     // hdr | slots | index | pairs | emis by slot | colr by slot
     uint32_t n_always, n_leaves, n_slots;
-    uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1)
-    uint32_t root;          // the root's pair (kBvhLeafRef: the tree is one leaf)
+    uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1; an upper bound for trees shaped on the device)
     uint32_t emis_at;       // bvh_emis_at(n_leaves, n_slots), formed on the host: the kernel has no scalar registers to spare for it
 };
 // offsets into the blob, in float4 units

@@ -38,8 +38,8 @@ struct rt_ctx {
     size_t bvh_stage_cap = 0;           // float4
     hipEvent_t bvh_stage_ev = nullptr;
     bool bvh_stage_used = false;
-    int bvh_sah = 1;                    // full scene uploads build the hierarchy on the host with its shape chosen by surface area (rt_bvh.hip)
-    uint32_t bvh_sah_root = 0;
+    int bvh_sah = 1;                    // the hierarchy's shape is chosen by surface area (rt_bvh.hip): 1 = uploads below kAlwaysWalkFrom tree spheres on the host,
+                                        // larger uploads and every device-resident update on the device; 2 = the device for uploads too; 0 = the fixed (halved) shape
     uint32_t bvh_n_tree = 0;            // spheres inside the tree (the slots are padded to whole leaves)
     // surface-area sums of a host-built tree (rt_bvh.hip): what a random line through the root box is expected to visit --
     // pair steps (inner nodes, the root counted once) and leaves; the estimate that settles hierarchy against sweep without a launch
@@ -150,6 +150,7 @@ int wait_all(rt_ctx *c);                            // host waits for everything
 const double *create_breakdown();                   // host ms of the last rt_create by phase (rt_debug_create_breakdown)
 
 // ---- rt_launch.hip: one launch of the render kernel ----
+constexpr uint32_t kAlwaysWalkFrom = 1500;          // tree spheres from which the hierarchy is walked without estimate or measurement (rt_launch.hip)
 constexpr size_t kLdsMax = 152 * 1024;              // what the kernels' dynamic-LDS attribute allows
 LaunchParams make_params(rt_ctx *c, int n_samples);
 const Instance *instances(bool fast, int *count);

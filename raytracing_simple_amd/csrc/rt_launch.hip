@@ -489,7 +489,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
     // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
     // scene measured, open or packed, and one pass of the sweep at 1080p costs 2.6 ms at 1024 spheres,
     // 28 ms at 4096, 138 ms at 8192, seconds beyond LDS
-    if (c->bvh_n_tree >= 1500u || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
+    if (c->bvh_n_tree >= kAlwaysWalkFrom || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
     if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
         return launch_priced(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);
     probe_poll(c, false);

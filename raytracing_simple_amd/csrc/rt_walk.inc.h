@@ -45,6 +45,8 @@
 // root box and |r| by the largest radius in the tree; the slab arithmetic's own rounding is inside the pad's linear
 // term (bvh_misses below).  A lane whose direction is not a unit vector to within 10^-3, or not finite, gets an
 // infinite pad: it visits everything, like the plain sweep.  Comparisons are written so that NaN means "visit".
+// the pair the walk starts at (kBvhLeafRef: the tree is one leaf): the low half of the header's last word
+RT_DEV uint32_t bvh_root(const float4 *s_hdr) { return __float_as_uint(s_hdr[1].w) & 0xffffu; }
 struct BvhRay {
     V3 clo, chi, inv;      // 1 / direction and -(origin +- pad) / direction: a slab distance is one fused multiply-add
     float tback;           // how far behind the origin / beyond the current best a box still counts
@@ -298,9 +300,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // (the scene index of a slot is only read for a candidate that passes the test: from HBM / L2, not staged)
     const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + bvh_index_at(n_slots));
     float4 *s_hdr = lds;
-    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
-    const uint32_t root_ref = n_pairs ? P.bvh.root : kBvhLeafRef;
 #if RT_OPT_GLOBAL_TABLES
     const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
     const float4 *s_slots = P.bvh.blob + bvh_slots_at();
@@ -310,6 +310,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     float4 *s_colr = s_emis;
 #else
     // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane]) | lights | materials
+    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
     float4 *s_pairs = s_hdr + 2;
     float4 *s_slots = s_pairs + 4 * n_pairs;
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
@@ -669,7 +670,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     ctl.set_st(kClosest);
                 }
                 R = bvh_ray(s_hdr, o, d);
-                W.cur = root_ref;
+                W.cur = bvh_root(s_hdr);           // (from the header the ray set-up has just read: whoever built the tree put it there)
                 W.sp = 0;
             }
         }
@@ -766,7 +767,6 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
     float4 *s_pairs = s_hdr + 2;
     float4 *s_slots = s_pairs + 4 * n_pairs;
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_slots + n_slots);
-    const uint32_t root_ref = n_pairs ? P.bvh.root : kBvhLeafRef;
     const int tid = threadIdx.x;
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
     {
@@ -787,7 +787,7 @@ extern "C" __global__ void __launch_bounds__(256) RT_WALK_RAYS_KERNEL_NAME(const
         unsigned long long roots = 0;
         uint4 res;
         const BvhRay R = bvh_ray(s_hdr, o, d);
-        uint32_t cur = root_ref, w_slot = 0, w_idx;
+        uint32_t cur = bvh_root(s_hdr), w_slot = 0, w_idx;
         int sp = 0;
         float w_far;
         // the two kinds of ray diverge here; each sweep's ballots see the lanes of its own kind

@@ -46,13 +46,14 @@ def _same(got, want):
                                    lambda: scenes.mirror_box(64), lambda: scenes.demo_plus(16),
                                    lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET)])
 def test_device_built_tables_are_a_valid_hierarchy(maker):
-    """Both builds: the device's (leaf ranges halved; what device-resident updates get) and the host's of a full scene upload
-    (the shape chosen by surface area, leaves of up to 8; the default) -- every leaf reached once from the root pair the tables
-    name, every sphere in one leaf, inside every box above it, lowest scene indices right, the stack deep enough."""
+    """All three builds: the device's fixed shape (leaf ranges halved), the host's of a full scene upload (the shape chosen by surface
+    area, leaves of up to 8; the default below 1500 tree spheres) and the device's by surface area (cuts between whole leaves; what
+    updates and large uploads get) -- every leaf reached once from the root pair the header names, every sphere in one leaf, inside
+    every box above it, lowest scene indices right, the stack deep enough."""
     sph, _, _ = maker()
     sph = api.as_spheres(sph)
-    leaves = {}
-    for by_area in (0, 1):
+    leaves, area = {}, {}
+    for by_area in (0, 1, 2):
         with api.RtContext(64, 64, diag=True) as ctx:
             ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
             ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
@@ -62,9 +63,14 @@ def test_device_built_tables_are_a_valid_hierarchy(maker):
         assert bvh_check.check_structure(sph, b) == []
         assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(sph)
         leaves[by_area] = b["n_leaves"]
+        area[by_area] = bvh_check.sum_of_box_areas(b)
         if by_area == 0 and b["n_leaves"] > 1:
             assert b["root"] == b["n_leaves"] // 2 - 1
     assert leaves[0] <= leaves[1] <= 2 * leaves[0]              # partial leaves only where they pay (below 128 tree spheres both are the device's)
+    assert leaves[2] == leaves[0]                               # the device cuts between whole leaves
+    n_tree = len(sph) - b["n_always"]
+    if n_tree >= 128:                                           # (below that every build is the halved shape)
+        assert area[2] < area[0] and area[2] < 1.1 * area[1]    # what the walk pays for: the boxes a ray can meet
 
 
 @pytest.mark.parametrize("maker,w,h,spp", [
@@ -197,9 +203,9 @@ def test_moving_spheres_rebuild_the_hierarchy_on_the_stream():
 
 
 def test_an_update_of_the_whole_scene_stays_on_the_stream():
-    """rt_update_spheres_async that rewrites EVERY record (the usual animated scene) is still an update: the device build
-    on the stream (fixed shape: root pair = n_leaves / 2 - 1, full leaves), never the host build of rt_set_scene, which
-    waits for the staging buffer's previous copy (the range must not decide)."""
+    """rt_update_spheres_async that rewrites EVERY record (the usual animated scene) is still an update: a device build on the
+    stream -- full leaves, the shape chosen by surface area by the device's own kernel --, never the host build of rt_set_scene,
+    which waits for the staging buffer's previous copy (the range must not decide)."""
     sph, orig, target = scenes.random_spheres(300)
     sph = api.as_spheres(sph).copy()
     w, h, spp = 64, 48, 2
@@ -215,11 +221,39 @@ def test_an_update_of_the_whole_scene_stays_on_the_stream():
         b = bvh_check.read_bvh(ctx)
         n_tree = b["n_slots"] - b["n_always"]
         assert b["n_leaves"] == (int((np.abs(sph["rad"]) <= 16 * np.median(np.abs(sph["rad"]))).sum()) + 7) // 8
-        assert n_tree == 8 * b["n_leaves"] and b["root"] == b["n_leaves"] // 2 - 1
-        assert shaped["root"] != shaped["n_leaves"] // 2 - 1 or shaped["n_leaves"] != b["n_leaves"]     # (the upload's tree was the shaped one)
+        assert n_tree == 8 * b["n_leaves"]              # (the host's build of the upload makes partial leaves, the device's never)
         assert bvh_check.check_structure(sph, b) == []
         got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
         _same(got, O.render(sph, cam, w, h, spp))
+
+
+def test_updates_get_the_shape_by_surface_area():
+    """A moving scene's frames walk a tree shaped by surface area as an upload's do (the device's own build): fewer pair steps per
+    ray than through the halved shape, the same bits."""
+    sph, orig, target = scenes.random_spheres(1024)
+    sph = api.as_spheres(sph).copy()
+    w, h, spp = 160, 96, 2
+    cam = host.compute_camera(orig, target, w, h)
+    moved = sph.copy()
+    moved["p"][2:, 0] += np.float32(0.75)
+    want = O.render(moved, cam, w, h, spp)
+    steps = {}
+    for by_area in (0, 1):
+        with api.RtContext(w, h, diag=True) as ctx:
+            ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
+            ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            ctx.update_spheres(0, moved)
+            b = bvh_check.read_bvh(ctx)
+            assert bvh_check.check_structure(moved, b) == []
+            got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            _same(got, want)
+            ctx.set_mode(api.instance_mode("rt_trace_parity_pairs_census"))
+            ctx.reset()
+            ctx.render_pass(spp, copy=False)
+            steps[by_area] = bvh_check.counters_raw(ctx)[21]        # pair steps, summed over lanes
+    assert steps[1] < 0.95 * steps[0]
 
 
 def test_fast_mode_with_the_hierarchy_is_as_close_as_fast_mode_without():
