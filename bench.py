@@ -571,12 +571,24 @@ def main():
                         cl.reset_async(); cl.render_pass(16, copy=False)
                     dt3 = time.perf_counter() - t0
                     st3, ch3, kern3 = cl.stats(), cl.scene_choice(), cl.last_kernel
+                    # the same scene MOVING: every frame rewrites the records on the device (rt_update_spheres_async, the whole range) and
+                    # the hierarchy is rebuilt on the stream -- its shape chosen by surface area by the device's own build kernel
+                    moved3 = api.as_spheres(sph3).copy()
+                    moved3["p"][1:, 0] += np.float32(0.25)
+                    upd_ms = []
+                    for k in range(5):
+                        cl.update_spheres(0, moved3 if k % 2 == 0 else api.as_spheres(sph3))
+                        cl.reset_async(); cl.render_pass(16, copy=False)
+                        upd_ms.append(cl.stats()["last_kernel_ms"])
+                    moving3 = {"what": "frames of the same scene after rt_update_spheres_async of every record (tree rebuilt on the stream by rt_bvh_build_sah_kernel)",
+                               "kernel_ms": round(sorted(upd_ms[1:])[len(upd_ms[1:]) // 2], 4), "kernel": cl.last_kernel}
                 first["large_scene"] = first_frame(api, mode, sph3, cam3, W, H, 16, st3["last_kernel_ms"])
                 cen3 = walk_census(api, sph3, cam3, W, H, 16) if "_pairs" in kern3 else None
                 large = {"workload": "C3: 1024 random spheres, 1920x1080, 16 spp, default seed stream", "steps": k3,
                          "ms_per_step": round(dt3 / k3 * 1e3, 4), "value": round((st3["samples"] + st3["shadow_rays"]) * k3 / dt3 / 1e6, 1),
                          "unit": "Mray/s", "kernel": kern3, "kernel_ms": round(st3["last_kernel_ms"], 4),
                          "roofline": roofline_block(kern3, st3["last_kernel_ms"], st3["sphere_tests"], W * H, len(sph3), "c3", args.mode, census=cen3, choice=ch3),
+                         "moving_scene": moving3,
                          "note": "frames, seeds and counters are the same bits through either form (DESIGN.md section 5; "
                                  "tests/test_gpu_parity.py test_baseline_configurations_at_full_size_bit_exact); bench.py --workload c3 is the full record"}
             except api.RtError as e:

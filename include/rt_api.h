@@ -145,9 +145,10 @@ RT_API void rt_destroy(rt_ctx *ctx);                              /* freeBuffer,
  * The 44-byte records go to the device as they are and a small kernel there builds the tables the
  * render kernel reads (centre | radius^2, emission | material, colour | radius, and the light list
  * SampleLights walks, with 4*pi*radius^2 -- all in binary32, the reference's own operations).
- * Scenes with 56 and more small spheres also get a hierarchy over them (a second kernel on the same stream; beyond
- * 8192 such spheres it is built on the host from the records and copied): it changes which instance renders the scene,
- * never the result (rt_last_kernel, rt_scene_choice).  Up to RT_MAX_SPHERES spheres; tables that do not fit LDS are read
+ * Scenes with 56 and more small spheres also get a hierarchy over them, its shape chosen by surface area (below 1500 such
+ * spheres on the host, which then also knows whether walking it will pay; up to 8192 by a second kernel on the same stream, the
+ * caller held for microseconds; beyond that built on the host from the records and copied): it changes which instance renders
+ * the scene, never the result (rt_last_kernel, rt_scene_choice).  Up to RT_MAX_SPHERES spheres; tables that do not fit LDS are read
  * from HBM / L2.  Ordered after every launch issued on this context; no device-wide synchronisation.  A refused
  * scene (bad arguments, too many spheres) leaves the previous one in place.                                                  */
 RT_API int rt_set_scene(rt_ctx *ctx, const rt_sphere *spheres, uint32_t count);
@@ -157,7 +158,8 @@ RT_API int rt_set_scene(rt_ctx *ctx, const rt_sphere *spheres, uint32_t count);
  * host wait: the records are staged through page-locked memory, copied and the tables rebuilt by the
  * device-side kernel, all asynchronously on `hip_stream` (a hipStream_t; NULL = the default stream, as
  * for rt_render_async); launches issued later on this context see the new scene (tables and, for large scenes, the
- * hierarchy are rebuilt behind the copy; the measured choice between hierarchy and sweep is kept).  The sphere count
+ * hierarchy are rebuilt behind the copy -- the hierarchy by the device's own build by surface area, never on the host; the
+ * choice between hierarchy and sweep is kept).  The sphere count
  * does not change.  `spheres` may be reused as soon as the call returns.                        */
 RT_API int rt_update_spheres_async(rt_ctx *ctx, uint32_t first, uint32_t count, const rt_sphere *spheres,
                                    void *hip_stream);
