@@ -161,9 +161,8 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
     if pm:
         out["traffic"] = pm.get("hbm_bytes_per_launch")
         if out["traffic"] and out["traffic"] > 1.15 * alg_bytes:
-            out["traffic_note"] = ("above the algorithmic bytes because pixels are dealt to wavefronts by cost in runs of 8: a wavefront's 64 pixels are 8 "
-                                   "runs scattered over a 32x32 region, so its per-pixel loads and stores (seeds 8 B, colour 12 B, pixel 4 B, cost 2 B) go out "
-                                   "in 16-96 byte segments rather than whole lines (DESIGN.md section 5); the kernel is VALU-bound at under 1 % of the HBM peak")
+            out["traffic_note"] = ("above the algorithmic bytes: a wavefront's 8x8 square stores its colours (12 B per pixel) and seeds in 32-96 byte segments, "
+                                   "not whole lines; the kernel is VALU-bound at under 1 % of the HBM peak")
         if pm.get("valu_insts_per_launch"):
             # what the VALU actually issues (PMC of the committed profile, same command): the time its instructions
             # need at full issue rate, and how much of this run's kernel time that is
@@ -496,7 +495,7 @@ def main():
     other, target, in_library, large, unseen, first = None, None, None, None, None, None
     if world == 1 and not args.no_extras:
         # The headline renders the SAME frame K times (reset + SPP passes, fixed seed stream: what makes it checkable against the
-        # oracle), and the library schedules a launch from what the launch before cost (tile order, deal of pixels) -- costs that
+        # oracle), and the library schedules a launch from what the launch before cost (tile order) -- costs that
         # are exact for a frame rendered again.  The same launch on passes it has NOT seen: SPP more passes of the running image
         # per launch, no reset in between (what a progressive renderer does all day).
         ctx.set_pixel_buffer(0, 0)
@@ -510,7 +509,7 @@ def main():
         st_b = ctx.stats()
         rays_u = (st_b["samples"] + st_b["shadow_rays"]) - (st_a["samples"] + st_a["shadow_rays"])
         unseen = {"what": "launches of %d passes continuing the running image (passes %d .. %d): random numbers the costs behind the tile order and "
-                          "the deal of pixels have never seen" % (SPP, SPP, 7 * SPP - 1),
+                          "the tile order has never seen" % (SPP, SPP, 7 * SPP - 1),
                   "launches": 6, "kernel_ms": round(sum(ms_u) / 6, 4), "value": round(rays_u / sum(ms_u) / 1e3, 1), "unit": "Mray/s (kernel time)",
                   "headline_kernel_ms": round(kernel_ms, 4)}
         first = {"what": "a new scene's first frame on a warm GPU: fresh context, rt_set_scene, rt_set_camera, one blocking frame (device ms between "
@@ -574,13 +573,13 @@ def main():
                     # the same scene MOVING: every frame rewrites the records on the device (rt_update_spheres_async, the whole range) and
                     # the hierarchy is rebuilt on the stream -- its shape chosen by surface area by the device's own build kernel
                     moved3 = api.as_spheres(sph3).copy()
-                    moved3["p"][1:, 0] += np.float32(0.25)
                     upd_ms = []
-                    for k in range(5):
-                        cl.update_spheres(0, moved3 if k % 2 == 0 else api.as_spheres(sph3))
+                    for k in range(6):
+                        moved3["p"][1:, 0] += np.float32(0.05)          # (every sphere but the ground drifts: an animation's frame-to-frame step)
+                        cl.update_spheres(0, moved3)
                         cl.reset_async(); cl.render_pass(16, copy=False)
                         upd_ms.append(cl.stats()["last_kernel_ms"])
-                    moving3 = {"what": "frames of the same scene after rt_update_spheres_async of every record (tree rebuilt on the stream by rt_bvh_build_sah_kernel)",
+                    moving3 = {"what": "frames of the same scene with every sphere drifting 0.05 per frame: rt_update_spheres_async of every record, tree rebuilt on the stream by rt_bvh_build_sah_kernel, tile order sorted again from the frame before",
                                "kernel_ms": round(sorted(upd_ms[1:])[len(upd_ms[1:]) // 2], 4), "kernel": cl.last_kernel}
                 first["large_scene"] = first_frame(api, mode, sph3, cam3, W, H, 16, st3["last_kernel_ms"])
                 cen3 = walk_census(api, sph3, cam3, W, H, 16) if "_pairs" in kern3 else None

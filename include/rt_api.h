@@ -184,12 +184,10 @@ RT_API int rt_reset_async(rt_ctx *ctx, void *hip_stream);
  * launch that keeps seeds and the running average in registers, then one D2H copy of the
  * pixel buffer into `out_host` (the full image for an unsharded context, the local rows for
  * a sharded one).  out_host may be NULL to skip the copy.  Blocking.
- * Scheduling, never results: every launch leaves what each pixel and each tile cost it, and long launches (8 passes and
- * more) of the same scene and camera use that -- the second deals the pixels of every 32x32 region to wavefronts by cost
- * (in runs of 8), the third also walks the tiles heaviest first -- and a launch of 24 passes or more that has no costs to go
- * by renders 4 of its passes first to get them, then the rest heaviest first -- so a scene's first two frames are a few percent
- * slower than its later ones.  What a launch cost predicts the next one exactly only if it is the same frame again (reset, same passes);
- * the defaults are the ones that pay on passes not seen before.                                      */
+ * Scheduling, never results: every launch leaves what each tile cost it, and the next long launch (8 passes and more) walks
+ * the tiles heaviest first (sorted again from the last launch's costs whenever the scene or the camera has changed); a launch
+ * of 24 passes or more that has no costs to go by renders 4 of its passes first to get them, then the rest heaviest first --
+ * so a scene's first frame is a few percent slower than its later ones.                                                     */
 RT_API int rt_render_pass(rt_ctx *ctx, uint32_t *out_host, int n_samples);
 
 /* Page-lock the host buffer that rt_render_pass copies into (the host's `pPixels`,

@@ -66,11 +66,8 @@ RT_API int rt_debug_set_choice_estimate(rt_ctx *ctx, int on);  /* 0: the surface
 RT_API int rt_debug_bvh_pick(rt_ctx *ctx);   /* 0 = not decided yet, 1 = the hierarchy, 2 = the plain sweep (of this scene, by measurement) */
 RT_API int rt_debug_read_bvh(rt_ctx *ctx, float *blob_out, uint32_t cap_float4, uint32_t *counts4);
 RT_API int rt_debug_set_wg_waves(rt_ctx *ctx, int waves);          /* 0 = automatic, 1 or 4 wavefronts per workgroup */
-RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order; 1 = heavy first; | homes << 8: workgroup numbers equal modulo `homes` (1..8) render the tiles of one 32x32 region (1 = plain heavy-first order, the default) */
+RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order; 1 = heavy first (the default) */
 RT_API int rt_debug_read_tile_order(rt_ctx *ctx, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid);
-RT_API int rt_debug_set_pixel_deal(rt_ctx *ctx, int rows);         /* 0 = every wavefront renders its 8x8 square (no deal by cost); else rows of a region of 32 x rows pixels (8 .. 128) | pixels of a run that stays on adjacent lanes (1, 2, 4, 8; 0 = keep) << 8 */
-/* the deal in use -- per region 32 * rows positions dy * 32 + dx in rank order; *valid = rows of a region, 0 = no deal -- and the per-pixel costs of the last launch */
-RT_API int rt_debug_read_pixel_deal(rt_ctx *ctx, uint16_t *deal_out, size_t deal_cap, uint16_t *cost_out, size_t cost_cap, int *valid);
 
 /* raw diagnostic counters (section census of the stamped instances; valid after rt_get_stats) */
 RT_API int rt_debug_counters(rt_ctx *ctx, unsigned long long *out24);

@@ -214,10 +214,6 @@ RT_API int rt_create_sharded(rt_ctx **out, int w, int h, int device, int rank, i
         if (c->n_tiles) {
             HIP_TRY(hipMalloc(&c->d_tile_cost, (size_t)c->n_tiles * sizeof(uint32_t)));
             HIP_TRY(hipMalloc(&c->d_order, (size_t)c->n_tiles * sizeof(uint32_t)));
-            // (regions of 8 rows need the most entries: every region is padded to whole rows of 32 pixels)
-            const size_t deal_entries = (size_t)((w + rt::kRegionW - 1) / rt::kRegionW) * rt::kRegionW * (size_t)(((rows + 7) / 8) * 8 + rt::kMaxDealRows);
-            HIP_TRY(hipMalloc(&c->d_pixel_cost, ((size_t)rows * w + 4) * sizeof(uint16_t)));
-            HIP_TRY(hipMalloc(&c->d_deal, deal_entries * sizeof(uint16_t)));
         }
         lap(2);
         // function attributes (dynamic-LDS limit) are per device, not per context
@@ -273,8 +269,6 @@ RT_API void rt_destroy(rt_ctx *c) {
         (void)hipFree(c->d_stats);
         (void)hipFree(c->d_tile_cost);
         (void)hipFree(c->d_order);
-        (void)hipFree(c->d_pixel_cost);
-        (void)hipFree(c->d_deal);
         (void)hipFree(c->d_timelog);
         (void)hipFree(c->d_wavelog);
         (void)hipFree(c->d_blocklog);
@@ -328,7 +322,6 @@ RT_API int rt_set_scene(rt_ctx *c, const rt_sphere *spheres, uint32_t count) {
     c->is_light.assign(c->scene_cap, 0);
     c->h_spheres.assign(spheres, spheres + count);
     c->cost_valid = c->order_valid = false;
-    c->pixel_cost_valid = c->deal_valid = false;
     rearm_probe(c);                     // a new scene: hierarchy or plain sweep is measured again
     rc = upload_spheres(c, 0, count, spheres, count, c->stream, true);
     if (rc != RT_OK) {
@@ -349,9 +342,8 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
-    // the last frames' costs still predict this one (moving spheres): the order stays, and is sorted again from
-    // fresh costs after a few changes
-    if (++c->order_age >= 8) c->order_valid = c->deal_valid = false;
+    // the last frame's costs still predict this one (moving spheres): the next long launch sorts the order again from them
+    c->order_valid = false;
     rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream, false);
     if (rc == RT_OK) rearm_probe_if_changed(c);
     return rc;
@@ -361,7 +353,7 @@ RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
     if (c->multi) return rt::multi_set_camera(c, cam);
     if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) {
-        if (++c->order_age >= 8) c->order_valid = c->deal_valid = false;        // a moved camera: order and deal stay for a few frames, then are sorted again
+        c->order_valid = false;            // a moved camera: the next long launch sorts the order again from the last frame's costs
     }
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;

@@ -182,15 +182,7 @@ static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v & 0xffffff; c->coop_kmax = v >> 24; return RT_OK; }
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
-static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; if (v >> 8) c->order_homes = v >> 8; c->order_valid = false; return RT_OK; }
-static int dbg_set_deal(rt_ctx *c, int v) {       // 0 = off; rows of a region | pixels of a run << 8
-    c->use_deal = v ? 1 : 0;
-    if (v & 255) c->deal_rows = v & 255;
-    if (v >> 8) c->deal_group = v >> 8;
-    c->deal_valid = false;
-    c->cost_valid = c->order_valid = false;
-    return RT_OK;
-}
+static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
 static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }
 
 // tuning knob (not part of the contract): 0 = automatic, 1 = free-running, n = gate of n lanes
@@ -214,30 +206,9 @@ RT_API int rt_debug_set_wg_waves(rt_ctx *c, int waves) {    // 0 = automatic, 1 
     if (!c || (waves != 0 && waves != 1 && waves != 4)) return fail(RT_ERR_ARG, "waves %d", waves);
     return dbg_apply(c, dbg_set_wg, waves);
 }
-RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour); 1: heavy first; | homes << 8 (1 .. 8; 1 = regions not kept on one XCD)
-    if (!c || on < 0 || (on >> 8) > 8) return fail(RT_ERR_ARG, "ctx is null / order %d", on);
+RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour); 1: heavy first
+    if (!c || on < 0 || on > 1) return fail(RT_ERR_ARG, "ctx is null / order %d", on);
     return dbg_apply(c, dbg_set_order, on);
-}
-RT_API int rt_debug_set_pixel_deal(rt_ctx *c, int rows) {     // 0: every wavefront renders its 8x8 square (the round-2 behaviour); else rows of a region (8 .. 128) | pixels of a run (1, 2, 4, 8; 0 = keep) << 8
-    const int r = rows & 255, g = rows >> 8;
-    if (!c || rows < 0 || (rows != 0 && r != 8 && r != 16 && r != 32 && r != 64 && r != 128) || (g != 0 && g != 1 && g != 2 && g != 4 && g != 8))
-        return fail(RT_ERR_ARG, "rows %d, run %d", r, g);
-    return dbg_apply(c, dbg_set_deal, rows);
-}
-// the deal in use (valid = 0: none) -- per region 256 positions dy * 32 + dx in rank order -- and the per-pixel costs of the last launch
-RT_API int rt_debug_read_pixel_deal(rt_ctx *c, uint16_t *deal_out, size_t deal_cap, uint16_t *cost_out, size_t cost_cap, int *valid) {
-    if (!c || c->multi) return fail(RT_ERR_ARG, "null / multi-device context");
-    int rc = select_device(c);
-    if (rc != RT_OK) return rc;
-    rc = wait_all(c);
-    if (rc != RT_OK) return rc;
-    const size_t regions = (size_t)((c->w + rt::kRegionW - 1) / rt::kRegionW) * (size_t)((c->local_rows + c->deal_rows - 1) / c->deal_rows);
-    const size_t per_region = (size_t)rt::kRegionW * c->deal_rows;
-    const size_t n_deal = regions * per_region < deal_cap ? regions * per_region : deal_cap, n_cost = (size_t)c->local_rows * c->w < cost_cap ? (size_t)c->local_rows * c->w : cost_cap;
-    if (deal_out && n_deal && c->d_deal) HIP_TRY(hipMemcpy(deal_out, c->d_deal, n_deal * sizeof(uint16_t), hipMemcpyDeviceToHost));
-    if (cost_out && n_cost && c->d_pixel_cost) HIP_TRY(hipMemcpy(cost_out, c->d_pixel_cost, n_cost * sizeof(uint16_t), hipMemcpyDeviceToHost));
-    if (valid) *valid = c->deal_valid ? c->deal_rows : 0;
-    return RT_OK;
 }
 // the tile order in use (valid = 0: none, tiles run in their natural order) and the per-tile costs of the last launch
 RT_API int rt_debug_read_tile_order(rt_ctx *c, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid) {

@@ -15,8 +15,6 @@ constexpr int kTileH = 8;
 constexpr int kMaxDepth = 8;        // .cl:320 (depth > 7 ends the path)
 constexpr int kStatReplicas = 64;    // work counters are summed into 64 separate 64-byte lines
 constexpr int kMaxK2Table = 1024;   // running-average reciprocals kept in LDS up to this many passes per launch
-constexpr int kRegionW = 32;        // the pixels of a region of 32 x deal_rows pixels are dealt to its wavefronts by cost (LaunchParams::deal)
-constexpr int kMaxDealRows = 128;
 
 // Sphere tables in HBM, written once by rt_set_scene and staged into LDS by every workgroup.
 //   geom[i] = { p.x, p.y, p.z, rad*rad }      closest-hit / any-hit loops read only this
@@ -102,14 +100,6 @@ struct LaunchParams {
     int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
     const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order
     uint32_t *tile_cost;    // per tile: wall-clock ticks (10 ns) of its slowest wavefront, written by every launch (or null)
-    // Pixels dealt to wavefronts by cost (rt_order_pixels_kernel): the pixels of every region of 32 x deal_rows pixels, sorted
-    // by the loop trips the last launch spent on them, so that a wavefront renders 64 pixels of similar cost -- and of a similar
-    // kind: sky with sky, glass with glass -- instead of an 8x8 square that straddles them, and the four wavefronts of a
-    // workgroup finish together.  Rank r of a region goes to the region's 8-row band r / 256, wavefront (r / 64) % 4, lane r % 64.
-    const uint16_t *deal;   // [region][32 * deal_rows]: the region's pixels (dy * 32 + dx) in descending order of cost.  null = 8x8 squares
-    int deal_rows;          // rows of a region: 8, 16, 32, 64 or 128
-    uint16_t *pixel_cost;   // per local pixel (lrow * w + x): loop trips this launch spent on it, saturated -- one per closest-hit ray in the sweep
-                            // kernels, one per ray (closest-hit or shadow) in the hierarchy walk --, or null
     // diagnostics build only (null in the product library): launch sequence number and the buffers the
     // instrumented instance logs device wall-clock intervals into (tools/gather_stress.py)
     unsigned long long *timelog;   // [seq][8]: min start, max end of the launch (s_memrealtime, 100 MHz), kind, tag, ...

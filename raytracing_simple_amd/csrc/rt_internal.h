@@ -72,20 +72,7 @@ struct rt_ctx {
     uint32_t cost_tiles = 0;            // tile count of the launch the costs come from
     int wg_waves = 0;                   // diagnostics knob: 0 = automatic, 1 / 4 = force the workgroup shape
     bool cost_valid = false, order_valid = false;
-    int order_age = 0;                  // scene / camera changes since the order was sorted (it is sorted again at 8)
     int use_order = 1;
-    // pixels dealt to wavefronts by cost (rt_device.h LaunchParams::deal): per-pixel rays of the last launch, the deal derived from them
-    uint16_t *d_pixel_cost = nullptr;
-    uint16_t *d_deal = nullptr;
-    bool pixel_cost_valid = false, deal_valid = false;
-    int pixel_cost_form = 0;            // the form (1 = walk: rays per pixel, 2 = sweep: loop trips per pixel) whose launch wrote d_pixel_cost
-    int use_deal = 1, deal_rows = 32;   // rows of a region (8 .. 128)
-    int order_homes = 1;                // heavy-first order: the tiles of a region go to workgroup numbers equal modulo this (8 = one XCD per region:
-                                        // a fifth less traffic, 1 % more time -- measured, not the default); 1 = plain order
-    int deal_group = 8;                 // horizontally adjacent pixels that stay together (a run on adjacent lanes: coalesced loads and stores).
-                                        // Chosen on passes the costs have NOT seen (profiles/r03u_deal_on_unseen_passes.jsonl, tools/ab_bench.py --unseen): single
-                                        // pixels win only when the very frame the costs were measured on is rendered again; runs of 4 and 8 are
-                                        // level there, and runs of 8 keep the launch's traffic at 1.16 x what it produces (runs of 4: 1.48 x)
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
     uint32_t stage_cap = 0;             // records per slot
     int stage_next = 0;

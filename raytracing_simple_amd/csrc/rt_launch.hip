@@ -1,6 +1,6 @@
 // rt_launch.hip -- what one launch of the render kernel is made of: which kernel instance (rt_device.h Instance: arithmetic mode x
-// role x workgroup shape), its tables and LDS, the scheduling data it runs with (heavy-first tile order, pixels dealt to
-// wavefronts by cost) and, for scenes that have a hierarchy, whether it is walked or the plain sweep runs -- settled by a
+// role x workgroup shape), its tables and LDS, the scheduling data it runs with (heavy-first tile order) and, for scenes
+// that have a hierarchy, whether it is walked or the plain sweep runs -- settled by a
 // surface-area estimate at rt_set_scene, by measurement inside the estimate's band.
 #include <hip/hip_runtime.h>
 
@@ -21,31 +21,14 @@ using rt::fail;
 
 // Heavy-first order of the tiles from the costs the last launch left (rt_trace.inc.h): ONE workgroup; a counting sort over
 // 1024 cost classes (largest first; the order inside a class does not matter).
-// With n_home > 1 (rt_debug_set_tile_order; NOT the default: it saves a fifth of the launch's traffic and costs 1 % of its time)
-// the order also keeps the tiles of a REGION (region_tx x region_ty tiles: the 32 x 32 pixels whose lanes the
-// deal by cost mixes) on one XCD: workgroups are dealt to the 8 XCDs round-robin (block b and b + 8 share one: observed, not
-// promised -- only traffic depends on it), so every region gets a home ((column + 3 x row) mod n_home), each home's tiles are sorted
-// heavy first on their own, and position n_home * k + h takes the k-th tile of home h.  The wavefronts of a region then store
-// their scattered pixels, colours and seeds through ONE L2, where the partial lines meet before they leave, and read the
-// region's seeds and deal from it.  (Homes hold equally many tiles up to a region or two; the tiles beyond the shortest
-// list's length -- the cheapest ones -- follow at the end.)
-__global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t grid_x,
-                                                             uint32_t region_tx, uint32_t region_ty, uint32_t n_home) {
-    constexpr unsigned kMaxHome = 8;
+__global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *cost, uint32_t *order, uint32_t n) {
     __shared__ unsigned s_max;
-    __shared__ unsigned s_hist[kMaxHome][1024];
-    __shared__ unsigned s_len[kMaxHome], s_tail[kMaxHome], s_min;
+    __shared__ unsigned s_hist[1024];
     const unsigned tid = threadIdx.x;
     constexpr unsigned kCap = 0x1FFFFFu;            // 21 ms of ticks: cost * 1023 stays inside 32 bits
-    if (n_home < 1u || n_home > kMaxHome) n_home = 1u;
-    auto home_of = [&](uint32_t i) -> unsigned {
-        if (n_home == 1u) return 0u;
-        const uint32_t ty = i / grid_x, tx = i - ty * grid_x;
-        return (tx / region_tx + 3u * (ty / region_ty)) % n_home;       // (neighbours across AND down get different homes: a tall or a wide expensive object is spread over all of them)
-    };
     auto key_of = [&](uint32_t i) -> unsigned { return cost[i] < kCap ? cost[i] : kCap; };
     if (tid == 0) s_max = 1u;
-    for (unsigned h = 0; h < kMaxHome; ++h) s_hist[h][tid] = 0u;
+    s_hist[tid] = 0u;
     __syncthreads();
     unsigned m = 0;
     for (uint32_t i = tid; i < n; i += 1024) {
@@ -55,89 +38,18 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
     atomicMax(&s_max, m);
     __syncthreads();
     const unsigned top = s_max;
-    for (uint32_t i = tid; i < n; i += 1024) {
-        const unsigned c_ = key_of(i);
-        atomicAdd(&s_hist[home_of(i)][1023u - c_ * 1023u / top], 1u);
-    }
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&s_hist[1023u - key_of(i) * 1023u / top], 1u);
     __syncthreads();
-    if (tid < kMaxHome) {               // exclusive prefix over the classes of one home, most expensive class first
+    if (tid == 0) {                     // exclusive prefix over the classes, most expensive class first
         unsigned run = 0;
         for (int k = 0; k < 1024; ++k) {
-            const unsigned c_ = s_hist[tid][k];
-            s_hist[tid][k] = run;
+            const unsigned c_ = s_hist[k];
+            s_hist[k] = run;
             run += c_;
         }
-        s_len[tid] = run;
     }
     __syncthreads();
-    if (tid == 0) {
-        unsigned lo = 0xffffffffu;
-        for (unsigned h = 0; h < n_home; ++h) lo = s_len[h] < lo ? s_len[h] : lo;
-        s_min = lo;
-        unsigned run = lo * n_home;
-        for (unsigned h = 0; h < n_home; ++h) {
-            s_tail[h] = run;
-            run += s_len[h] - lo;
-        }
-    }
-    __syncthreads();
-    const unsigned shortest = s_min;
-    for (uint32_t i = tid; i < n; i += 1024) {
-        const unsigned c_ = key_of(i);
-        const unsigned h = home_of(i);
-        const unsigned k = atomicAdd(&s_hist[h][1023u - c_ * 1023u / top], 1u);
-        order[k < shortest ? k * n_home + h : s_tail[h] + (k - shortest)] = i;
-    }
-}
-
-// The deal of a region's pixels to its wavefronts (rt_device.h LaunchParams::deal): ONE workgroup per region of 32 x deal_rows
-// pixels sorts them by the cost the last launch left for them (rays traced; descending, ties by position) -- a bitonic sort
-// in LDS -- and writes their positions (dy * 32 + dx) in that order.  What is sorted are runs of `group` horizontally adjacent
-// pixels (1, 2, 4 or 8; key = the run's summed cost; 8 by default): a run stays on adjacent lanes, so the launch's loads and
-// stores of seeds, colours and pixels still come in segments of 8 * group .. 12 * group bytes instead of single words (with
-// single pixels the launch wrote 3.5 times the bytes it produces).  What the previous launch cost predicts the next launch only
-// as far as a pixel's EXPECTED cost goes -- single pixels sorted by the realised cost are an exact fit for the same frame rendered
-// again (same random numbers) and a slight loss on new passes; runs of 4 and 8 gain on both (profiles/r03u_deal_on_unseen_passes.jsonl).  A region that is not wholly inside the rendered rows keeps the 8x8 squares
-// (its workgroups do not all exist: ranks must not move out of their square).
-__global__ void __launch_bounds__(1024) rt_order_pixels_kernel(const uint16_t *__restrict__ cost, uint16_t *__restrict__ deal, int w, int rows,
-                                                              int regions_x, int deal_rows, int group) {
-    __shared__ uint32_t s_key[rt::kRegionW * rt::kMaxDealRows];
-    const int tid = threadIdx.x, nt = blockDim.x, n = rt::kRegionW * deal_rows;       // n pixels: a power of two
-    const int ng = n / group;                                                          // runs: a power of two as well
-    const int region = blockIdx.x, ry = region / regions_x, rx = region - ry * regions_x;
-    const int x0 = rx * rt::kRegionW, y0 = ry * deal_rows;
-    const bool whole = (x0 + rt::kRegionW <= w) && (y0 + deal_rows <= rows);
-    if (!whole) {
-        // identity: rank (band b, wavefront q, lane l) -> the pixel (q * 8 + (l & 7), b * 8 + (l >> 3)) of the wavefront's own square
-        for (int r = tid; r < n; r += nt) {
-            const int b = r >> 8, q = (r >> 6) & 3, l = r & 63;
-            deal[(size_t)region * n + r] = (uint16_t)(((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7)));
-        }
-        return;
-    }
-    for (int i = tid; i < ng; i += nt) {
-        const int p0 = i * group, dx = p0 & 31, dy = p0 >> 5;                          // (a run never crosses a row: 32 % group == 0)
-        uint32_t c_ = 0;
-        for (int j = 0; j < group; ++j) c_ += cost[(size_t)(y0 + dy) * (size_t)w + (size_t)(x0 + dx + j)];
-        s_key[i] = (c_ << 12) | (uint32_t)(4095 - i);       // descending sort of the key = heaviest run first, then lowest position
-    }
-    __syncthreads();
-    for (int k = 2; k <= ng; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < ng; i += nt) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t a = s_key[i], b = s_key[l];
-                    if ((a < b) == ((i & k) == 0)) { s_key[i] = b; s_key[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < ng; i += nt) {
-        const uint32_t p0 = (4095u - (s_key[i] & 4095u)) * (uint32_t)group;
-        for (int j = 0; j < group; ++j) deal[(size_t)region * n + (size_t)i * group + j] = (uint16_t)(p0 + (uint32_t)j);
-    }
+    for (uint32_t i = tid; i < n; i += 1024) order[atomicAdd(&s_hist[1023u - key_of(i) * 1023u / top], 1u)] = i;
 }
 
 namespace rt {
@@ -301,39 +213,12 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     const uint32_t n_tiles = grid.x * grid.y;
     const bool instance_logs_cost = (inst->flags & rt::kInstNoTileCost) == 0;
     if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
-        // pixels dealt to wavefronts by cost: every launch leaves the rays it traced per pixel; once a long launch has,
-        // the 256 pixels of each 32x8 region are sorted by them (on the device, once per scene and camera) and later
-        // launches hand rank r of a region to wavefront r / 64, lane r % 64.  The tile costs measured under the old
-        // deal no longer describe the workgroups: the heavy-first order is sorted again from the next launch's.
-        if (c->use_deal && c->d_pixel_cost && !persist) {
-            // only launches of 8 passes and more leave per-pixel costs (fewer are mostly noise, and the pricing launches and the
-            // adapter's small batches would overwrite a good plane with them); the unit is the form's own -- loop trips of the
-            // sweep kernels, rays of the walk -- so costs written by the other form are not sorted from
-            const int form_now = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal) ? 1 : 2;
-            if (c->pixel_cost_valid && c->pixel_cost_form != form_now) c->pixel_cost_valid = false;
-            if (n_samples >= 8) p.pixel_cost = c->d_pixel_cost;
-            if (c->pixel_cost_valid && !c->deal_valid && n_samples >= 4 && !natural_order) {
-                const int regions_x = (c->w + rt::kRegionW - 1) / rt::kRegionW, regions_y = (c->local_rows + c->deal_rows - 1) / c->deal_rows;
-                hipLaunchKernelGGL(rt_order_pixels_kernel, dim3((unsigned)(regions_x * regions_y)), dim3((unsigned)std::min(rt::kRegionW * c->deal_rows, 1024)), 0, stream,
-                                   c->d_pixel_cost, c->d_deal, c->w, c->local_rows, regions_x, c->deal_rows, c->deal_group);
-                HIP_TRY(hipGetLastError());
-                c->deal_valid = true;
-                c->cost_valid = c->order_valid = false;
-            }
-            if (c->deal_valid) {
-                p.deal = c->d_deal;
-                p.deal_rows = c->deal_rows;
-            }
-        }
         if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
         if (c->cost_valid && !c->order_valid && n_samples >= 8 && !natural_order) {
-            // (a region: 32 pixels across = 4 single-wavefront tiles or one 4-wavefront tile; the deal's rows down)
-            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles, grid.x,
-                               inst->waves == 1 ? 4u : 1u, (uint32_t)(c->deal_rows / rt::kTileH), (uint32_t)c->order_homes);
+            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
-            c->order_age = 0;
         }
         if (c->order_valid && !natural_order) p.order = c->d_order;
     }
@@ -366,10 +251,6 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     if (p.tile_cost && n_samples >= 4) {
         c->cost_valid = true;
         c->cost_tiles = n_tiles;
-    }
-    if (p.pixel_cost) {
-        c->pixel_cost_valid = true;
-        c->pixel_cost_form = c->last_form;
     }
     c->seeds_default = false;           // this launch has written every seed pair the context renders
     c->pixels_current = c->pixel_write != 0;
@@ -449,15 +330,14 @@ void rearm_probe_if_changed(rt_ctx *c) {
     }
 }
 
-// A long launch that would walk its tiles in image order although their costs can be had -- the first frame of a scene or camera,
-// and the frame after it, whose deal of pixels changes what a tile is -- renders 4 of its passes first (they are passes of the
-// frame like any other: progressive launches equal one launch bit for bit), which prices the tiles, and the rest heavy first.
+// A long launch that would walk its tiles in image order although their costs can be had -- the first frame of a scene --
+// renders 4 of its passes first (they are passes of the frame like any other: progressive launches equal one launch bit for bit),
+// which prices the tiles, and the rest heavy first.
 // A renderer that draws one frame per scene would otherwise never leave image order ("Heavy tiles first").
 constexpr int kPricePasses = 4, kPriceFrom = 24;
 static int launch_priced(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     const bool explicit_mode = form == 0;
-    const bool will_deal = c->use_deal && c->pixel_cost_valid && !c->deal_valid;
-    if (!explicit_mode && c->use_order && c->d_tile_cost && n_samples >= kPriceFrom && ((!c->order_valid && !c->cost_valid) || will_deal)) {
+    if (!explicit_mode && c->use_order && c->d_tile_cost && n_samples >= kPriceFrom && !c->order_valid && !c->cost_valid) {
         const int rc = launch_form(c, kPricePasses, stream, form);
         if (rc != RT_OK) return rc;
         n_samples -= kPricePasses;

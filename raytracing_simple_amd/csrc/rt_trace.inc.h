@@ -545,23 +545,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
     __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
     if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
-    // The pixel of this lane: the 8x8 square of its wavefront -- or, once a launch has left the cost of every pixel
-    // (P.deal), the pixel of this wavefront's rank in the order by cost of the region (32 x P.deal_rows pixels) the square
-    // lies in.  Which lane renders which pixel is invisible in the results: a pixel's samples, draws and arithmetic are its own.
-#if RT_OPT_WG_WAVES == 1
-    const int region_x = tile_bx >> 2, quarter = tile_bx & 3;               // four single-wavefront workgroups side by side share a band
-    const int regions_x = (int)((gridDim.x + 3u) >> 2);
-#else
-    const int region_x = tile_bx, quarter = wave;
-    const int regions_x = (int)gridDim.x;
-#endif
-    int x = region_x * kRegionW + quarter * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
-    if (P.deal) {
-        const int bands = P.deal_rows >> 3, region_y = tile_by / bands, band = tile_by - region_y * bands;
-        const unsigned id = P.deal[(size_t)(region_y * regions_x + region_x) * (size_t)(kRegionW * P.deal_rows) + (unsigned)((band * 4 + quarter) * 64 + lane)];
-        x = region_x * kRegionW + (int)(id & 31u);
-        lrow = region_y * P.deal_rows + (int)(id >> 5);
-    }
+    // The pixel of this lane: the 8x8 square of its wavefront.  (Which lane renders which pixel is invisible in the results: a pixel's
+    // samples, draws and arithmetic are its own.  Rounds 2-4 also DEALT the pixels of 32x32 regions to wavefronts by the cost the last
+    // launch had left for them; on passes the costs had not seen that gained 0 .. 2 % when the costs were fresh and lost 7 % on a moving
+    // scene, where they never are: removed in round 4, profiles/r04q_pixel_deal_*.)
+    const int x = tile_bx * kTileW + wave * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
     const int tile = lrow / P.tile_rows;
     const int y = (tile * P.nranks + P.rank) * P.tile_rows + (lrow - tile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
@@ -954,16 +942,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
     if (valid_e && Q.n_samples > 0) {
-        int le = tile_by * kTileH + (lane_e >> 3);
-        if (Q.deal) {                                                      // (the local row of a dealt pixel: read again, not kept)
-#if RT_OPT_WG_WAVES == 1
-            const int rx_e = tile_bx >> 2, q_e = tile_bx & 3, nx_e = (int)((gridDim.x + 3u) >> 2);
-#else
-            const int rx_e = tile_bx, q_e = wave, nx_e = (int)gridDim.x;
-#endif
-            const int rows_e = Q.deal_rows, bands = rows_e >> 3, ry_e = tile_by / bands, band = tile_by - ry_e * bands;
-            le = ry_e * rows_e + (int)(Q.deal[(size_t)(ry_e * nx_e + rx_e) * (size_t)(kRegionW * rows_e) + (unsigned)((band * 4 + q_e) * 64 + lane_e)] >> 5);
-        }
+        const int le = tile_by * kTileH + (lane_e >> 3);
         const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16);
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;           // .cl:560-563
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;   // .cl:579
@@ -975,9 +954,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =               // .cl:594-596
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);   // .cl:598-599
-        if (Q.pixel_cost)                                                  // what this pixel cost, in loop trips its lane took part in (one per
-            Q.pixel_cost[(size_t)le * (size_t)Q.w + (size_t)xe] =           // closest-hit ray): the next deal sorts by it
-                (uint16_t)(c_closest < 65535u ? c_closest : 65535u);
     }
 
 #endif

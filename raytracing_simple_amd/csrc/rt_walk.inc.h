@@ -365,12 +365,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
     if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
     int x = tile_bx * kTileW + wave * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
-    if (P.deal) {
-        const int bands = P.deal_rows >> 3, region_y = tile_by / bands, band = tile_by - region_y * bands;
-        const unsigned id = P.deal[(size_t)(region_y * (int)gridDim.x + tile_bx) * (size_t)(kRegionW * P.deal_rows) + (unsigned)(band * 256 + tid)];
-        x = tile_bx * kTileW + (int)(id & 31u);
-        lrow = region_y * P.deal_rows + (int)(id >> 5);
-    }
     const int rtile = lrow / P.tile_rows;
     const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
@@ -708,10 +702,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     if (valid_e && Q.n_samples > 0) {
         const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16);
         int le = tile_by * kTileH + ((int)(threadIdx.x & 63u) >> 3);
-        if (Q.deal) {                                                      // (the local row of a dealt pixel: read again, not kept)
-            const int rows_e = Q.deal_rows, bands = rows_e >> 3, ry_e = tile_by / bands, band = tile_by - ry_e * bands;
-            le = ry_e * rows_e + (int)(Q.deal[(size_t)(ry_e * (int)gridDim.x + tile_bx) * (size_t)(kRegionW * rows_e) + (unsigned)(band * 256 + (int)threadIdx.x)] >> 5);
-        }
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;
         float *colors = Q.colors;
@@ -722,11 +712,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);
-        uint16_t *pc = Q.pixel_cost;
-        if (pc) {
-            const uint32_t rays = c_closest + c_shadow;
-            pc[(size_t)le * (size_t)Q.w + (size_t)xe] = (uint16_t)(rays < 65535u ? rays : 65535u);
-        }
     }
     uint32_t n_done = valid_e ? (uint32_t)Q.n_samples : 0u;
     uint32_t t_samples = wave_sum(n_done);

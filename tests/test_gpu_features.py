@@ -265,9 +265,9 @@ def test_rt_render_second_call_costs_little_more_than_its_kernel():
 
 # ---- heavy tiles first -------------------------------------------------------------------------------------
 def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
-    """A launch of 24 passes or more that has no tile costs to go by -- the first frame of a scene, and the frame after it, whose
-    deal of pixels changes what a tile is -- renders 4 of its passes first and the rest heavy first (rt_api.hip launch_priced):
-    two launches instead of one, the same frame bit for bit; from the third frame on one launch.  Shorter frames are not split."""
+    """A launch of 24 passes or more that has no tile costs to go by -- the first frame of a scene -- renders 4 of its passes first
+    and the rest heavy first (rt_launch.hip launch_priced): two launches instead of one, the same frame bit for bit; from the
+    second frame on one launch.  Shorter frames are not split."""
     w, h = 160, 96
     sph, orig, target = scenes.demo_plus(16)
     cam = host.compute_camera(orig, target, w, h)
@@ -279,7 +279,7 @@ def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
             ctx.reset()
             _assert_same(_state(ctx, ctx.render_pass(24)), want)
             launches.append(ctx.stats()["launches"])
-        assert launches == [2, 2, 1, 1]
+        assert launches == [2, 1, 1, 1]
         ctx.set_scene(scenes.demo_plus(12)[0])                                 # another scene: priced again
         ctx.reset(); ctx.render_pass(30)
         assert ctx.stats()["launches"] == 2
@@ -293,10 +293,9 @@ def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
 
 
 def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_bit():
-    """Long launches of one scene and camera walk the tiles in descending order of the cost the launch before measured (the
-    third one on: the second deals the pixels of every region to its wavefronts by cost, which changes what a tile is).
+    """Long launches of one scene and camera walk the tiles in descending order of the cost the launch before measured.
     Scheduling only: pixels, colour plane, seeds and counters equal the oracle either way; a new scene drops the order until
-    costs exist again."""
+    costs exist again; a moved camera or an updated scene sorts it again from the last frame's costs."""
     lib = api.load_library(diag=True)
     w, h, spp = 200, 120, 8
     sph, orig, target = scenes.demo_plus(16)
@@ -318,37 +317,12 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         n8 = ((w + 7) // 8) * ((h + 7) // 8)                                   # 16 spheres: single-wavefront workgroups, 8x8 tiles
         assert not valid and len(cost) == n8 and cost[:n8].min() > 0
         ctx.reset()
-        _assert_same(_state(ctx, ctx.render_pass(spp)), want)                  # pixels dealt by cost from now on: tile costs are measured afresh
-        _, cost, valid = order_state(ctx)
-        assert not valid and cost[:n8].min() > 0
-        ctx.reset()
         _assert_same(_state(ctx, ctx.render_pass(spp)), want)                  # heavy first
-        order, cost2, valid = order_state(ctx)
+        order, _, valid = order_state(ctx)
         assert valid and sorted(order.tolist()) == list(range(len(order)))
         capped = np.minimum(cost, 0x1FFFFF).astype(np.uint64)
         cls = 1023 - (capped * 1023 // int(capped.max())).astype(np.int64)                    # the kernel's cost classes
         assert np.all(np.diff(cls[order]) >= 0)                                # most expensive class first
-        # homes = 8 (a knob: a fifth less traffic, 1 % more time): the tiles of one 32x32-pixel region (4 x 4 of these tiles: the
-        # pixels the deal mixes) run under workgroup numbers that are equal modulo 8 -- on one XCD, whose L2 their scattered
-        # stores meet in -- and each of the eight lists is sorted most expensive class first.  The lists' lengths differ by whole
-        # regions: what is beyond the shortest list's length follows at the end of the order.
-        api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (8 << 8)), lib)
-        ctx.reset()
-        _assert_same(_state(ctx, ctx.render_pass(spp)), want)
-        order8, cost3, valid = order_state(ctx)
-        assert valid and sorted(order8.tolist()) == list(range(len(order8)))
-        capped2 = np.minimum(cost2, 0x1FFFFF).astype(np.uint64)               # (sorted from the costs the launch before left)
-        cls2 = 1023 - (capped2 * 1023 // int(capped2.max())).astype(np.int64)
-        tiles_x = (w + 7) // 8
-        home = ((order8 % tiles_x) // 4 + 3 * ((order8 // tiles_x) // 4)) % 8
-        per_home = np.bincount(home, minlength=8)
-        head = 8 * int(per_home.min())
-        assert np.array_equal(home[:head], np.arange(head) % 8)
-        for x in range(8):
-            rest = order8[head:][home[head:] == x]
-            assert len(rest) == per_home[x] - per_home.min()
-            assert np.all(np.diff(cls2[np.concatenate([order8[:head][x::8], rest])]) >= 0)
-        api._check(lib.rt_debug_set_tile_order(ctx._h, 1 | (1 << 8)), lib)
         # short launches neither sort nor need an order
         ctx.reset(); ctx.render_pass(2); ctx.render_pass(6)
         _assert_same(_state(ctx, ctx.read_pixels()), want)
@@ -528,98 +502,3 @@ def test_mixed_device_lists_are_refused():
     assert e.value.code == -1 and "mixed" in str(e.value)
 
 
-def test_pixels_are_dealt_to_wavefronts_by_cost_and_no_bit_changes():
-    """Every launch leaves the rays it traced per pixel; the next long launch sorts the pixels of each region (32 x 8, 16 or 32
-    rows) by them and hands rank r to the region's band r / 256, wavefront (r / 64) % 4, lane r % 64 (rt_order_pixels_kernel).
-    The deal is a permutation of every whole region in descending order of cost, regions that hang over the image edge keep
-    their 8x8 squares, and frames, colour plane, seeds and counters are the oracle's with it and without -- for both
-    workgroup shapes, the hierarchy walk, ragged images and a sharded context."""
-    lib = api.load_library(diag=True)
-
-    def deal_state(ctx, w, rows, deal_rows):
-        regions = ((w + 31) // 32) * ((rows + deal_rows - 1) // deal_rows)
-        deal = np.zeros(regions * 32 * deal_rows, np.uint16)
-        cost = np.zeros(rows * w, np.uint16)
-        valid = C.c_int()
-        api._check(lib.rt_debug_read_pixel_deal(ctx._h, deal.ctypes.data_as(C.c_void_p), deal.size, cost.ctypes.data_as(C.c_void_p), cost.size,
-                                                C.byref(valid)), lib)
-        return deal.reshape(regions, 32 * deal_rows), cost.reshape(rows, w), valid.value
-
-    def identity(deal_rows):
-        r = np.arange(32 * deal_rows)
-        b, q, l = r >> 8, (r >> 6) & 3, r & 63
-        return (((b * 8 + (l >> 3)) << 5) | (q * 8 + (l & 7))).astype(np.uint16)
-
-    # (the last column: pixels of a run -- what is sorted are runs of 1, 2, 4 or 8 horizontally adjacent pixels, by their summed
-    # cost, and a run stays on adjacent lanes; None = the library's default, runs of 8)
-    cases = [(lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32, 1),             # single-wavefront workgroups, ragged: 200 = 6 * 32 + 8, 120 = 3 * 32 + 24
-             (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 32, None),
-             (lambda: scenes.demo_plus(16), 200, 120, 8, {}, 8, 8),
-             (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 256, 64, 8, {"wg": 4}, 16, 1),    # four-wavefront workgroups
-             (lambda: scenes.random_spheres(300), 160, 96, 8, {"walk": 1}, 32, 1),  # the hierarchy walk
-             (lambda: scenes.random_spheres(300), 160, 96, 8, {"walk": 1}, 32, 4),
-             (lambda: scenes.mirror_box(64), 96, 72, 8, {}, 32, 2)]              # cooperative any-hit
-    for maker, w, h, spp, knobs, deal_rows, run in cases:
-        knob = deal_rows | ((run or 0) << 8)
-        run = run or 8
-        sph, orig, target = maker()
-        cam = host.compute_camera(orig, target, w, h)
-        want = O.render(sph, cam, w, h, spp)
-        with api.RtContext(w, h, diag=True) as ctx:
-            if "wg" in knobs:
-                lib.rt_debug_set_wg_waves(ctx._h, knobs["wg"])
-            if "walk" in knobs:
-                ctx._check(lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
-                ctx._check(lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
-            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, knob))
-            ctx.set_scene(sph); ctx.set_camera(cam)
-            _assert_same(_state(ctx, ctx.render_pass(spp)), want)              # 8x8 squares; leaves the cost of every pixel
-            deal, cost, valid = deal_state(ctx, w, h, deal_rows)
-            st = ctx.stats()
-            # the cost of a pixel = loop trips spent on it: one per closest-hit ray, in the hierarchy walk one per ray of either kind
-            walked = "_pairs" in ctx.last_kernel          # (a scene of 56 spheres and more may be walked: the library measures)
-            assert not valid and int(cost.astype(np.int64).sum()) == st["closest_rays"] + (st["shadow_rays"] if walked else 0)
-            for _ in range(3):
-                ctx.reset()
-                _assert_same(_state(ctx, ctx.render_pass(spp)), want)          # dealt by cost (the same frame costs the same again)
-            deal, cost2, valid = deal_state(ctx, w, h, deal_rows)
-            assert valid == deal_rows
-            if ("_pairs" in ctx.last_kernel) == walked:
-                assert np.array_equal(cost2, cost)                              # the same frame costs the same again
-            regions_x = (w + 31) // 32
-            whole = 0
-            for r in range(deal.shape[0]):
-                ry, rx = divmod(r, regions_x)
-                if rx * 32 + 32 <= w and ry * deal_rows + deal_rows <= h:
-                    whole += 1
-                    assert sorted(deal[r].tolist()) == list(range(32 * deal_rows)), r
-                    c = cost[ry * deal_rows + (deal[r] >> 5).astype(int), rx * 32 + (deal[r] & 31).astype(int)].astype(int)
-                    assert np.all(np.diff(c.reshape(-1, run).sum(axis=1)) <= 0), r        # heaviest run first
-                    pos = deal[r].astype(int).reshape(-1, run)                             # a run: adjacent pixels of one row, aligned
-                    assert np.all(np.diff(pos, axis=1) == 1) and np.all(pos[:, 0] % run == 0), r
-                else:
-                    assert np.array_equal(deal[r], identity(deal_rows)), r     # a region over the edge keeps its squares
-            assert whole > 0
-            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, 0))                  # knob: squares again
-            ctx.reset()
-            _assert_same(_state(ctx, ctx.render_pass(spp)), want)
-            # progressive passes on a dealt context, and a pass count that changes the launch shape
-            ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, knob))
-            ctx.reset(); ctx.render_pass(spp); ctx.reset()
-            ctx.render_pass(3); ctx.render_pass(9); ctx.render_pass(4)
-            _assert_same(_state(ctx, ctx.read_pixels()), O.render(sph, cam, w, h, 16))
-    # sharded contexts deal their own rows
-    sph, orig, target = scenes.demo_plus(16)
-    w, h, spp = 200, 120, 8
-    cam = host.compute_camera(orig, target, w, h)
-    want = O.render(sph, cam, w, h, spp)
-    parts = []
-    for r in range(3):
-        with api.RtContext(w, h, rank=r, nranks=3, diag=True) as ctx:
-            ctx.set_scene(sph); ctx.set_camera(cam)
-            for _ in range(3):
-                ctx.reset(); px = ctx.render_pass(spp)
-            assert deal_state(ctx, w, ctx.local_rows, 32)[2] == 32
-            parts.append(px)
-    from raytracing_simple_amd import dist as rdist
-    assert np.array_equal(rdist.assemble_numpy(parts, h, w, 3, 8), want["pixels"])

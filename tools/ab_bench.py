@@ -44,7 +44,6 @@ def main():
     ap.add_argument("--skip-pixels", action="store_true", help="launches leave the packed pixels alone (rt_set_pixel_write 0)")
     ap.add_argument("--gates", default="", help="comma list of regeneration gates to sweep (mode list then = base modes)")
     ap.add_argument("--orders", default="", help="comma list of 0/1: natural tile order / heavy tiles first")
-    ap.add_argument("--deal", default="", help="rt_debug_set_pixel_deal value for the context (rows | run << 8; 0 = 8x8 squares); default: the library's")
     ap.add_argument("--unseen", action="store_true", help="time launches on passes not rendered before (three launches continuing the image after each "
                                                             "reset) instead of the same frame again: what a schedule derived from the last launch's costs "
                                                             "is worth when those costs are predictions, not answers")
@@ -72,8 +71,6 @@ def main():
                 lib.rt_debug_set_coop_min(ctx._h, args.coop_min)
             if args.skip_pixels:
                 ctx.set_pixel_write(False)
-            if args.deal:
-                ctx._check(lib.rt_debug_set_pixel_deal(ctx._h, int(args.deal, 0)))
             for r in range(args.rounds + 1):
                 for v in variants:
                     m, g, q, o = v
@@ -105,7 +102,7 @@ def main():
                 rays = st["samples"] + st["shadow_rays"]
                 med, mn = statistics.median(times[v]), min(times[v])
                 same = bool(np.array_equal(pix[v], base))
-                print(json.dumps({"config": cname, "mode": m, "kernel": kernels[v], "gate": g, "persist": q, "heavy_first": o, "unseen_passes": bool(args.unseen), "deal": args.deal or None, "ms_median": round(med, 4), "ms_min": round(mn, 4),
+                print(json.dumps({"config": cname, "mode": m, "kernel": kernels[v], "gate": g, "persist": q, "heavy_first": o, "unseen_passes": bool(args.unseen), "ms_median": round(med, 4), "ms_min": round(mn, 4),
                                   "Gray_s": round(rays / med / 1e6, 2), "same_as_first": same,
                                   "psnr_vs_first": None if same else round(host.psnr(pix[v], base), 2),
                                   "tests_per_sample": round(st["sphere_tests"] / st["samples"], 2),

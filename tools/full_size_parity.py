@@ -31,7 +31,7 @@ for name in (sys.argv[1] if len(sys.argv) > 1 else "c1,c2,c16,c3,c5,c4").split("
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         # three frames of the same scene and camera: the first in image order and 8x8 squares, the second with the pixels
-        # dealt to wavefronts by cost, the third also with heavy tiles first -- the frame must be the same bits each time
+        # priced, the third with heavy tiles first -- the frame must be the same bits each time
         same_every_frame = True
         first_px = None
         for k in range(3):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Counters of the LAST dispatch of every render kernel in a rocprofv3 --pmc output directory (earlier dispatches are the
-warm-up frames that leave per-pixel costs, the deal of pixels by cost and the heavy-first order):  python tools/pmc_last.py DIR [--json]"""
+warm-up frames that leave tile costs and the heavy-first order):  python tools/pmc_last.py DIR [--json]"""
 import csv
 import glob
 import json

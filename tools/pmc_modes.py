@@ -10,15 +10,11 @@ modes = [int(m) if m.lstrip("-").isdigit() else api.instance_mode(m) for m in sy
 maker, w, h, spp = CONFIGS[cname]
 sph, orig, target = maker()
 cam = host.compute_camera(orig, target, w, h)
-with api.RtContext(w, h, diag=any(m >= 100 for m in modes) or bool(os.environ.get('RT_NO_DEAL') or os.environ.get('RT_DEAL') or os.environ.get('RT_ORDER'))) as ctx:
+with api.RtContext(w, h, diag=any(m >= 100 for m in modes) or bool(os.environ.get('RT_ORDER'))) as ctx:
     ctx.set_scene(sph); ctx.set_camera(cam)
-    warm = int(os.environ.get("RT_PMC_WARM", "3"))      # frames before the measured one: per-pixel costs, the deal, the heavy-first order
-    if os.environ.get("RT_NO_DEAL"):
-        ctx._check(ctx._lib.rt_debug_set_pixel_deal(ctx._h, 0))
-    if os.environ.get("RT_ORDER"):                         # 1 | homes << 8 (rt_debug_set_tile_order)
+    warm = int(os.environ.get("RT_PMC_WARM", "3"))      # frames before the measured one: tile costs, the heavy-first order
+    if os.environ.get("RT_ORDER"):                         # 0 / 1 (rt_debug_set_tile_order)
         ctx._check(ctx._lib.rt_debug_set_tile_order(ctx._h, int(os.environ["RT_ORDER"], 0)))
-    if os.environ.get("RT_DEAL"):                          # rows | run << 8 (rt_debug_set_pixel_deal)
-        ctx._check(ctx._lib.rt_debug_set_pixel_deal(ctx._h, int(os.environ["RT_DEAL"], 0)))
     for m in modes:
         ctx.set_mode(m)
         for _ in range(warm + 1):

@@ -23,9 +23,7 @@ for cname in (args[0] if args else "c2").split(","):
     with api.RtContext(w, h, diag=True) as ctx:
         ctx.set_scene(sph)
         ctx.set_camera(cam)
-        if "--no-deal" in sys.argv:
-            api.load_library(diag=True).rt_debug_set_pixel_deal(ctx._h, 0)
-        for _ in range(3):                  # the shipped instance first: per-pixel costs, the deal of pixels by cost, the heavy-first order
+        for _ in range(3):                  # the shipped instance first: tile costs, the heavy-first order
             ctx.reset()
             ctx.render_pass(spp, copy=False)
         ctx.reset()
@@ -35,7 +33,7 @@ for cname in (args[0] if args else "c2").split(","):
         buf = (C.c_ulonglong * 24)()
         api.load_library(diag=True).rt_debug_counters(ctx._h, buf)
         v = list(buf)[:12]
-        print(f"{cname}{' (no deal: 8x8 squares)' if '--no-deal' in sys.argv else ' (pixels dealt by cost)'}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
+        print(f"{cname}: {st['last_kernel_ms']:.3f} ms (census build); per section: wave-level executions, "
               f"active lanes per execution, executions per sample-wave")
         waves_samples = st["samples"] / 64.0
         for n, c in zip(NAMES, v):

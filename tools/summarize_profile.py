@@ -40,7 +40,7 @@ def main():
                 summary["avg_kernel_ns"] = float(r["AverageNs"])
                 summary["calls"] = int(r["Calls"])
     # the timed launches = the last RT_PROF_LAST dispatches of the kernel (bench.py --steps; the ones before them are the
-    # untimed frames that leave per-pixel costs, the deal of pixels by cost and the heavy-first order)
+    # untimed frames that leave tile costs and the heavy-first order)
     last_n = int(os.environ.get("RT_PROF_LAST", "10"))
     trace = find(os.path.join(src, "trace"), "*kernel_trace.csv")
     if trace:

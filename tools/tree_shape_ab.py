@@ -39,7 +39,7 @@ for name in (sys.argv[1] if len(sys.argv) > 1 else "c3").split(","):
             px = ctx.render_pass(spp)
             if r == 0:
                 pix[shape] = px
-            elif r >= 2:                    # (the first two frames price the tiles and deal the pixels)
+            elif r >= 2:                    # (the first frames price the tiles)
                 times[shape].append(ctx.stats()["last_kernel_ms"])
     for shape, ctx in ctxs.items():
         ctx.set_mode(api.instance_mode("rt_trace_parity_pairs_census"))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The hierarchy walk's shading gate and pair steps in a row (rt_debug_set_walk, rt_debug_set_walk_round) with the deal of pixels
-by cost warm:  python tools/walk_sweep.py [c3|c256|...] -- frame time, min of 4, frames compared with the first setting's."""
+"""The hierarchy walk's shading gate and pair steps in a row (rt_debug_set_walk, rt_debug_set_walk_round)
+with the tile order warm:  python tools/walk_sweep.py [c3|c256|...] -- frame time, min of 4, frames compared with the first setting's."""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
