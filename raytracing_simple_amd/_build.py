@@ -27,6 +27,8 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
           "-fvisibility=hidden", "-DRT_BUILDING_LIBRARY=1",
           "-Wall", "-Wno-unused-function", "-Wno-sometimes-uninitialized", "-Wno-uninitialized"]
+if os.environ.get("RT_BUILD_DEFINES"):        # experiments only (e.g. -DRT_BVH_LEAF=6): part of the build id like every flag
+    COMMON = COMMON + os.environ["RT_BUILD_DEFINES"].split()
 UNITS = [
     # source, extra flags
     ("rt_kernel_parity.hip", ["-ffp-contract=off"]),

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
 //               segmented prefix / suffix unions of the leaf boxes inside every node (Hillis-Steele, 7 words per box) ->
 //               one thread per cut evaluates its cost, ds_min_u64 per node picks -> the pair record of the cut, the children's
 //               ranges, axes and references.  Inner node (a, b) cut at c has its pair at c - 1, as in every other build.
-constexpr uint32_t kSahDeviceMaxTree = 8192;        // 1024 leaves: a thread per leaf (up to 512 leaves the unions towards both ends of a node are formed at once)
+constexpr uint32_t kSahDeviceMaxTree = 1024 * rt::kBvhLeaf;        // 1024 leaves (8192 spheres): a thread per leaf (up to 512 leaves the unions towards both ends of a node are formed at once)
 __device__ inline float bvh_area7(const float *b) {
     const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
     return dx * dy + dy * dz + dz * dx;

@@ -97,8 +97,8 @@ static const rt::Instance *find_role(bool fast, int role, int waves) {
 }
 
 // LDS the hierarchy's staged tables take for this scene
-static size_t pairs_lds(const rt_ctx *c, bool mat, int n_samples) {
-    return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 256);
+static size_t pairs_lds(const rt_ctx *c, bool mat, int n_samples, int waves = 4) {
+    return rt::lds_bytes_pairs(c->scene.n_spheres, c->scene.n_lights, mat, n_samples, c->bvh.n_leaves, c->bvh.n_slots, c->bvh.stack_depth, 64 * waves);
 }
 
 // the plain sweep's tables (geometry and lights) fit LDS for this launch
@@ -134,11 +134,11 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
             break;
         case rt::kTabPairsLds:
             p.mat_in_lds = 0;               // (the walk reads a hit's material by slot from the hierarchy's blob: nothing of it is staged)
-            lds = pairs_lds(c, false, n_samples);
+            lds = pairs_lds(c, false, n_samples, inst.waves);
             break;
         case rt::kTabPairsGlobal:
             p.mat_in_lds = 0;
-            lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 256);
+            lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 64 * inst.waves);
             break;
         default:
             return fail(RT_ERR_STATE, "%s: unknown table kind %d", inst.name, inst.tables);

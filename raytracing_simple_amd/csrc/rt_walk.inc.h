@@ -207,13 +207,14 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             // spheres: such ties are real, and rare).
             uint32_t need = 0u;
             uint32_t leaf_cnt = 0u;         // (census: spheres of the leaf whose discriminant is non-negative for this lane)
+            constexpr int kPart = kBvhLeaf % 4 == 0 ? 4 : 3;        // (the leaf in parts of four; of three for leaves of 6)
 #pragma unroll
-            for (int half = 0; half < kBvhLeaf; half += 4) {
-                HitPre p[4];
+            for (int half = 0; half < kBvhLeaf; half += kPart) {
+                HitPre p[kPart];
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
+                for (int k4 = 0; k4 < kPart; ++k4) p[k4] = hit_pre(s_slots[sl + (uint32_t)(half + k4)], o, d);
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
+                for (int k4 = 0; k4 < kPart; ++k4) {
                     const int k = half + k4;
                     if (cen) leaf_cnt += p[k4].det >= 0.f ? 1u : 0u;
                     if (wave_any_nonneg(p[k4].det)) {
