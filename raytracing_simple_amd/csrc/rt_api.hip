@@ -342,8 +342,8 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
-    // the last frame's costs still predict this one (moving spheres): the next long launch sorts the order again from them
-    c->order_valid = false;
+    // the last frame's costs still predict this one (moving spheres): the order stays in use and the next long launch sorts it again from them
+    c->order_stale = true;
     rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream, false);
     if (rc == RT_OK) rearm_probe_if_changed(c);
     return rc;
@@ -353,7 +353,7 @@ RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (!c || !cam) return fail(RT_ERR_ARG, "null argument");
     if (c->multi) return rt::multi_set_camera(c, cam);
     if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) {
-        c->order_valid = false;            // a moved camera: the next long launch sorts the order again from the last frame's costs
+        c->order_stale = true;             // a moved camera: the order stays in use, the next long launch sorts it again from the last frame's costs
     }
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;

@@ -72,6 +72,7 @@ struct rt_ctx {
     uint32_t cost_tiles = 0;            // tile count of the launch the costs come from
     int wg_waves = 0;                   // diagnostics knob: 0 = automatic, 1 / 4 = force the workgroup shape
     bool cost_valid = false, order_valid = false;
+    bool order_stale = false;           // scene or camera have changed since the order was sorted: it stays in use until a long launch sorts it again
     int use_order = 1;
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
     uint32_t stage_cap = 0;             // records per slot

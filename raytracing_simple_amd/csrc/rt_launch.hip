@@ -215,10 +215,11 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
         if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
         p.tile_cost = c->d_tile_cost;
-        if (c->cost_valid && !c->order_valid && n_samples >= 8 && !natural_order) {
+        if (c->cost_valid && (!c->order_valid || c->order_stale) && n_samples >= 8 && !natural_order) {
             hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
+            c->order_stale = false;
         }
         if (c->order_valid && !natural_order) p.order = c->d_order;
     }
