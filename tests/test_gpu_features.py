@@ -329,9 +329,13 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         # a moved camera keeps the last frame's costs (they still predict the next frame) and sorts them again
         cam2 = host.compute_camera((30.0, 90.0, 110.0), target, w, h)
         ctx.set_camera(cam2)
-        ctx.reset()
-        _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))
+        assert order_state(ctx)[2]                                             # stale, but still in use: short launches need no fresh one
+        ctx.reset(); ctx.render_pass(2)
         assert order_state(ctx)[2]
+        stale = order_state(ctx)[0].copy()
+        ctx.reset()
+        _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))      # a long launch: sorted again from the last costs
+        assert order_state(ctx)[2] and not np.array_equal(order_state(ctx)[0], stale)
         ctx.set_scene(sph)                                                     # the identical scene: nothing changes
         ctx.reset()
         _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))
