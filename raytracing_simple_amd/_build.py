@@ -109,8 +109,19 @@ def _version_script(path, headers):
     return path
 
 
+def _flags_stamp(tag, defines):
+    """csrc/_obj/flags<tag>.stamp, rewritten only when the compiler flags of this library change: every object depends on
+    it, so a build with other flags (RT_BUILD_DEFINES=-DRT_BVH_LEAF=6 and back) recompiles every unit instead of relinking
+    objects of the other configuration under the new build id."""
+    path = os.path.join(OBJ, "flags" + tag + ".stamp")
+    text = repr((COMMON, defines, UNITS))
+    if not os.path.exists(path) or open(path).read() != text:
+        open(path, "w").write(text)
+    return path
+
+
 def _build_lib(cc, out, tag, defines, force, verbose, headers=("rt_api.h",)):
-    deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, d) for d in DEPS] + [os.path.abspath(__file__), _flags_stamp(tag, defines)]
     id_header = _build_id_header()
     jobs, objs = [], []
     for src, extra in UNITS:
@@ -129,6 +140,31 @@ def _build_lib(cc, out, tag, defines, force, verbose, headers=("rt_api.h",)):
     vs = _version_script(os.path.join(OBJ, "exports" + tag + ".map"), headers)
     if force or _stale(out, objs + [vs]):
         _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-Wl,--version-script=" + vs], verbose)
+    return out
+
+
+def kernel_metadata(lib=None):
+    """What the gfx950 code objects inside a built library say about every kernel: registers, LDS, and the private
+    segment (scratch) -- {symbol: {vgpr_count, sgpr_count, private_segment_fixed_size, vgpr_spill_count, ...}}.
+    Read with the image's llvm-objdump / llvm-readelf in a scratch directory (tests/test_abi.py holds DESIGN.md's
+    "no scratch, <= 96 registers" to it; tools/profile_gpu.sh prints it beside every profile)."""
+    import re
+    import tempfile
+    lib = lib or OUT
+    llvm = "/opt/rocm/lib/llvm/bin"
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(lib))
+        shutil.copy(lib, local)
+        subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", local], check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+        for name in sorted(os.listdir(tmp)):
+            if "amdgcn" not in name:
+                continue
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(tmp, name)], check=True,
+                                   capture_output=True, text=True).stdout
+            for block in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+                fields = dict(re.findall(r"\.([a-z_]+):\s+(\S+)", block))
+                out[fields["name"]] = {k: int(v) for k, v in fields.items() if re.fullmatch(r"\d+", v)}
     return out
 
 

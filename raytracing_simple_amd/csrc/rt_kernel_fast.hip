@@ -49,7 +49,7 @@
 #define RT_KERNEL_NAME rt_trace_fast_pairs_g
 #define RT_OPT_WALK 1
 #define RT_OPT_GLOBAL_TABLES 1
-#define RT_OPT_MINWAVES 4
+#define RT_OPT_MINWAVES 5
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 

@@ -495,9 +495,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const int tid = threadIdx.x;
     __shared__ unsigned long long s_stat[5];
     __shared__ unsigned s_tile_cost;
+    __shared__ unsigned long long s_wg_t0;      // the workgroup's start on the device's wall clock (10 ns ticks)
     (void)s_tile_cost;
+    (void)s_wg_t0;
     if (tid < 5) s_stat[tid] = 0;
-    if (tid == 5) s_tile_cost = 0u;
+    if (tid == 5) {
+        s_tile_cost = 0u;
+        s_wg_t0 = __builtin_amdgcn_s_memrealtime();
+    }
 #if !RT_OPT_GLOBAL_TABLES
     for (uint32_t i = tid; i < n; i += kBlockThreads) s_geom[i] = P.scene.geom[i];
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
@@ -543,8 +548,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
     const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;           // (wave-uniform: a scalar load)
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
-    __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
-    if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
     // The pixel of this lane: the 8x8 square of its wavefront.  (Which lane renders which pixel is invisible in the results: a pixel's
     // samples, draws and arithmetic are its own.  Rounds 2-4 also DEALT the pixels of 32x32 regions to wavefronts by the cost the last
     // launch had left for them; on passes the costs had not seen that gained 0 .. 2 % when the costs were fresh and lost 7 % on a moving
@@ -702,8 +705,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             float kcx = ((float)x + j1) * inv_w - 0.5f;
             float kcy = ((float)y + j2) * inv_h - 0.5f;
 #else
-            float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
-            float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
+            // (unpacked HERE, per sample: the compiler otherwise hoists x and y out of the loop into two more registers --
+            // the ones the 4-wavefront cooperative instance then spilled)
+            uint32_t xy_now = xy;
+            asm volatile("; pixel coordinates unpacked per sample" : "+v"(xy_now));
+            float kcx = ((float)(xy_now & 0xffffu) + j1) * inv_w - 0.5f;
+            float kcy = ((float)(xy_now >> 16) + j2) * inv_h - 0.5f;
 #endif
             V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x,
                        cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
@@ -943,7 +950,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
     if (valid_e && Q.n_samples > 0) {
         const int le = tile_by * kTileH + (lane_e >> 3);
-        const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16);
+        uint32_t xy_e = xy;
+        asm volatile("; pixel coordinates unpacked after the loop" : "+v"(xy_e));     // (not before it, into registers held through it)
+        const int xe = (int)(xy_e & 0xffffu), ye = (int)(xy_e >> 16);
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;           // .cl:560-563
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;   // .cl:579
         float *colors = Q.colors;
@@ -974,9 +983,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // separate lines (162 000 same-address global atomics cost 1.8 ms per launch: one word takes
     // about 88 atomics per microsecond)
 #if !RT_OPT_PERSIST
-    if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wave_t0[wave]));   // 10 ns ticks
+    // what this tile cost: the wall clock of its slowest wavefront since the workgroup started (one start for the workgroup: a
+    // start per wavefront needed the wavefront's number here, a register held through the loop for nothing else)
+    if (lane_e == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wg_t0));   // 10 ns ticks
+    const int lane_c = lane_e;
+#else
+    const int lane_c = lane;
 #endif
-    if (lane == 0) {
+    if (lane_c == 0) {
         atomicAdd(&s_stat[0], (unsigned long long)t_samples);
         atomicAdd(&s_stat[1], (unsigned long long)t_closest);
         atomicAdd(&s_stat[2], (unsigned long long)t_shadow);

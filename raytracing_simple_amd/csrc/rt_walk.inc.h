@@ -328,7 +328,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     __shared__ unsigned s_tile_cost;
     __shared__ float4 s_cam[4];         // orig, dir | x, y | 1/w, 1/h
     if (tid < 5) s_stat[tid] = 0;
-    if (tid == 5) s_tile_cost = 0u;
+    __shared__ unsigned long long s_wg_t0;      // the workgroup's start on the device's wall clock (10 ns ticks)
+    if (tid == 5) {
+        s_tile_cost = 0u;
+        s_wg_t0 = __builtin_amdgcn_s_memrealtime();
+    }
     if (tid == 6) {
         s_cam[0] = make_float4(P.cam.orig.x, P.cam.orig.y, P.cam.orig.z, P.cam.dir.x);
         s_cam[1] = make_float4(P.cam.dir.y, P.cam.dir.z, P.cam.x.x, P.cam.x.y);
@@ -363,8 +367,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
     const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
-    __shared__ unsigned long long s_wave_t0[RT_OPT_WG_WAVES];
-    if (lane == 0) s_wave_t0[wave] = __builtin_amdgcn_s_memrealtime();
     int x = tile_bx * kTileW + wave * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
     const int rtile = lrow / P.tile_rows;
     const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
@@ -625,8 +627,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     float j1 = next_random_centred(s0, s1);
                     float j2 = next_random_centred(s0, s1);
                     c_draws += 2;
-                    float kcx = ((float)(xy & 0xffffu) + j1) * inv_w - 0.5f;
-                    float kcy = ((float)(xy >> 16) + j2) * inv_h - 0.5f;
+                    uint32_t xy_now = xy;
+                    asm volatile("; pixel coordinates unpacked per sample" : "+v"(xy_now));       // (as in rt_trace.inc.h: not hoisted into two more registers)
+                    float kcx = ((float)(xy_now & 0xffffu) + j1) * inv_w - 0.5f;
+                    float kcy = ((float)(xy_now >> 16) + j2) * inv_h - 0.5f;
                     V3 rd = mk(cam_x.x * kcx + cam_y.x * kcy + cam_d.x, cam_x.y * kcx + cam_y.y * kcy + cam_d.y,
                                cam_x.z * kcx + cam_y.z * kcy + cam_d.z);
                     o = add(scale(rd, 0.1f), cam_o);
@@ -701,7 +705,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
     const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
     if (valid_e && Q.n_samples > 0) {
-        const int xe = (int)(xy & 0xffffu), ye = (int)(xy >> 16);
+        uint32_t xy_e = xy;
+        asm volatile("; pixel coordinates unpacked after the loop" : "+v"(xy_e));
+        const int xe = (int)(xy_e & 0xffffu), ye = (int)(xy_e >> 16);
         int le = tile_by * kTileH + ((int)(threadIdx.x & 63u) >> 3);
         const size_t gid = (size_t)ye * (size_t)Q.w + (size_t)xe;
         const size_t ci = (size_t)(Q.h - ye - 1) * (size_t)Q.w + (size_t)xe;
@@ -722,7 +728,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     unsigned long long tests64 = (unsigned long long)c_tests + (unsigned long long)c_closest * n;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tests64 += __shfl_xor(tests64, off, 64);
-    if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wave_t0[wave]));
+    if (lane == 0) atomicMax(&s_tile_cost, (unsigned)(__builtin_amdgcn_s_memrealtime() - s_wg_t0));      // (as in rt_trace.inc.h)
     if (lane == 0) {
         atomicAdd(&s_stat[0], (unsigned long long)t_samples);
         atomicAdd(&s_stat[1], (unsigned long long)t_closest);

@@ -41,6 +41,23 @@ def test_library_exports_exactly_the_declared_symbols():
     assert not any(n.startswith("rt_debug") for n in _exports(api.lib_path()))
 
 
+def test_shipped_kernels_have_no_private_segment_and_fit_their_occupancy():
+    """no kernel of the product library uses scratch (no register spills, no private arrays), the
+    sweep instances fit 80 vector registers (6 wavefronts per SIMD), the instances that walk the hierarchy 96 (5 per SIMD).
+    Read from the code objects inside librt_hip.so (rt_trace_parity_coop had a 12-byte private segment,
+    rt_trace_parity_pairs_g 98 registers)."""
+    from raytracing_simple_amd import _build
+    meta = _build.kernel_metadata()
+    trace = {k: v for k, v in meta.items() if k.startswith("rt_trace_")}
+    assert len(trace) == 14 and len(meta) >= 23, sorted(meta)
+    for name, m in meta.items():
+        assert m["private_segment_fixed_size"] == 0, (name, m)
+        assert m["vgpr_spill_count"] == 0 and m["sgpr_spill_count"] == 0, (name, m)
+        assert m.get("agpr_count", 0) == 0, (name, m)
+    for name, m in trace.items():
+        assert m["vgpr_count"] <= (96 if "_pairs" in name else 80), (name, m["vgpr_count"])
+
+
 def test_no_built_binaries_are_tracked():
     """Built artefacts stay out of history (.gitignore policy): no ELF file in the index."""
     files = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True)

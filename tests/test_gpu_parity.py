@@ -231,24 +231,6 @@ def test_progressive_passes_equal_one_launch():
         assert np.array_equal(px2, want["pixels"])
 
 
-def test_config_mirror_runs_reference_pass_loop():
-    from raytracing_simple_amd import SupportType, createConfig, selectType
-    cfg = createConfig(64, 48, selectType(2))
-    assert selectType(0) is SupportType.OpenCL and selectType(7) is SupportType.Default
-    cfg.sceneSetup(host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET)
-    cfg.updateCamera()
-    pixels = cfg.getPixels()
-    for _ in range(3):
-        text = cfg.updateRendering()
-    assert "pass 3" in text and cfg.mCurrentSample == 3
-    assert cfg.getPixels() is pixels                       # stable buffer, as SetupGL.cpp:85 needs
-    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 64, 48)
-    assert np.array_equal(pixels, O.render(host.demo_scene(), cam, 64, 48, 3)["pixels"])
-    cfg.close()
-    with pytest.raises(RuntimeError, match="Unsupported Framework Type"):
-        createConfig(8, 8, selectType(0))
-
-
 # ---- scheduling knobs never change a bit -------------------------------------------------------
 def test_regeneration_gate_and_cooperative_any_hit_are_bit_invisible():
     lib = api.load_library(diag=True)
