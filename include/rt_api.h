@@ -158,8 +158,9 @@ RT_API int rt_set_scene(rt_ctx *ctx, const rt_sphere *spheres, uint32_t count);
  * host wait: the records are staged through page-locked memory, copied and the tables rebuilt by the
  * device-side kernel, all asynchronously on `hip_stream` (a hipStream_t; NULL = the default stream, as
  * for rt_render_async); launches issued later on this context see the new scene (tables and, for large scenes, the
- * hierarchy are rebuilt behind the copy -- the hierarchy by the device's own build by surface area, never on the host; the
- * choice between hierarchy and sweep is kept).  The sphere count
+ * hierarchy are rebuilt behind the copy -- up to 8192 spheres inside the tree by the device's own build by surface area,
+ * with no host wait; beyond that the host builds the fixed (halved) shape from its mirror of the records and the call waits
+ * for the previous such build's upload to have left its staging buffer; the choice between hierarchy and sweep is kept).  The sphere count
  * does not change.  `spheres` may be reused as soon as the call returns.                        */
 RT_API int rt_update_spheres_async(rt_ctx *ctx, uint32_t first, uint32_t count, const rt_sphere *spheres,
                                    void *hip_stream);
@@ -236,7 +237,11 @@ RT_API int rt_throttle(rt_ctx *ctx, int max_in_flight, double *ms_per_pass);
  * than its scheduler keeps resident -- one process per GPU is always fine; four processes of 8 queues each on one
  * GPU were not: the scheduler then time-slices the queues, a dispatch can run XCD-share by XCD-share around a
  * descheduling, and on this driver stack the early share occasionally loses its writes (no fence or store form the
- * library could issue prevents it).  tools/gather_stress.py is the acceptance test for a deployment.            */
+ * library could issue prevents it).  tools/gather_stress.py is the acceptance test for a deployment.
+ * Of a MULTI-DEVICE context: the stream its assembled frame is complete on -- with several devices the first device's
+ * gather stream, behind the receives and the de-interleave of the last frame queued (rt_render_async takes no stream there:
+ * every device renders on its own).  Work queued on it after rt_render_async sees the whole frame in rt_device_pixels, and
+ * the next frame's assembly waits for that work: this is the stream that orders the frame buffer.                    */
 RT_API void *rt_stream(rt_ctx *ctx);
 
 /* Device address and element count (uint32) of the local pixel buffer.                       */

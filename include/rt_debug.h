@@ -30,6 +30,12 @@ RT_API int rt_debug_stage_tables(rt_ctx *ctx, int n_samples, int repeats);
 /* failure injection: puts a multi-device context into the state a failed gather (ncclGroupEnd) leaves it in and returns that
  * failure's code; every later rendering / state call on the context must then return RT_ERR_STATE until it is destroyed */
 RT_API int rt_debug_break_gather(rt_ctx *ctx);
+/* Bind `path` in the place of librccl.so.1 for multi-device contexts created AFTER this call (tests/rccl_double.cpp: sends
+ * paired with receives as device-to-device copies on the streams it is handed; can be told to fail the k-th call of a
+ * function), and -- second argument -- take a device listed n times as n devices, so that the grouped ncclRecv / ncclSend
+ * branch (not the one-GPU rehearsal's copies) runs on a one-GPU box.  (NULL, 0) restores RCCL.  Contexts created before the
+ * call keep their communicators of the previously bound library: destroy them first.                                    */
+RT_API int rt_debug_set_rccl_library(const char *path, int repeated_devices_count_as_distinct);
 
 /* Device-side evaluation of the scalar building blocks, for unit parity tests:
  * op 0: sinf, 1: cosf, 2: pow(x, 1/2.2f), 3: 1/x, 4: sqrt(x), 5: toInt(x) (result as float),

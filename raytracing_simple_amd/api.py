@@ -22,7 +22,7 @@ SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_
            "rt_read_seeds", "rt_get_stats", "rt_last_error", "rt_deinterleave_rows", "rt_compute_camera",
            "rt_default_seeds", "rt_demo_scene", "rt_read_scene", "rt_build_id"]
 # include/rt_debug.h: what librt_hip_diag.so exports on top of that
-DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_instance", "rt_debug_instance_name", "rt_debug_shard_kernel", "rt_debug_break_gather", "rt_debug_stage_tables", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
+DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_instance", "rt_debug_instance_name", "rt_debug_shard_kernel", "rt_debug_break_gather", "rt_debug_set_rccl_library", "rt_debug_stage_tables", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
                  "rt_debug_rcp_probe", "rt_debug_set_regen_gate", "rt_debug_set_mat_lds_limit", "rt_debug_set_persist",
                  "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_set_bvh", "rt_debug_set_tree_shape", "rt_debug_set_walk", "rt_debug_set_walk_round", "rt_debug_bvh_pick", "rt_debug_tree_estimate", "rt_debug_set_choice_estimate", "rt_debug_create_breakdown", "rt_debug_walk_rays", "rt_debug_read_bvh", "rt_debug_set_tile_order", "rt_debug_read_tile_order", "rt_debug_set_wg_waves", "rt_debug_counters", "rt_debug_counters_raw",
                  "rt_debug_reset_by_copy", "rt_debug_probe_seeds", "rt_debug_sidelog_read", "rt_debug_timelog_enable", "rt_debug_timelog_tag",
@@ -116,6 +116,7 @@ def load_library(diag=False):
             "rt_debug_instance_name": (C.c_char_p, [i32, i32]),
             "rt_debug_shard_kernel": (C.c_char_p, [vp, i32]),
             "rt_debug_break_gather": (i32, [vp]),
+            "rt_debug_set_rccl_library": (i32, [C.c_char_p, i32]),
             "rt_debug_stage_tables": (i32, [vp, i32, i32]),
             "rt_debug_eval": (i32, [i32, vp, vp, sz]),
             "rt_debug_sqrt_mismatches": (C.c_longlong, []),

@@ -255,11 +255,16 @@ RT_API void rt_destroy(rt_ctx *c) {
         delete c;
         return;
     }
+    if (c->abandon_streams) {
+        // a shard of a multi-device context whose gather failed (rt_multi.hip mark_broken): its stream may hold a transfer that
+        // never completes, and hipFree / hipHostFree / hipStreamDestroy synchronise with the device's work -- so nothing on the
+        // device is waited for or freed; the shard's device memory and stream are leaked, the call returns
+        delete c;
+        return;
+    }
     if (hipSetDevice(c->device) == hipSuccess) {
-        if (!c->abandon_streams) {
-            if (c->last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
-            if (c->stream) (void)hipStreamSynchronize(c->stream);
-        }
+        if (c->last_stream && c->last_stream != c->stream) (void)hipStreamSynchronize(c->last_stream);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
         if (c->pinned_out) (void)hipHostUnregister(c->pinned_out);
         (void)hipFree(c->d_seeds);
         (void)hipFree(c->d_seeds0);

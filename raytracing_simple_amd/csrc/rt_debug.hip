@@ -169,6 +169,11 @@ RT_API int rt_debug_break_gather(rt_ctx *c) {
     if (!c || !c->multi) return fail(RT_ERR_ARG, "not a multi-device context");
     return rt::multi_debug_break(c);
 }
+// test double in the place of RCCL (tests/rccl_double.cpp), and a repeated device list taken as distinct devices: the grouped
+// ncclRecv / ncclSend branch of rt_multi.hip and its failure handling then run on one GPU.  path = NULL, 0 restores RCCL.
+RT_API int rt_debug_set_rccl_library(const char *path, int repeated_devices_count_as_distinct) {
+    return rt::multi_debug_set_rccl(path, repeated_devices_count_as_distinct);
+}
 // the kernel symbol of row `row` of the parity (fast = 0) or fast table, or "" beyond it
 RT_API const char *rt_debug_instance_name(int fast, int row) {
     int n = 0;

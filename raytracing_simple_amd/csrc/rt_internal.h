@@ -183,5 +183,6 @@ rt_ctx *multi_first_shard(rt_ctx *front);
 rt_ctx *multi_shard(rt_ctx *front, int r);
 int multi_debug_each(rt_ctx *front, int (*fn)(rt_ctx *, int), int arg);
 int multi_debug_break(rt_ctx *front);
+int multi_debug_set_rccl(const char *path, int repeated_counts_as_distinct);   // diagnostics build
 
 }  // namespace rt

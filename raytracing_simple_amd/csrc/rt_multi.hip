@@ -20,9 +20,14 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "rt_internal.h"
+
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
+#endif
 
 using rt::fail;
 
@@ -45,14 +50,23 @@ constexpr int kRcclUint32 = 3;          // ncclUint32 (rccl.h: ncclInt8 0, ncclU
 
 Rccl g_rccl;
 std::mutex g_rccl_mu;
+// Diagnostics build only (rt_debug_set_rccl_library): a library to bind INSTEAD of RCCL -- tests/rccl_double.cpp, which pairs
+// sends with receives as device-to-device copies on the streams it is handed and can be told to fail a call -- and whether a
+// device listed n times counts as n devices, so that the grouped send / receive branch and its failure handling run on one GPU.
+std::string g_rccl_override;
+bool g_repeated_counts_as_distinct = false;
 
 int load_rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.handle) return RT_OK;
     const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
     void *h = nullptr;
+    if (!g_rccl_override.empty()) {
+        h = dlopen(g_rccl_override.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(RT_ERR_NO_DEVICE, "%s cannot be loaded (%s)", g_rccl_override.c_str(), dlerror());
+    }
     for (const char *n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;                  // a copy the process already has (torch's)
+        if (h || (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;             // a copy the process already has (torch's)
     for (const char *n : names) {
         if (h) break;
         h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -272,7 +286,7 @@ RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, in
     m->w = w;
     m->h = h;
     m->tile_rows = tile_rows;
-    m->emulated = repeated;
+    m->emulated = repeated && !g_repeated_counts_as_distinct;
     m->devices.assign(devices, devices + ngpus);
     for (int r = 0; r < ngpus; ++r) m->pad_rows = rows_of(h, r, ngpus, tile_rows) > m->pad_rows ? rows_of(h, r, ngpus, tile_rows) : m->pad_rows;
 
@@ -336,8 +350,11 @@ void multi_destroy(rt_ctx *front) {
     if (!m) return;
     if (m->gather_stream && !m->broken && !m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess)
         (void)hipStreamSynchronize(m->gather_stream);   // (it reads the shards' buffers: before they go)
-    for (rt_ctx *s : m->shard) rt_destroy(s);           // waits for each shard's stream
-    if (!m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess) {
+    for (rt_ctx *s : m->shard) rt_destroy(s);           // waits for each shard's stream (a broken context's shards: neither wait nor free, rt_api.hip)
+    // A broken context (mark_broken) may hold a transfer that never completes on the gather stream or on a shard's: hipFree and
+    // hipStreamDestroy synchronise with such work and would hang with it, so the root's buffers, events and stream are LEAKED
+    // there -- teardown of a failed multi-device context returns, it does not tidy up.
+    if (!m->broken && !m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess) {
         if (m->pinned_out) (void)hipHostUnregister(m->pinned_out);
         (void)hipFree(m->d_gathered[0]);
         (void)hipFree(m->d_gathered[1]);
@@ -349,8 +366,10 @@ void multi_destroy(rt_ctx *front) {
             if (e) (void)hipEventDestroy(e);
         if (m->gather_stream) (void)hipStreamDestroy(m->gather_stream);
     }
+    // (mark_broken has aborted and cleared the communicators where the library has ncclCommAbort; where it has not, a
+    // communicator that sits in a failed group is not handed to ncclCommDestroy, which may wait for that group: leaked too)
     for (rcclComm c : m->comm)
-        if (c) (void)g_rccl.CommDestroy(c);
+        if (c && !m->broken) (void)g_rccl.CommDestroy(c);
     delete m;
     front->multi = nullptr;
 }
@@ -400,7 +419,22 @@ int multi_reset(rt_ctx *front, bool async) {
     EACH_SHARD(async ? rt_reset_async(s, s->stream) : rt_reset(s));
 }
 
-void *multi_stream(rt_ctx *front) { return (void *)front->multi->shard[0]->stream; }
+// rt_stream() of a multi-device context: the stream the ASSEMBLED frame is complete on (n > 1: the root's gather stream, behind
+// the receives and the de-interleave of the last frame queued; n = 1: the one shard's render stream).  A consumer that reads
+// rt_device_pixels behind it sees whole frames, and the next frame's assembly is ordered behind that read in turn.
+void *multi_stream(rt_ctx *front) { return (void *)frame_stream(front->multi); }
+
+#if RT_DIAGNOSTICS
+// rt_debug_set_rccl_library: forget the bound library (contexts created before keep the communicators of the old one: the
+// tests create theirs afterwards) and bind `path` at the next multi-device context
+int multi_debug_set_rccl(const char *path, int repeated_counts_as_distinct) {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    g_rccl = Rccl{};
+    g_rccl_override = path ? path : "";
+    g_repeated_counts_as_distinct = repeated_counts_as_distinct != 0;
+    return RT_OK;
+}
+#endif
 
 int multi_render(rt_ctx *front, uint32_t *out_host, int n_samples, bool blocking) {
     rt_multi *m = front->multi;

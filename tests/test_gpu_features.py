@@ -470,6 +470,122 @@ def test_a_failed_gather_leaves_the_context_in_a_defined_error_state():
         assert np.array_equal(again.render_pass(2), O.render(sph, cam, w, h, 2)["pixels"])
 
 
+def test_consumer_behind_rt_stream_sees_whole_frames_of_a_multi_device_context():
+    """The documented interop pattern on a multi-device context: rt_render_async, then a reader of
+    rt_device_pixels queued behind rt_stream(ctx) -- no rt_throttle, no blocking call in between.  Since round 4 the frame is
+    assembled on the root's gather stream, so THAT is the stream rt_stream must hand out: every copy taken behind it must be a
+    whole frame of the pass count it was queued at, also while the next frames are already being rendered and gathered."""
+    import torch
+    sph, orig, target = scenes.demo_plus(16)
+    w, h = 1024, 768
+    cam = host.compute_camera(orig, target, w, h)
+    want = {k: torch.from_numpy(O.render(sph, cam, w, h, k)["pixels"].view(np.int32).reshape(h, w).copy()) for k in (1, 2, 3, 9, 10)}
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        with api.RtContext(w, h, devices=devices) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            frame = torch.as_tensor(ctx.device_pixels_array(), device="cuda")
+            reader = torch.cuda.ExternalStream(ctx.stream)
+            copies = {}
+            for k in range(1, 11):
+                ctx.render_async(1)
+                if k in want:
+                    with torch.cuda.stream(reader):
+                        copies[k] = frame.clone()               # queued behind rt_stream(ctx): nothing waited for
+            torch.cuda.synchronize()
+            for k, got in copies.items():
+                assert torch.equal(got.cpu(), want[k]), (devices, k)
+
+
+@pytest.fixture(scope="module")
+def rccl_double(tmp_path_factory):
+    """tests/rccl_double.cpp built into a scratch directory and bound in the place of RCCL by the diagnostics library, with a
+    repeated device list taken as distinct devices: rt_multi.hip's grouped ncclRecv / ncclSend branch and its failure handling
+    run on this one GPU.  Yields the double's own handle (call counts, failure injection); RCCL is restored afterwards."""
+    import os
+    import subprocess
+    from raytracing_simple_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path_factory.mktemp("rccl_double") / "librccl_double.so")
+    subprocess.run([_build.hipcc(), "-O1", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+                    os.path.join(root, "tests", "rccl_double.cpp"), "-o", so], check=True, capture_output=True)
+    lib = api.load_library(diag=True)
+    assert lib.rt_debug_set_rccl_library(so.encode(), 1) == 0
+    dbl = C.CDLL(so)                                        # the same handle the library binds (dlopen counts references)
+    dbl.rccl_double_fail.argtypes = [C.c_char_p, C.c_long]
+    dbl.rccl_double_reset()
+    yield dbl
+    assert lib.rt_debug_set_rccl_library(None, 0) == 0
+
+
+def _double_counts(dbl):
+    out = (C.c_long * 8)()
+    dbl.rccl_double_counts(out)
+    return dict(zip(("init", "group_start", "send", "recv", "group_end", "abort", "destroy", "copies"), out))
+
+
+def test_grouped_send_receive_branch_runs_against_the_double(rccl_double):
+    """The in-library n > 1 branch as it runs on real links -- ncclCommInitAll, per frame ONE group of n - 1 receives on the
+    root's gather stream and one send per other shard on its own stream, the de-interleave behind them -- executed for real,
+    against a double that keeps RCCL's pairing and stream ordering.  Frames, colour plane, seeds and counters equal the
+    oracle's; asynchronous frames are whole; the double saw exactly the calls the design promises."""
+    sph, orig, target = scenes.demo_plus(16)
+    w, h, spp = 320, 200, 6
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    for n in (2, 3, 8):
+        rccl_double.rccl_double_reset()
+        with api.RtContext(w, h, devices=[0] * n, diag=True) as ctx:
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+            ctx.reset()
+            for k in range(spp):
+                ctx.render_async(1)
+                if k == 2:
+                    assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, 3)["pixels"])
+            assert np.array_equal(ctx.read_pixels(), want["pixels"])
+        got = _double_counts(rccl_double)
+        frames = 1 + spp
+        assert got["init"] == 1 and got["group_start"] == frames and got["group_end"] == frames
+        assert got["recv"] == got["send"] == got["copies"] == (n - 1) * frames
+        assert got["destroy"] == n and got["abort"] == 0
+
+
+@pytest.mark.parametrize("where,kth", [("ncclSend", 2), ("ncclRecv", 4), ("ncclGroupEnd", 2), ("ncclGroupStart", 3)])
+def test_a_failing_rccl_call_breaks_the_context_and_teardown_returns(rccl_double, where, kth):
+    """mark_broken for real: the k-th call of one RCCL function fails -- inside the group, at its end, at its
+    start.  The frame before it is intact, the failing call returns RT_ERR_HIP naming the function, the communicators are aborted
+    (not destroyed), every later call is refused with RT_ERR_STATE, rt_destroy returns, and a new context works."""
+    sph, orig, target = scenes.demo_plus(16)
+    w, h = 96, 64
+    cam = host.compute_camera(orig, target, w, h)
+    rccl_double.rccl_double_reset()
+    ctx = api.RtContext(w, h, devices=[0, 0, 0], diag=True)
+    ctx.set_scene(sph)
+    ctx.set_camera(cam)
+    assert np.array_equal(ctx.render_pass(1), O.render(sph, cam, w, h, 1)["pixels"])
+    assert rccl_double.rccl_double_fail(where.encode(), kth) == 0             # the kth call from now (a frame = 1 start, 2 receives, 2 sends, 1 end)
+    with pytest.raises(api.RtError) as e:
+        for _ in range(3):
+            ctx.render_pass(1)
+    assert e.value.code == -3 and where in str(e.value) and "unusable" in str(e.value)
+    for call in (lambda: ctx.render_pass(1), lambda: ctx.render_async(1), lambda: ctx.read_pixels(), lambda: ctx.set_camera(cam), lambda: ctx.reset()):
+        with pytest.raises(api.RtError) as e2:
+            call()
+        assert e2.value.code == -5 and where in str(e2.value)
+    t0 = time.time()
+    ctx.close()
+    assert time.time() - t0 < 5.0
+    got = _double_counts(rccl_double)
+    assert got["abort"] == 3 and got["destroy"] == 0
+    rccl_double.rccl_double_reset()
+    with api.RtContext(w, h, devices=[0, 0], diag=True) as again:
+        again.set_scene(sph)
+        again.set_camera(cam)
+        assert np.array_equal(again.render_pass(2), O.render(sph, cam, w, h, 2)["pixels"])
+
+
 def _device_count():
     import torch
     return torch.cuda.device_count()
