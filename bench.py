@@ -87,6 +87,35 @@ def walk_census(api, spheres, cam, w, h, spp):
             "lanes_per_leaf_step": round(raw[23] / max(raw[22], 1), 1), "reference_equivalent_sphere_tests": st["sphere_tests"]}
 
 
+def scaling_bound(api, mode, spheres, cam, w, h, spp, frame_ms=None, device=0):
+    """DESIGN.md section 6's strong-scaling bound of ONE frame, as numbers: a pixel's samples consume one random stream in order
+    (.cl:143-169), so however many GPUs share the image a frame lasts at least as long as its slowest wavefront.  That time is
+    measured here -- every launch leaves the wall clock of each tile's slowest wavefront (the heavy-first order's input), read
+    through the diagnostics library after an untimed, unsharded frame on this GPU -- and the predicted ceiling of the speed-up at
+    N GPUs is frame / max(slowest wavefront, frame / N).  The first measured SCALE record is to be read against this."""
+    import ctypes as C
+    import numpy as np
+    with api.RtContext(w, h, device=device, diag=True) as c:
+        c.set_scene(spheres)
+        c.set_camera(cam)
+        c.set_mode(mode)
+        for _ in range(2):                      # (the second frame walks its tiles heavy first, as the timed ones do)
+            c.reset()
+            c.render_pass(spp, copy=False)
+        one_gpu_ms = c.stats()["last_kernel_ms"]
+        cap = ((w + 7) // 8) * ((h + 7) // 8)
+        cost = np.zeros(cap, np.uint32)
+        n_tiles, valid = C.c_uint32(), C.c_int()
+        c._check(c._lib.rt_debug_read_tile_order(c._h, None, cost.ctypes.data_as(C.c_void_p), cap, C.byref(n_tiles), C.byref(valid)))
+        slowest_ms = float(cost[:n_tiles.value].max()) * 1e-5           # s_memrealtime ticks of 10 ns
+    frame = frame_ms if frame_ms else one_gpu_ms
+    return {"slowest_wavefront_ms": round(slowest_ms, 4), "one_gpu_frame_ms": round(frame, 4),
+            "predicted_speedup_ceiling": {str(n): round(frame / max(slowest_ms, frame / n), 2) for n in (2, 4, 8)},
+            "predicted_ms_per_frame_floor": {str(n): round(max(slowest_ms, frame / n), 4) for n in (2, 4, 8)},
+            "note": "kernel time only: the gather of the packed rows (8.3 MB at 1080p over xGMI) and launch latency come on top; "
+                    "frames_in_flight is the figure that scales with N"}
+
+
 def first_frame(api, mode, spheres, cam, w, h, spp, steady_ms):
     """A NEW scene's first frame -- what rt_render(scene, cam, out, w, h, spp), the call north_star names, is by definition: a
     fresh context (GPU warm, outside every timed region), rt_set_scene + rt_set_camera + ONE blocking frame.  `ms` is the device
@@ -106,6 +135,25 @@ def first_frame(api, mode, spheres, cam, w, h, spp, steady_ms):
             out["choice"] = ch["picked"] + (" (measured: four probe launches inside this frame)" if ch["hierarchy_ms_per_pass"] > 0
                                             else " (from the uploaded tree's surface areas: nothing measured)")
     return out
+
+
+NORTH_STAR_PSNR_GATE_DB = 50.0       # BASELINE.json north_star: "PSNR >= 50 dB against it for multi-spp float accumulation"
+
+
+def fast_mode_check(api, host, ctx, spp, parity_pixels):
+    """RT_MODE_FAST on the workload `ctx` holds, against north_star's tolerance: one warm and one timed fast frame of the same
+    sample count, its PSNR against the parity frame (which is bit-equal to the reference CPU path).  Outside every timed
+    region; the context is handed back in parity mode.  No fast-mode rate may be quoted for a workload that fails the gate."""
+    ctx.set_pixel_buffer(0, 0)
+    ctx.set_mode(api.RT_MODE_FAST)
+    for _ in range(2):
+        ctx.reset()
+        px = ctx.render_pass(spp)
+    ms, kern = ctx.stats()["last_kernel_ms"], ctx.last_kernel
+    ctx.set_mode(api.RT_MODE_PARITY)
+    db = host.psnr(px, parity_pixels)
+    return {"kernel": kern, "kernel_ms": round(ms, 4), "psnr_db_vs_parity": round(db, 2), "gate_db": NORTH_STAR_PSNR_GATE_DB,
+            "meets_north_star_gate": bool(db >= NORTH_STAR_PSNR_GATE_DB)}
 
 
 def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workload, mode, census=None, choice=None):
@@ -527,7 +575,10 @@ def main():
         other = {"mode": "fast" if other_mode == api.RT_MODE_FAST else "parity", "ms_per_step": round(el_o1 / 8 * 1e3, 4),
                  "value": round(rays_o * 8 / el_o1 / 1e6, 1), "unit": "Mray/s", "kernel_ms": round(k_o1, 4),
                  "frames_in_flight": {"frames": F, "ms_per_step": round(el_oF / 8 * 1e3, 4), "value": round(rays_o * 8 / el_oF / 1e6, 1)},
-                 "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2)}
+                 "psnr_db_vs_headline_mode": round(host.psnr(px_o, last_pixels), 2), "gate_db": NORTH_STAR_PSNR_GATE_DB,
+                 "meets_north_star_gate": bool(host.psnr(px_o, last_pixels) >= NORTH_STAR_PSNR_GATE_DB),
+                 "gate_note": "north_star's tolerance for the fused mode: PSNR >= 50 dB against the reference CPU path (= the parity frame, bit for bit) "
+                              "at this workload's sample count; a fast-mode rate counts only where this is true (DESIGN.md section 3, tools/fast_gate.py)"}
         for c in ctxs:
             c.set_mode(mode)
         # the north-star target workload (16-sphere scene, 1080p x 64 spp, >= 10 Gray/s asked), driver-timed
@@ -548,6 +599,8 @@ def main():
                       "roofline": roofline_block(c16[0].last_kernel, kms16, st16["sphere_tests"], W * H, len(sph16), "c16", args.mode),
                       "frames_in_flight": {"frames": F, "ms_per_step": round(el16F / k16 * 1e3, 4), "value": round(rays16 * k16 / el16F / 1e6, 1)}}
             first["north_star_target"] = first_frame(api, mode, sph16, cam16, W, H, SPP, kms16)
+            if mode == api.RT_MODE_PARITY:
+                target["fast_mode"] = fast_mode_check(api, host, c16[0], SPP, px16)
             if not args.no_cpu and mode == api.RT_MODE_PARITY:
                 base16, cpu16 = cpu_baseline(sph16, cam16, W, H, SPP, reference_too=False)
                 target["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(px16, cpu16["pixels"]))
@@ -570,6 +623,7 @@ def main():
                         cl.reset_async(); cl.render_pass(16, copy=False)
                     dt3 = time.perf_counter() - t0
                     st3, ch3, kern3 = cl.stats(), cl.scene_choice(), cl.last_kernel
+                    fast3 = fast_mode_check(api, host, cl, 16, cl.read_pixels()) if mode == api.RT_MODE_PARITY else None
                     # the same scene MOVING: every frame rewrites the records on the device (rt_update_spheres_async, the whole range) and
                     # the hierarchy is rebuilt on the stream -- its shape chosen by surface area by the device's own build kernel
                     moved3 = api.as_spheres(sph3).copy()
@@ -587,7 +641,7 @@ def main():
                          "ms_per_step": round(dt3 / k3 * 1e3, 4), "value": round((st3["samples"] + st3["shadow_rays"]) * k3 / dt3 / 1e6, 1),
                          "unit": "Mray/s", "kernel": kern3, "kernel_ms": round(st3["last_kernel_ms"], 4),
                          "roofline": roofline_block(kern3, st3["last_kernel_ms"], st3["sphere_tests"], W * H, len(sph3), "c3", args.mode, census=cen3, choice=ch3),
-                         "moving_scene": moving3,
+                         "moving_scene": moving3, "fast_mode": fast3,
                          "note": "frames, seeds and counters are the same bits through either form (DESIGN.md section 5; "
                                  "tests/test_gpu_parity.py test_baseline_configurations_at_full_size_bit_exact); bench.py --workload c3 is the full record"}
             except api.RtError as e:
@@ -604,7 +658,9 @@ def main():
                     m1.reset_async(); m1.render_async(SPP)
                 m1.throttle(0)
                 dt = time.perf_counter() - t0
-                in_library = {"path": "rt_create_multi(ngpus=1): one shard rendering straight into the frame (no communicator, no gather, no de-interleave), blocking rt_render_pass",
+                in_library = {"path": "rt_create_multi(ngpus=1): one shard rendering straight into the frame (no communicator, no gather, no de-interleave); 8 frames queued with "
+                                      "rt_reset_async + rt_render_async and ONE rt_throttle(0) at the end (since round 4; BENCH_r03's figure under this key timed blocking rt_render_pass calls)",
+                              "method": "queued rt_render_async x 8 + rt_throttle(0)",
                               "ms_per_frame": round(dt / 8 * 1e3, 4), "frame_equals_headline": bool(np.array_equal(m1.read_pixels(), last_pixels))}
         except api.RtError as e:
             in_library = {"error": str(e)}
@@ -632,6 +688,12 @@ def main():
         except (subprocess.TimeoutExpired, ValueError, OSError) as e:
             in_library = {"error": repr(e)[:400]}
 
+    bound = None
+    if not args.no_extras:
+        try:
+            bound = scaling_bound(api, mode, spheres, cam, W, H, SPP, kernel_ms if world == 1 else None, device=local_rank)
+        except Exception as e:       # noqa: BLE001 -- a diagnostics figure never takes the headline down
+            bound = {"error": repr(e)[:300]}
     rays = samples + shadow                      # primary + shadow, the metric's ray count
     ms_per_step = el1_max / args.steps * 1e3
     value = rays * args.steps / el1_max / 1e6
@@ -664,10 +726,7 @@ def main():
                    "every_gathered_frame_equals_unsharded": None if frames_ok is None else frames_ok["wrong_pixels"] == 0,
                    "gathered_frames_checked": None if frames_ok is None else frames_ok["frames_checked"],
                    "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
-                   "strong_scaling_bound": None if world == 1 else
-                   "one frame cannot take less than its slowest wavefront: a pixel's 64 samples consume ONE random stream in order "
-                   "(.cl:143-169), 8 bounces x 64 samples over glass = 1.2-1.7 ms, so one frame gains at most ~2.3x from any number of "
-                   "GPUs (DESIGN.md section 6); frames_in_flight is the throughput of the same frames",
+                   "strong_scaling_bound": bound,
                    "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
                    "Mray_s_all_rays": round((closest + shadow) * args.steps / el1_max / 1e6, 1),
                    "Msample_s": round(samples * args.steps / el1_max / 1e6, 1)},

@@ -60,6 +60,38 @@
 #include "rt_opts_reset.h"
 
 #if RT_DIAGNOSTICS
+// fused mode with every decision in parity arithmetic (RT_OPT_EXACT_DECISIONS, rt_trace.inc.h): the instances BASELINE's
+// configurations run on, for tools/fast_gate.py
+#define RT_NS fastdx_w1
+#define RT_KERNEL_NAME rt_trace_fastdx_w1
+#define RT_OPT_WG_WAVES 1
+#define RT_OPT_EXACT_DECISIONS 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fastdx_coop_w1
+#define RT_KERNEL_NAME rt_trace_fastdx_coop_w1
+#define RT_OPT_WG_WAVES 1
+#define RT_OPT_COOP 1
+#define RT_OPT_EXACT_DECISIONS 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fastdx_coop
+#define RT_KERNEL_NAME rt_trace_fastdx_coop
+#define RT_OPT_COOP 1
+#define RT_OPT_EXACT_DECISIONS 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS fastdx_pairs
+#define RT_KERNEL_NAME rt_trace_fastdx_pairs
+#define RT_OPT_WALK 1
+#define RT_OPT_MINWAVES 5
+#define RT_OPT_EXACT_DECISIONS 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS fast_persist
 #define RT_KERNEL_NAME rt_trace_fast_persist
 #define RT_OPT_PERSIST 1
@@ -86,6 +118,10 @@ static const Instance kFastInstances[] = {
     { fast_g::rt_trace_fast_g, "rt_trace_fast_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { fast::rt_sched_fast, "rt_sched_fast", 4, kTabSweepLds, kRoleNone, kInstNoTileCost },
+    { fastdx_w1::rt_trace_fastdx_w1, "rt_trace_fastdx_w1", 1, kTabSweepLds, kRoleNone, 0 },
+    { fastdx_coop_w1::rt_trace_fastdx_coop_w1, "rt_trace_fastdx_coop_w1", 1, kTabSweepLds, kRoleNone, kInstStaticCoop },
+    { fastdx_coop::rt_trace_fastdx_coop, "rt_trace_fastdx_coop", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
+    { fastdx_pairs::rt_trace_fastdx_pairs, "rt_trace_fastdx_pairs", 4, kTabPairsLds, kRoleNone, 0 },
     { fast_persist::rt_trace_fast_persist, "rt_trace_fast_persist", 4, kTabSweepLds, kRolePersist, kInstPersistent | kInstNoTileCost },
     { fast_persist_coop::rt_trace_fast_persist_coop, "rt_trace_fast_persist_coop", 4, kTabSweepLds, kRolePersistCoop,
       kInstPersistent | kInstNoTileCost | kInstStaticCoop },

@@ -13,3 +13,4 @@
 #undef RT_OPT_PERSIST
 #undef RT_OPT_STAMPS
 #undef RT_OPT_TIMELOG
+#undef RT_OPT_EXACT_DECISIONS

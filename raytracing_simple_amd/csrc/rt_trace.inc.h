@@ -69,6 +69,14 @@
 #ifndef RT_OPT_PERSIST
 #define RT_OPT_PERSIST 0
 #endif
+// Fused mode, diagnostics build only (the experiment VERDICT r4 item 1c asked for, profiles/r05_fast_gate.jsonl): every DECISION of
+// a path -- the sphere test's discriminant, root and epsilon compares (.cl:173-201), which side of a light and of the surface a
+// sample lies on (.cl:283-296), total internal reflection (.cl:438), the Fresnel roulette (.cl:470) -- in uncontracted,
+// correctly rounded binary32 as in parity mode; everything continuous (hit points, normals, directions, weights, sine / cosine,
+// gamma) fused and on the hardware's approximations as in fast mode.
+#ifndef RT_OPT_EXACT_DECISIONS
+#define RT_OPT_EXACT_DECISIONS 0
+#endif
 #ifndef RT_OPT_STAMPS
 #define RT_OPT_STAMPS 0
 #endif
@@ -122,6 +130,17 @@ RT_DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_DEV V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_DEV V3 scale(V3 a, float k) { return mk(a.x * k, a.y * k, a.z * k); }
 RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // .cl:117-120
+// A product in front of a decision: never contracted into the sum that follows where RT_OPT_EXACT_DECISIONS asks for that
+// (parity mode never contracts).  Under -ffp-contract=fast the backend fuses whatever multiply and add it sees, whatever a
+// pragma says, so the product is made opaque to it: an empty asm statement, no instruction.
+RT_DEV float mul_decision(float a, float b) {
+    float m = a * b;
+#if RT_OPT_EXACT_DECISIONS && RT_FAST
+    asm("" : "+v"(m));
+#endif
+    return m;
+}
+RT_DEV float dot_decision(V3 a, V3 b) { return mul_decision(a.x, b.x) + mul_decision(a.y, b.y) + mul_decision(a.z, b.z); }
 RT_DEV V3 cross(V3 a, V3 b) {                                                        // .cl:128-131
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
@@ -170,7 +189,7 @@ RT_DEV float rt_sqrt_unit(float x) {
 // |b| < 2^-23 both are below EPSILON and the test returns 0 (rt_debug_hitpost_mismatches tries
 // every such det against a set of b on the device).
 RT_DEV float rt_sqrt_det(float x) {
-#if RT_FAST
+#if RT_FAST && !RT_OPT_EXACT_DECISIONS
     return __builtin_amdgcn_sqrtf(x);
 #else
     return ieee_sqrt_core(x);
@@ -265,8 +284,13 @@ struct HitPre {
 };
 RT_DEV HitPre hit_pre(float4 g, V3 o, V3 d) {
     V3 op = mk(g.x - o.x, g.y - o.y, g.z - o.z);
+#if RT_OPT_EXACT_DECISIONS
+    float b = dot_decision(op, d);
+    return HitPre{ b, mul_decision(b, b) - dot_decision(op, op) + g.w };
+#else
     float b = dot(op, d);
     return HitPre{ b, b * b - dot(op, op) + g.w };
+#endif
 }
 RT_DEV float hit_post(HitPre p) {
     float sq = rt_sqrt_det(p.det);
@@ -354,6 +378,22 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
     return first;
 }
 
+// .cl:438 and .cl:470: the two quantities a glass hit DECIDES on (total internal reflection; reflect or refract)
+RT_DEV float cos2t_of(float nnt, float ddn) {
+#if RT_OPT_EXACT_DECISIONS
+    return 1.f - mul_decision(mul_decision(nnt, nnt), 1.f - mul_decision(ddn, ddn));
+#else
+    return 1.f - nnt * nnt * (1.f - ddn * ddn);
+#endif
+}
+RT_DEV float roulette_p(float Re) {
+#if RT_OPT_EXACT_DECISIONS
+    return .25f + mul_decision(.5f, Re);
+#else
+    return .25f + .5f * Re;
+#endif
+}
+
 // One light of SampleLights (.cl:258-295) up to the visibility test.  Draws its two numbers
 // whatever happens next, as the reference does.  Returns true when a shadow ray is needed and
 // then gives its unit direction, its length and the numerator 4*pi*r^2*wi*wo of .cl:297.
@@ -373,10 +413,10 @@ RT_DEV bool sample_light(float4 la, float4 lb, uint32_t &s0, uint32_t &s1, uint3
     V3 on_light = add(scale(us, la.w), mk(la.x, la.y, la.z));
     sd = sub(on_light, hp);
     sd = scale(sd, sqrt_and_rcp(dot(sd, sd), len));
-    float wo = dot(sd, us);
+    float wo = dot_decision(sd, us);
     if (wo > 0.f) return false;                                            // far side of the light
     wo = -wo;
-    float wi = dot(sd, nl);
+    float wi = dot_decision(sd, nl);
     numer = lb.w * wi * wo;
     return wi > 0.f;
 }
@@ -891,7 +931,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 const float ddn = -fabsf(dp);
                 const float nc = 1.f, nt = 1.52f;
                 float nnt = into ? nc / nt : nt / nc;
-                float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
+                float cos2t = cos2t_of(nnt, ddn);
                 if (cos2t < 0.f) {                                         // total internal reflection
                     thr = mul(thr, col);
                     d = rfl;
@@ -903,7 +943,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     float c = 1 - (into ? -ddn : dot(td, nrm));
                     float Re = R0 + (1 - R0) * c * c * c * c * c;
                     float Tr = 1.f - Re;
-                    float Pr = .25f + .5f * Re;
+                    float Pr = roulette_p(Re);
                     float pick = next_random(s0, s1);
                     c_draws += 1;
                     // RP = Re / P and TP = Tr / (1 - P): only the branch taken is divided

@@ -516,7 +516,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                             const float ddn = -fabsf(dp);
                             const float nc = 1.f, nt = 1.52f;
                             float nnt = into ? nc / nt : nt / nc;
-                            float cos2t = 1.f - nnt * nnt * (1.f - ddn * ddn);
+                            float cos2t = cos2t_of(nnt, ddn);
                             if (cos2t < 0.f) {
                                 thr = mul(thr, col);
                                 d = rfl;
@@ -528,7 +528,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                                 float c = 1 - (into ? -ddn : dot(td, nrm));
                                 float Re = R0 + (1 - R0) * c * c * c * c * c;
                                 float Tr = 1.f - Re;
-                                float Pr = .25f + .5f * Re;
+                                float Pr = roulette_p(Re);
                                 float pick = next_random(s0, s1);
                                 c_draws += 1;
                                 const bool take_rfl = pick < Pr;
@@ -587,8 +587,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     V3 sd = sub(on_light, o);
                     float len;
                     sd = scale(sd, sqrt_and_rcp(dot(sd, sd), len));
-                    float wo = dot(sd, us);
-                    const float wi = dot(sd, nl);
+                    float wo = dot_decision(sd, us);
+                    const float wi = dot_decision(sd, nl);
                     if (!(wo > 0.f) && wi > 0.f) {                                 // .cl:283-296: this side of the light, facing it
                         wo = -wo;
                         // ---- shadow ray, any hit, .cl:234-247: the large spheres at the end of this phase, the tree in the trips to come ----
