@@ -207,7 +207,17 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
                                     "tools/summarize_profile.py make a record for this library)" % (pm.get("kernel"), pm.get("build_id"), kernel, lib_id))
         pm = None
     if pm:
-        out["traffic"] = pm.get("hbm_bytes_per_launch")
+        # FETCH_SIZE on gfx950 counts HALF the bytes of reads that arrive as wide coalesced segments (MI355X_MICROARCH.md, HBM section).
+        # The 8x8-pixel workgroups of the *_w1 instances read their seeds in 64-byte row segments: the raw count is right there (C2:
+        # 1.06 x algorithmic).  The 32x8 workgroups of every other instance read 256-byte rows: there the corrected figure (2 x fetch
+        # + write) is the traffic, and the raw one -- below the algorithmic minimum -- is kept beside it as what it is.
+        wide = not kernel.endswith("_w1")
+        raw, fixed = pm.get("hbm_bytes_per_launch"), pm.get("hbm_bytes_per_launch_fetch_x2")
+        out["traffic"] = fixed if (wide and fixed) else raw
+        out["traffic_basis"] = ("WRITE_SIZE + 2 x FETCH_SIZE: this instance's 32x8-pixel workgroups read seeds in 256-byte rows, which FETCH_SIZE half-counts on gfx950 "
+                                "(raw: %s B)" % raw) if (wide and fixed) else "WRITE_SIZE + FETCH_SIZE as counted (64-byte row segments: no half-count)"
+        if out["traffic"] and out["traffic"] < alg_bytes:
+            out["traffic_note"] = "below the algorithmic bytes: a counter artefact, not a saving -- read `hbm.algorithmic_bytes_per_launch` as the floor"
         if out["traffic"] and out["traffic"] > 1.15 * alg_bytes:
             out["traffic_note"] = ("above the algorithmic bytes: a wavefront's 8x8 square stores its colours (12 B per pixel) and seeds in 32-96 byte segments, "
                                    "not whole lines; the kernel is VALU-bound at under 1 % of the HBM peak")
@@ -217,7 +227,11 @@ def roofline_block(kernel, kernel_ms, sphere_tests, n_pixels, n_spheres, workloa
             floor_ms = pm["valu_busy_frac_single_stream"] * pm["profiled_kernel_ms"]
             out["executed"] = {"valu_insts_per_launch": pm["valu_insts_per_launch"], "active_lane_frac": pm["active_lane_frac"],
                                "valu_issue_floor_ms": round(floor_ms, 4), "valu_busy_frac": round(floor_ms / kernel_ms, 4),
-                               "l2_hit_rate": pm.get("l2_hit_rate"), "lds_bank_conflict_frac": pm.get("lds_bank_conflict_frac"),
+                               "l2_hit_rate_whole_kernel": pm.get("l2_hit_rate"), "l2_hit_rate_staged_tables": pm.get("l2_hit_rate_staged_tables"),
+                               "l2_hit_rate_note": "whole kernel = every TCC request of the launch (mostly the once-per-pixel seed / colour streams, which miss by design); "
+                                                   "staged tables = the workgroups' reads of the sphere tables into LDS in isolation (north_star's figure; "
+                                                   "rt_debug_stage_tables under --pmc, tools/pmc_staging.sh, same library)",
+                               "lds_bank_conflict_frac": pm.get("lds_bank_conflict_frac"),
                                "source": pm.get("source", "profiles/pmc_traffic.json")}
     return out
 
@@ -339,8 +353,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5"], default="c2",
-                    help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request")
+    ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5", "box300", "r2048"], default="c2",
+                    help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request; box300 / r2048 = scenes "
+                         "that run on the two shipped instances no BASELINE configuration reaches (rt_trace_*_coop, rt_trace_*_pairs_g), for their profiles")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames kept in flight per rank in the throughput region (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
     ap.add_argument("--no-extras", action="store_true", help="headline regions only (profiling runs)")
@@ -390,6 +405,8 @@ def main():
         "c3": ("C3: 1024 random spheres", lambda: scenes.random_spheres(1024), 1920, 1080, 16),
         "c4": ("C4: Demo scene (6 spheres)", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
         "c5": ("C5: 64-sphere mirror box, depth 8", lambda: scenes.mirror_box(64), 1920, 1080, 64),
+        "box300": ("closed box of 300 mirror / glass spheres (the 4-wavefront cooperative sweep)", lambda: scenes.mirror_box(300), 1920, 1080, 8),
+        "r2048": ("2048 random spheres (hierarchy tables beyond LDS: read from HBM / L2)", lambda: scenes.random_spheres(2048), 1920, 1080, 8),
     }
     wl_name, wl_maker, W, H, SPP = workloads[args.workload]
     spheres, cam_orig, cam_target = wl_maker()

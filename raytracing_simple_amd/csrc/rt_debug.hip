@@ -255,6 +255,7 @@ RT_API int rt_debug_set_tree_shape(rt_ctx *c, int by_area) {
 }
 static int dbg_set_walk_gate(rt_ctx *c, int v) { if (v > 0) c->walk_gate = v; return RT_OK; }
 static int dbg_set_walk_round(rt_ctx *c, int v) { c->walk_round = v; return RT_OK; }
+static int dbg_set_walk_tail(rt_ctx *c, int v) { c->walk_tail = v; return RT_OK; }
 
 RT_API int rt_debug_set_walk_round(rt_ctx *c, int steps) {
     if (!c || steps < 1) return fail(RT_ERR_ARG, "steps %d", steps);
@@ -266,7 +267,12 @@ static int dbg_set_walk_forced(rt_ctx *c, int v) { c->walk_forced = v ? 1 : 0; r
 // forced: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = the hierarchy whenever the scene has one
 RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int forced) {
     if (!c || steps < 0 || gate < 0 || gate > 64 || forced < 0 || forced > 1) return fail(RT_ERR_ARG, "steps %d, gate %d, forced %d", steps, gate, forced);
-    int rc = dbg_apply(c, dbg_set_walk_gate, gate);         // (`steps`: the per-trip step budget of rounds 2-3; a walk now runs to its end within the trip)
+    // `steps`: rounds 2-3, the per-trip step budget; round 5: the walk phase of a trip ends once no more than `steps` lanes still walk (0 = every walk
+    // runs to its end within the trip) -- it rides in the high bits of walk_round
+    if (steps < 0 || steps > 63) return fail(RT_ERR_ARG, "tail lanes %d", steps);
+    int rc = dbg_apply(c, dbg_set_walk_tail, steps);
+    if (rc != RT_OK) return rc;
+    rc = dbg_apply(c, dbg_set_walk_gate, gate);
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_walk_forced, forced);
 }
 // rays8[i] = { o.xyz, t_max, d.xyz, shadow != 0 } through the hierarchy walk and through the plain sweep (csrc/rt_walk.inc.h

@@ -50,6 +50,7 @@ struct rt_ctx {
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
     int walk_gate = 16, walk_round = 4; // rt_walk.inc.h: ready lanes that make the wavefront shade; pair steps in a row before a leaf step
                                         // (round 4, this kernel: 2 / 3 / 4 / 6 in a row = 5.42 / 5.37 / 5.22 / 5.45 ms on C3, profiles/r04k_walk_sweep.jsonl)
+    int walk_tail = 0;                  // lanes that may be left walking when a trip's walk phase ends (0 = none: every walk runs to its end within the trip)
     int walk_forced = 0;                // 0 = measured choice (below); diagnostics: 1 = the hierarchy whenever the scene has one
     // hierarchy or plain sweep?  Decided per scene by measurement (rt_api.hip launch()): each form once warm and once
     // timed between events, in the same tile order; whichever took less time per pass renders the rest

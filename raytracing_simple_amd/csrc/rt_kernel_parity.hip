@@ -79,6 +79,22 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs_planes    /* A/B: the staged pairs as four planes of 16-byte parts (LDS bank conflicts of the pair fetch) */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_planes
+#define RT_OPT_WALK 1
+#define RT_OPT_PAIR_PLANES 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs_g_w4      /* A/B: the L2 walk under the 4-waves launch bound it shipped with until round 5 (98 registers then) */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_g_w4
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_MINWAVES 4
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_coop_check      /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coop_check
 #define RT_OPT_COOP 2
@@ -136,6 +152,8 @@ static const Instance kParityInstances[] = {
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs_planes::rt_trace_parity_pairs_planes, "rt_trace_parity_pairs_planes", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs_g_w4::rt_trace_parity_pairs_g_w4, "rt_trace_parity_pairs_g_w4", 4, kTabPairsGlobal, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },
     { parity_coop_census::rt_trace_parity_coop_census, "rt_trace_parity_coop_census", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

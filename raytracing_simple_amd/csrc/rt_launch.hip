@@ -186,7 +186,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
         role = rt::kRoleSweepGlobal;
         waves = 4;
     }
-    p.walk_round = c->walk_round;
+    p.walk_round = (c->walk_round & 0xff) | (c->walk_tail << 8);       // (one kernel argument: pair steps in a row | tail lanes << 8)
     const rt::Instance *inst = nullptr;
 #if RT_DIAGNOSTICS
     if (c->persist != 0 && c->mode < 100) {

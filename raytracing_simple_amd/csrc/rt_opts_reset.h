@@ -14,3 +14,4 @@
 #undef RT_OPT_STAMPS
 #undef RT_OPT_TIMELOG
 #undef RT_OPT_EXACT_DECISIONS
+#undef RT_OPT_PAIR_PLANES

@@ -149,9 +149,13 @@ RT_DEV bool bvh_misses(const BvhRay &R, float4 A, float4 B, float t_far) {
 // branch; `both` only moves the stack pointer: the entry above the top is dead).
 // cen (census instance only): [0] pair steps of the wavefront, [1] of this lane, [2]/[3] leaf steps; hist: steps by lanes.
 constexpr uint32_t kWalkDone = 0xffffffffu;
+// `tail` (0 = off): the walk phase ends for everybody once no more than `tail` lanes are still walking (a wave ballot after each
+// round); their walks are lane state and go on in the next trip, beside the walks the other lanes start in between.
+// `plane` (RT_OPT_PAIR_PLANES): the staged pairs lie in four planes of `plane` records (part k of pair m at [k * plane + m]), so
+// that the lanes of a ds_read_b128 group, which sit at different pairs, spread over sixteen 16-byte slots of a bank row, not four.
 RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
-                       uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist) {
+                       uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist, int tail = 0, uint32_t plane = 0) {
     const int lane_ = threadIdx.x & 63;
     uint32_t kind_m = shadow ? 0xffffffffu : 0u;        // all ones: a shadow ray (as a value the compiler does not see through)
     asm("" : "+v"(kind_m));
@@ -166,8 +170,12 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                 }
                 cen[1] += 1ull;
             }
+#if RT_OPT_PAIR_PLANES
+            const float4 A0 = s_pairs[cur], B0 = s_pairs[cur + plane], A1 = s_pairs[cur + 2u * plane], B1 = s_pairs[cur + 3u * plane];
+#else
             const float4 *pp = s_pairs + 4u * cur;
             const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
+#endif
             float tn0, tn1;
             const float t_hi = w_far + R.tback;
             const bool out0 = bvh_misses_upto(R, A0, B0, t_hi, tn0), out1 = bvh_misses_upto(R, A1, B1, t_hi, tn1);
@@ -260,6 +268,7 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
             sp = sp < 0 ? 0 : sp;
         }
+        if (tail > 0 && __popcll(__builtin_amdgcn_ballot_w64(cur != kWalkDone)) <= tail) break;      // (wave-uniform)
     }
 }
 
@@ -344,7 +353,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     {
         const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
         const float4 *g_slots = P.bvh.blob + bvh_slots_at();
+#if RT_OPT_PAIR_PLANES
+        for (uint32_t i = tid; i < 4u * n_pairs; i += kBlockThreads) s_pairs[(i & 3u) * n_pairs + (i >> 2)] = g_pairs[i];
+#else
         for (uint32_t i = tid; i < 4u * n_pairs; i += kBlockThreads) s_pairs[i] = g_pairs[i];
+#endif
         for (uint32_t i = tid; i < n_slots; i += kBlockThreads) s_slots[i] = g_slots[i];
     }
     for (uint32_t i = tid; i < n_lights; i += kBlockThreads) {
@@ -402,11 +415,17 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     V3 nl = mk(0.f, 0.f, 1.f), ld = mk(0.f, 0.f, 0.f);
     float l_k = 0.f;
     uint16_t *my_stack = s_stack + tid;
+#if RT_OPT_PAIR_PLANES && !RT_OPT_GLOBAL_TABLES
+    const uint32_t kPlane = P.bvh.n_leaves - 1u;
+#else
+    const uint32_t kPlane = 0u;
+#endif
 #if RT_OPT_WALK == 2
     // census instance.  cen[0/1] pair steps (two box tests each) per wavefront / per lane, [2/3] leaf steps (kBvhLeaf sphere tests
     // each), [4/5] shade phases, [6/7] clock ticks in the walk / in shading, [8] loop trips, [9] sphere tests of the always-list
     // sweeps -> counters[20..29]; hist[0..3] leaf steps with 1-8 / 9-16 / 17-32 / 33-64 lanes, hist[4..7] pair steps likewise -> counters[8..15]
     unsigned long long cen[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long emu[4] = { 0, 0, 0, 0 };         // (lane 0 only) more rays than lanes, emulated on the walk phases as executed: below
     unsigned long long hist[13] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };      // [8] lanes' non-negative discriminants per leaf step, [9] the largest such count per leaf step, [10] root halves executed, [11] hits, [12] nearer hits -> counters[16..19], [31]
 #define RT_WALK_COUNT(k, mask)                                                                     \
     do {                                                                                         \
@@ -440,19 +459,46 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #endif
 
         // ---- T: every walk in flight runs to its end ----
+#if RT_OPT_WALK == 2
+        const unsigned long long emu_p0 = cen[1], emu_l0 = cen[3];
+#endif
         if (W.cur != kWalkDone) {
 #if RT_OPT_WALK == 2
-            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
-                       W.slot, cen, hist);
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
+                       W.slot, cen, hist, P.walk_round >> 8, kPlane);
 #else
-            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round, W.cur, W.sp, W.far, W.idx,
-                       W.slot, nullptr, nullptr);
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
+                       W.slot, nullptr, nullptr, P.walk_round >> 8, kPlane);
 #endif
         }
 
 #if RT_OPT_WALK == 2
         RT_WALK_CLOCK(cen, 6, t_trip);
         const unsigned long long t_s = __builtin_amdgcn_s_memtime();
+        {
+            // What MORE RAYS THAN LANES would make of this very walk phase, measured on the frame: this lane's steps
+            // of the trip (a leaf step weighs four pair steps: 212 against 54 instructions), the phase's length as executed (the
+            // slowest lane), and its length if lanes l and l + 32 (l, l + 16, l + 32, l + 48) were ONE lane walking their rays one
+            // after the other -- two (four) rays per lane with a free, instant switch.  counters[0..3] = sums over all trips of:
+            // the slowest lane, all lanes' steps, the slowest pair, the slowest four.
+            uint32_t mine = (uint32_t)(cen[1] - emu_p0) + 4u * (uint32_t)(cen[3] - emu_l0);
+            uint32_t two = mine + (uint32_t)__shfl_xor((int)mine, 32, 64);
+            uint32_t four = two + (uint32_t)__shfl_xor((int)two, 16, 64);
+            uint32_t m1 = mine, m2 = two, m4 = four, sum = mine;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                m1 = max(m1, (uint32_t)__shfl_xor((int)m1, off, 64));
+                m2 = max(m2, (uint32_t)__shfl_xor((int)m2, off, 64));
+                m4 = max(m4, (uint32_t)__shfl_xor((int)m4, off, 64));
+                sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+            }
+            if (lane == 0) {
+                emu[0] += m1;
+                emu[1] += sum;
+                emu[2] += m2;
+                emu[3] += m4;
+            }
+        }
 #endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
         const bool ready = (W.cur == kWalkDone) & !finished;
@@ -690,6 +736,8 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             atomicAdd(&P.counters[8 + k], h);
         }
     }
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) atomicAdd(&P.counters[k], emu[k]);
     for (int k = 10; k < 13; ++k) {
         unsigned long long h = hist[k];
 #pragma unroll

@@ -29,6 +29,13 @@ CONFIGS = {
     "c64": (lambda: scenes.random_spheres(64), 1920, 1080, 64),
     "c256": (lambda: scenes.random_spheres(256), 1920, 1080, 32),
     "c4": (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
+    # scenes for the two shipped instances no BASELINE configuration reaches: the 4-wavefront cooperative sweep, the walk over tables in HBM / L2
+    "box120": (lambda: scenes.mirror_box(120), 1920, 1080, 8),
+    "box300": (lambda: scenes.mirror_box(300), 1920, 1080, 8),
+    "box700": (lambda: scenes.mirror_box(700), 1920, 1080, 4),
+    "r2048": (lambda: scenes.random_spheres(2048), 1920, 1080, 8),
+    "r8192": (lambda: scenes.random_spheres(8192), 1920, 1080, 4),
+    "r262144": (lambda: scenes.random_spheres(262144), 1920, 1080, 4),
 }
 
 

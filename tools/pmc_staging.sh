@@ -20,6 +20,24 @@ by = {}
 for r in rows:
     by.setdefault((int(r["Dispatch_Id"]), r["Kernel_Name"], r["Grid_Size"], r["LDS_Block_Size"]), {}).setdefault(r["Counter_Name"], 0.0)
     by[(int(r["Dispatch_Id"]), r["Kernel_Name"], r["Grid_Size"], r["LDS_Block_Size"])][r["Counter_Name"]] += float(r["Counter_Value"])
+order, stage_rates = [], {}
+for line in open(os.path.join(sys.argv[1], "p.log")):
+    if line.startswith("STAGE"):
+        order.append(line.split()[1])
+probes = [k for k in sorted(by) if k[1].startswith("rt_stage_probe")]
+for i, k in enumerate(probes):                 # three staging launches per configuration, in the order of the STAGE lines
+    d = by[k]
+    if i // 3 < len(order):
+        h, m = stage_rates.setdefault(order[i // 3], [0.0, 0.0])
+        stage_rates[order[i // 3]] = [h + d.get("TCC_HIT_sum", 0.0), m + d.get("TCC_MISS_sum", 0.0)]
+if os.environ.get("RT_STAGING_JSON"):
+    import json
+    sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
+    from raytracing_simple_amd import api
+    json.dump({"build_id": api.build_id(diag=True), "what": "TCC hit rate of the render kernels' table staging alone (rt_debug_stage_tables, three launches of the "
+               "render grid per configuration, rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum): north_star's 'L2-hit rate on the LDS-staged sphere reads'",
+               "l2_hit_rate_staged_tables": {k: round(h / max(h + m, 1.0), 4) for k, (h, m) in stage_rates.items()}},
+              open(os.environ["RT_STAGING_JSON"], "w"), indent=1)
 for k in sorted(by):
     d = by[k]
     hit, miss = d.get("TCC_HIT_sum", 0.0), d.get("TCC_MISS_sum", 0.0)

@@ -128,8 +128,11 @@ def main():
         if "valu_busy_frac_single_stream" in summary:
             rec["valu_busy_frac_single_stream"] = round(summary["valu_busy_frac_single_stream"], 4)
         if "hbm_bytes_per_launch" in summary:
-            rec.update({"hbm_bytes_per_launch": int(summary["hbm_bytes_per_launch"]), "fetch_raw_bytes": round(summary["hbm_fetch_bytes_raw"], 1),
-                        "write_bytes": round(summary["hbm_write_bytes"], 1)})
+            rec.update({"hbm_bytes_per_launch": int(summary["hbm_bytes_per_launch"]), "hbm_bytes_per_launch_fetch_x2": int(summary["hbm_bytes_per_launch_fetch_x2"]),
+                        "fetch_raw_bytes": round(summary["hbm_fetch_bytes_raw"], 1), "write_bytes": round(summary["hbm_write_bytes"], 1)})
+        old = (data.get(key) or {}).get(mode) or {}
+        if old.get("build_id") == rec["build_id"] and "l2_hit_rate_staged_tables" in old:     # (tools/pmc_staging.sh of the same library)
+            rec["l2_hit_rate_staged_tables"] = old["l2_hit_rate_staged_tables"]
         if "l2_hit_rate" in summary:
             rec["l2_hit_rate"] = round(summary["l2_hit_rate"], 4)
         if avg.get("SQ_LDS_IDX_ACTIVE"):

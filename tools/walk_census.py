@@ -19,12 +19,15 @@ import bvh_check  # noqa: E402
 names = (sys.argv[1] if len(sys.argv) > 1 else "c3").split(",")
 inst = sys.argv[2] if len(sys.argv) > 2 else "rt_trace_parity_pairs_census"
 product = inst.replace("_census", "")
+tail = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # rt_debug_set_walk: lanes that may be left walking when a trip's walk phase ends
 lib = api.load_library(diag=True)
 for name in names:
     maker, w, h, spp = CONFIGS[name]
     sph, orig, target = maker()
     cam = host.compute_camera(orig, target, w, h)
     with api.RtContext(w, h, diag=True) as ctx:
+        if tail:
+            ctx._check(lib.rt_debug_set_walk(ctx._h, tail, 0, 1))
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         ctx.set_mode(api.instance_mode(product))
@@ -38,7 +41,7 @@ for name in names:
         raw = bvh_check.counters_raw(ctx)
         st = ctx.stats()
     c, hs = raw[20:30], raw[8:18]
-    rec = {"config": name, "instance": inst, "product_ms": round(ms, 3), "census_ms": round(st["last_kernel_ms"], 3),
+    rec = {"config": name, "instance": inst, "tail_lanes": tail, "product_ms": round(ms, 3), "census_ms": round(st["last_kernel_ms"], 3),
            "rays": st["closest_rays"] + st["shadow_rays"],
            "wave_pair_steps": c[0], "lanes_per_pair_step": round(c[1] / max(c[0], 1), 1),
            "wave_leaf_steps": c[2], "lanes_per_leaf_step": round(c[3] / max(c[2], 1), 1),
@@ -53,4 +56,12 @@ for name in names:
     rec.update({"nonneg_per_lane_leaf": round(raw[16] / max(c[3], 1), 2), "largest_nonneg_per_leaf_step": round(raw[17] / max(c[2], 1), 2),
                 "root_halves_per_leaf_step": round(raw[18] / max(c[2], 1), 2), "hits_per_lane_leaf": round(raw[19] / max(c[3], 1), 2),
                 "nearer_per_lane_leaf": round(raw[31] / max(c[3], 1), 2)})
+    # more rays than lanes, emulated on the walk phases this frame executed (rt_walk.inc.h, census instance): lane utilisation of the walk
+    # phase as executed, and if two (four) lanes' rays of every trip were walked by ONE lane one after the other, switching for free
+    m1, tot, m2, m4 = raw[0:4]
+    rec["rays_per_lane_emulation"] = {"lane_utilisation_as_executed": round(tot / max(64 * m1, 1), 3),
+                                      "two_rays_per_lane": round(tot / max(32 * m2, 1), 3), "four_rays_per_lane": round(tot / max(16 * m4, 1), 3),
+                                      "walk_phase_length_vs_executed": {"two": round(2 * m1 / max(m2, 1), 3), "four": round(4 * m1 / max(m4, 1), 3)},
+                                      "note": "steps in pair-step units (a leaf step = 4); an upper bound on what a kernel with that many rays per lane "
+                                              "could reach: the switch between a lane's rays costs nothing here and occupancy is not charged"}
     print(json.dumps(rec), flush=True)
