@@ -353,8 +353,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5", "box300", "r2048"], default="c2",
-                    help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request; box300 / r2048 = scenes "
+    ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5", "box120", "r2048"], default="c2",
+                    help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request; box120 / r2048 = scenes "
                          "that run on the two shipped instances no BASELINE configuration reaches (rt_trace_*_coop, rt_trace_*_pairs_g), for their profiles")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames kept in flight per rank in the throughput region (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
@@ -405,7 +405,7 @@ def main():
         "c3": ("C3: 1024 random spheres", lambda: scenes.random_spheres(1024), 1920, 1080, 16),
         "c4": ("C4: Demo scene (6 spheres)", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
         "c5": ("C5: 64-sphere mirror box, depth 8", lambda: scenes.mirror_box(64), 1920, 1080, 64),
-        "box300": ("closed box of 300 mirror / glass spheres (the 4-wavefront cooperative sweep)", lambda: scenes.mirror_box(300), 1920, 1080, 8),
+        "box120": ("closed box of 120 mirror / glass spheres (the 4-wavefront cooperative sweep)", lambda: scenes.mirror_box(120), 1920, 1080, 8),
         "r2048": ("2048 random spheres (hierarchy tables beyond LDS: read from HBM / L2)", lambda: scenes.random_spheres(2048), 1920, 1080, 8),
     }
     wl_name, wl_maker, W, H, SPP = workloads[args.workload]

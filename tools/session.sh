@@ -22,9 +22,9 @@ if [ "$PART" = "A" ]; then
     raytracing_simple_amd/rt_inflight 1 20 | tee $O/rt_inflight.jsonl; raytracing_simple_amd/rt_inflight 2 20 | tee -a $O/rt_inflight.jsonl
     RT_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_n2_rehearsal.json 2> $O/bench_n2.err; tail -c 300 $O/bench_n2_rehearsal.json
 elif [ "$PART" = "P" ]; then
-    # every shipped parity instance has a stamped record: _w1 (c2), _coop_w1 (c16, c5), _pairs (c3), _coop (box300), _pairs_g (r2048)
-    RT_STAGING_JSON=$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box300 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
-    for spec in "c2 parity" "c2 fast" "c16 parity" "c3 parity" "c5 parity" "box300 parity" "r2048 parity"; do
+    # every shipped parity instance has a stamped record: _w1 (c2), _coop_w1 (c16, c5), _pairs (c3), _coop (box120), _pairs_g (r2048)
+    RT_STAGING_JSON=$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
+    for spec in "c2 parity" "c2 fast" "c16 parity" "c3 parity" "c5 parity" "box120 parity" "r2048 parity"; do
         set -- $spec
         bash tools/profile_gpu.sh $TAG/prof_$1_$2 $2 $1 > $O/prof_$1_$2.log 2>&1; tail -1 $O/prof_$1_$2.log
     done
