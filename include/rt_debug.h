@@ -72,7 +72,7 @@ RT_API int rt_debug_set_choice_estimate(rt_ctx *ctx, int on);  /* 0: the surface
 RT_API int rt_debug_bvh_pick(rt_ctx *ctx);   /* 0 = not decided yet, 1 = the hierarchy, 2 = the plain sweep (of this scene, by measurement) */
 RT_API int rt_debug_read_bvh(rt_ctx *ctx, float *blob_out, uint32_t cap_float4, uint32_t *counts4);
 RT_API int rt_debug_set_wg_waves(rt_ctx *ctx, int waves);          /* 0 = automatic, 1 or 4 wavefronts per workgroup */
-RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order; 1 = heavy first (the default: a new scene's first frame by a guess from the scene, later ones by measured costs); 2 = heavy first with the first frame's tiles priced by a launch of 4 of its passes (rounds 2-4) */
+RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order; 1 = heavy first (the default) */
 RT_API int rt_debug_read_tile_order(rt_ctx *ctx, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid);
 
 /* raw diagnostic counters (section census of the stamped instances; valid after rt_get_stats) */

@@ -187,7 +187,7 @@ static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
 static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v & 0xffffff; c->coop_kmax = v >> 24; return RT_OK; }
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
-static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->guess_order = v == 2 ? 0 : 1; c->order_valid = false; return RT_OK; }
+static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
 static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }
 
 // tuning knob (not part of the contract): 0 = automatic, 1 = free-running, n = gate of n lanes
@@ -211,8 +211,8 @@ RT_API int rt_debug_set_wg_waves(rt_ctx *c, int waves) {    // 0 = automatic, 1 
     if (!c || (waves != 0 && waves != 1 && waves != 4)) return fail(RT_ERR_ARG, "waves %d", waves);
     return dbg_apply(c, dbg_set_wg, waves);
 }
-RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour); 1: heavy first (a new scene by the guess); 2: heavy first, a new scene priced by a launch of 4 passes
-    if (!c || on < 0 || on > 2) return fail(RT_ERR_ARG, "ctx is null / order %d", on);
+RT_API int rt_debug_set_tile_order(rt_ctx *c, int on) {      // 0: tiles in their natural order (the round-1 behaviour); 1: heavy first
+    if (!c || on < 0 || on > 1) return fail(RT_ERR_ARG, "ctx is null / order %d", on);
     return dbg_apply(c, dbg_set_order, on);
 }
 // the tile order in use (valid = 0: none, tiles run in their natural order) and the per-tile costs of the last launch

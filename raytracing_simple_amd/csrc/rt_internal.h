@@ -75,7 +75,6 @@ struct rt_ctx {
     bool cost_valid = false, order_valid = false;
     bool order_stale = false;           // scene or camera have changed since the order was sorted: it stays in use until a long launch sorts it again
     int use_order = 1;
-    int guess_order = 1;                // a new scene's first long launch walks its tiles by a guess from the scene (rt_launch.hip) instead of pricing them with a launch of 4 passes first
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads
     uint32_t stage_cap = 0;             // records per slot
     int stage_next = 0;

@@ -52,69 +52,7 @@ __global__ void __launch_bounds__(1024) rt_order_tiles_kernel(const uint32_t *co
     for (uint32_t i = tid; i < n; i += 1024) order[atomicAdd(&s_hist[1023u - key_of(i) * 1023u / top], 1u)] = i;
 }
 
-// A first guess at what the tiles of a NEW scene will cost, before anything has been rendered: which spheres a tile's primary rays
-// can meet, and what those spheres do to a path.  One thread per tile; the spheres are projected onto the image plane a chunk at a
-// time into LDS (centre and a conservatively grown radius in pixels, from the camera basis the host hands over: a point v from the eye
-// lies on the ray of kcx = v.x / (|x|^2 v.dir), Utility.cpp:71-85 / .cl:494-549), and a tile takes the heaviest material among the
-// spheres whose square meets its own -- glass 8, mirror 5, diffuse 2.5 (a shadow ray and a bounce), a light or the sky 1 -- plus a
-// little for every further sphere.  Scheduling data only, and only until the first launch has left measured costs: a wrong guess
-// costs time at the launch's tail, never a bit.
-__global__ void __launch_bounds__(256) rt_guess_tile_cost_kernel(const rt_sphere *sph, uint32_t n, const rt_camera cam, int w, int h, int tile_w, int grid_x,
-                                                                 uint32_t n_tiles, int rank, int nranks, int tile_rows, uint32_t *cost) {
-    __shared__ float4 s_box[256];
-    __shared__ float s_wt[256];
-    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
-    const int bx = (int)(tile % (uint32_t)grid_x), by = (int)(tile / (uint32_t)grid_x);
-    const int lrow0 = by * rt::kTileH, t = lrow0 / tile_rows;
-    const float tx0 = (float)(bx * tile_w), tx1 = tx0 + (float)tile_w;
-    const float ty0 = (float)((t * nranks + rank) * tile_rows + (lrow0 - t * tile_rows)), ty1 = ty0 + (float)rt::kTileH;
-    const float xx = cam.x.x * cam.x.x + cam.x.y * cam.x.y + cam.x.z * cam.x.z, yy = cam.y.x * cam.y.x + cam.y.y * cam.y.y + cam.y.z * cam.y.z;
-    float best = 1.f, sum = 0.f;
-    for (uint32_t base = 0; base < n; base += 256u) {
-        float4 box = make_float4(1.f, 0.f, 1.f, 0.f);              // empty
-        float wt = 0.f;
-        if (base + threadIdx.x < n) {
-            const rt_sphere S = sph[base + threadIdx.x];
-            const float vx = S.p.x - cam.orig.x, vy = S.p.y - cam.orig.y, vz = S.p.z - cam.orig.z;
-            const float z = vx * cam.dir.x + vy * cam.dir.y + vz * cam.dir.z, r = fabsf(S.rad);
-            const bool light = !(S.e.x == 0.f && S.e.z == 0.f);
-            wt = light ? 1.f : (S.refl == RT_REFR ? 8.f : (S.refl == RT_SPEC ? 5.f : 2.5f));
-            if (!(z + r > 0.1f) || !(xx > 0.f) || !(yy > 0.f)) {
-                wt = 0.f;                                         // behind the eye, or not a number: no tile
-            } else if (!(z - r > 0.25f * r + 0.1f)) {
-                box = make_float4(-1e30f, 1e30f, -1e30f, 1e30f);   // the eye is inside or close by: every tile
-            } else {
-                const float zn = z - r;                           // (the nearest depth: the square only grows by it)
-                const float cx = ((vx * cam.x.x + vy * cam.x.y + vz * cam.x.z) / (xx * z) + 0.5f) * (float)w;
-                const float cy = ((vx * cam.y.x + vy * cam.y.y + vz * cam.y.z) / (yy * z) + 0.5f) * (float)h;
-                const float rx = 1.25f * r / (sqrtf(xx) * zn) * (float)w + 1.f, ry = 1.25f * r / (sqrtf(yy) * zn) * (float)h + 1.f;
-                box = make_float4(cx - rx, cx + rx, cy - ry, cy + ry);
-            }
-        }
-        __syncthreads();
-        s_box[threadIdx.x] = box;
-        s_wt[threadIdx.x] = wt;
-        __syncthreads();
-        const uint32_t m = n - base < 256u ? n - base : 256u;
-        for (uint32_t k = 0; k < m; ++k) {
-            const float4 b = s_box[k];
-            if (b.x < tx1 && b.y > tx0 && b.z < ty1 && b.w > ty0) {     // (false for the empty square and for NaN)
-                best = fmaxf(best, s_wt[k]);
-                sum += s_wt[k];
-            }
-        }
-    }
-    if (tile < n_tiles) cost[tile] = (uint32_t)(best * 64.f + fminf(sum, 60.f));
-}
-
 namespace rt {
-
-constexpr uint32_t kGuessMaxSpheres = 2048;         // beyond: the first frame prices its tiles with four of its passes, as before
-
-// the tiles of a scene nothing has been rendered of yet can be ordered by the guess above (instead of by a pricing launch)
-static bool order_can_be_guessed(const rt_ctx *c) {
-    return c->guess_order != 0 && c->use_order && c->d_tile_cost && c->d_spheres && c->scene.n_spheres > 0 && c->scene.n_spheres <= kGuessMaxSpheres;
-}
 
 rt::LaunchParams make_params(rt_ctx *c, int n_samples) {
     rt::LaunchParams p{};
@@ -282,16 +220,6 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
             c->order_stale = false;
-        } else if (!c->cost_valid && !c->order_valid && n_samples >= 8 && !natural_order && order_can_be_guessed(c)) {
-            // a new scene: heavy tiles first by the guess (materials in front of each tile), in THIS launch -- no pricing launch; the
-            // launch overwrites the guessed costs with measured ones as its workgroups finish, and the next long launch sorts by those
-            hipLaunchKernelGGL(rt_guess_tile_cost_kernel, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, c->d_spheres, c->scene.n_spheres, c->cam,
-                               c->w, c->h, tile_w, (int)grid.x, n_tiles, c->rank, c->nranks, c->tile_rows, c->d_tile_cost);
-            HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
-            HIP_TRY(hipGetLastError());
-            c->order_valid = true;
-            c->order_stale = true;              // (sorted again from measured costs as soon as there are any)
         }
         if (c->order_valid && !natural_order) p.order = c->d_order;
     }
@@ -410,7 +338,7 @@ void rearm_probe_if_changed(rt_ctx *c) {
 constexpr int kPricePasses = 4, kPriceFrom = 24;
 static int launch_priced(rt_ctx *c, int n_samples, hipStream_t stream, int form) {
     const bool explicit_mode = form == 0;
-    if (!explicit_mode && c->use_order && c->d_tile_cost && n_samples >= kPriceFrom && !c->order_valid && !c->cost_valid && !order_can_be_guessed(c)) {
+    if (!explicit_mode && c->use_order && c->d_tile_cost && n_samples >= kPriceFrom && !c->order_valid && !c->cost_valid) {
         const int rc = launch_form(c, kPricePasses, stream, form);
         if (rc != RT_OK) return rc;
         n_samples -= kPricePasses;

@@ -268,7 +268,9 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
             sp = sp < 0 ? 0 : sp;
         }
+#if RT_DIAGNOSTICS      // (an experiment's knob, profiles/r05_walk_ab_c3.jsonl: the product kernel's loop does not carry its compare and branch)
         if (tail > 0 && __popcll(__builtin_amdgcn_ballot_w64(cur != kWalkDone)) <= tail) break;      // (wave-uniform)
+#endif
     }
 }
 

@@ -3,9 +3,10 @@
 
     python tools/first_frame_ab.py [c2,c16,c3,c5,...] > profiles/rNN_first_frame_ab.jsonl
 
-  guess     heavy tiles first by the guess from the scene (rt_guess_tile_cost_kernel: the materials in front of each tile), ONE launch (default since round 5)
-  priced    four of the frame's passes first, in image order, to price the tiles; the rest heavy first (rounds 2-4)
+  priced    four of the frame's passes first, in image order, to price the tiles; the rest heavy first (the library's way)
   natural   image order
+(Round 5 also measured a GUESS from the scene -- the materials in front of each tile -- in the place of the pricing launch: level with it
+on C2 / 16 spheres / C4 / C5, -2 % on C3, +1..4 % on 64 / 256 scattered spheres: profiles/r05_first_frame_guess_ab.jsonl, code at 2980596.)
 Each figure is the device time between the events around everything the blocking frame launched, on a fresh context (GPU warm),
 median of 5; `steady` is the same frame rendered again with measured costs.  Frames are compared bit for bit."""
 import json
@@ -21,7 +22,7 @@ from raytracing_simple_amd import api, host  # noqa: E402
 from tools.ab_bench import CONFIGS  # noqa: E402
 
 lib = api.load_library(diag=True)
-ARMS = {"guess": 1, "priced": 2, "natural": 0}
+ARMS = {"priced": 1, "natural": 0}
 for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2,c16,c3,c5").split(","):
     maker, w, h, spp = CONFIGS[cname]
     sph, orig, target = maker()
@@ -39,7 +40,7 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2,c16,c3,c5").split(","):
                 if r > 0:
                     ms[arm].append(st["last_kernel_ms"])
                 launches[arm], pix[arm] = int(st["launches"]), px
-                if arm == "guess" and r > 0:
+                if arm == "priced" and r > 0:
                     for _ in range(2):
                         c.reset()
                         c.render_pass(spp, copy=False)
@@ -47,7 +48,7 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2,c16,c3,c5").split(","):
     # the same first frame on a context that has just rendered ANOTHER scene (buffers, streams and code warm; only the scene is new):
     # what a host that keeps its context -- or calls rt_render again at the same size -- pays for a new scene
     other = host.demo_scene() if len(sph) != 6 else CONFIGS["c16"][0]()[0]
-    warm = {a: [] for a in ("guess", "priced")}
+    warm = {a: [] for a in ("priced",)}
     for arm in warm:
         with api.RtContext(w, h, diag=True) as c:
             c._check(lib.rt_debug_set_tile_order(c._h, ARMS[arm]))

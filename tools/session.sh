@@ -23,8 +23,12 @@ if [ "$PART" = "A" ]; then
     RT_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_n2_rehearsal.json 2> $O/bench_n2.err; tail -c 300 $O/bench_n2_rehearsal.json
 elif [ "$PART" = "P" ]; then
     # every shipped parity instance has a stamped record: _w1 (c2), _coop_w1 (c16, c5), _pairs (c3), _coop (box120), _pairs_g (r2048)
-    RT_STAGING_JSON=$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
-    for spec in "c2 parity" "c2 fast" "c16 parity" "c3 parity" "c5 parity" "box120 parity" "r2048 parity"; do
+    # (RT_PROF_SPECS="c2 parity;c3 parity" limits the call to some of them: all seven take about 25 minutes of box time)
+    if [ -z "${RT_PROF_SPECS:-}" ] || [ "${RT_PROF_STAGING:-0}" = "1" ]; then
+        RT_STAGING_JSON=$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
+    fi
+    IFS=';' read -ra SPECS <<< "${RT_PROF_SPECS:-c2 parity;c2 fast;c16 parity;c3 parity;c5 parity;box120 parity;r2048 parity}"
+    for spec in "${SPECS[@]}"; do
         set -- $spec
         bash tools/profile_gpu.sh $TAG/prof_$1_$2 $2 $1 > $O/prof_$1_$2.log 2>&1; tail -1 $O/prof_$1_$2.log
     done
