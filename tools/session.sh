@@ -25,7 +25,7 @@ elif [ "$PART" = "P" ]; then
     # every shipped parity instance has a stamped record: _w1 (c2), _coop_w1 (c16, c5), _pairs (c3), _coop (box120), _pairs_g (r2048)
     # (RT_PROF_SPECS="c2 parity;c3 parity" limits the call to some of them: all seven take about 25 minutes of box time)
     if [ -z "${RT_PROF_SPECS:-}" ] || [ "${RT_PROF_STAGING:-0}" = "1" ]; then
-        RT_STAGING_JSON=$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
+        RT_STAGING_JSON=$(pwd)/$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
     fi
     IFS=';' read -ra SPECS <<< "${RT_PROF_SPECS:-c2 parity;c2 fast;c16 parity;c3 parity;c5 parity;box120 parity;r2048 parity}"
     for spec in "${SPECS[@]}"; do
