@@ -152,6 +152,7 @@ enum InstanceFlags : uint8_t {
     kInstPersistent = 1,    // the grid only fills the machine; tiles come from the queue at counters[30]
     kInstNoTileCost = 2,    // neither reads the heavy-first order nor leaves per-tile costs
     kInstStaticCoop = 4,    // carries the cooperative any-hit mailbox (1.5 KiB of static LDS per wavefront)
+    kInstTwoRays = 8,       // diagnostics: two pixels per lane -- a wavefront's tile is 16 x 8, and every lane has two stacks
 };
 struct Instance {
     void (*fn)(const LaunchParams);

@@ -87,6 +87,21 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs_2r        /* A/B: the hierarchy walk with TWO pixels per lane (RT_OPT_RAYS2): both rays' state in registers, 3 wavefronts per SIMD */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_2r
+#define RT_OPT_WALK 1
+#define RT_OPT_RAYS2 1
+#define RT_OPT_MINWAVES 3
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs_2r_census /* ... and its census (steps, lanes per step) */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_2r_census
+#define RT_OPT_WALK 2
+#define RT_OPT_RAYS2 1
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_pairs_g_w4      /* A/B: the L2 walk under the 4-waves launch bound it shipped with until round 5 (98 registers then) */
 #define RT_KERNEL_NAME rt_trace_parity_pairs_g_w4
 #define RT_OPT_WALK 1
@@ -153,6 +168,8 @@ static const Instance kParityInstances[] = {
 #if RT_DIAGNOSTICS
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_planes::rt_trace_parity_pairs_planes, "rt_trace_parity_pairs_planes", 4, kTabPairsLds, kRoleNone, 0 },
+    { parity_pairs_2r::rt_trace_parity_pairs_2r, "rt_trace_parity_pairs_2r", 4, kTabPairsLds, kRoleNone, kInstTwoRays },
+    { parity_pairs_2r_census::rt_trace_parity_pairs_2r_census, "rt_trace_parity_pairs_2r_census", 4, kTabPairsLds, kRoleNone, kInstTwoRays },
     { parity_pairs_g_w4::rt_trace_parity_pairs_g_w4, "rt_trace_parity_pairs_g_w4", 4, kTabPairsGlobal, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },

@@ -134,7 +134,7 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
             break;
         case rt::kTabPairsLds:
             p.mat_in_lds = 0;               // (the walk reads a hit's material by slot from the hierarchy's blob: nothing of it is staged)
-            lds = pairs_lds(c, false, n_samples, inst.waves);
+            lds = pairs_lds(c, false, n_samples, inst.waves * ((inst.flags & rt::kInstTwoRays) ? 2 : 1));
             break;
         case rt::kTabPairsGlobal:
             p.mat_in_lds = 0;
@@ -206,7 +206,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     if (rc != RT_OK) return rc;
     const bool persist = (inst->flags & rt::kInstPersistent) != 0;
 
-    const int tile_w = 8 * inst->waves;
+    const int tile_w = 8 * inst->waves * ((inst->flags & rt::kInstTwoRays) ? 2 : 1);
     dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
     // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
     // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)

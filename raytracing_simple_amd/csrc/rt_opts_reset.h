@@ -15,3 +15,4 @@
 #undef RT_OPT_TIMELOG
 #undef RT_OPT_EXACT_DECISIONS
 #undef RT_OPT_PAIR_PLANES
+#undef RT_OPT_RAYS2

@@ -74,6 +74,9 @@
 // sample lies on (.cl:283-296), total internal reflection (.cl:438), the Fresnel roulette (.cl:470) -- in uncontracted,
 // correctly rounded binary32 as in parity mode; everything continuous (hit points, normals, directions, weights, sine / cosine,
 // gamma) fused and on the hardware's approximations as in fast mode.
+#ifndef RT_OPT_RAYS2
+#define RT_OPT_RAYS2 0                  /* diagnostics: the hierarchy walk with two pixels per lane (rt_walk.inc.h) */
+#endif
 #ifndef RT_OPT_PAIR_PLANES
 #define RT_OPT_PAIR_PLANES 0            /* diagnostics: the walk's staged pairs in four 16-byte planes (rt_walk.inc.h) */
 #endif

@@ -155,7 +155,8 @@ constexpr uint32_t kWalkDone = 0xffffffffu;
 // that the lanes of a ds_read_b128 group, which sit at different pairs, spread over sixteen 16-byte slots of a bank row, not four.
 RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
-                       uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist, int tail = 0, uint32_t plane = 0) {
+                       uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist, int tail = 0, uint32_t plane = 0,
+                       bool once = false) {
     const int lane_ = threadIdx.x & 63;
     uint32_t kind_m = shadow ? 0xffffffffu : 0u;        // all ones: a shadow ray (as a value the compiler does not see through)
     asm("" : "+v"(kind_m));
@@ -268,6 +269,7 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
             cur = sp >= 0 ? (uint32_t)my_stack[sp * stack_stride] : kWalkDone;
             sp = sp < 0 ? 0 : sp;
         }
+        if (once) break;        // (RT_OPT_RAYS2: one round per call, the caller's loop decides whose ray walks next; a constant everywhere else)
 #if RT_DIAGNOSTICS      // (an experiment's knob, profiles/r05_walk_ab_c3.jsonl: the product kernel's loop does not carry its compare and branch)
         if (tail > 0 && __popcll(__builtin_amdgcn_ballot_w64(cur != kWalkDone)) <= tail) break;      // (wave-uniform)
 #endif
@@ -304,7 +306,12 @@ struct PathCtl {
 
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;
-    constexpr int kTileW = 8 * RT_OPT_WG_WAVES;
+    // RT_OPT_RAYS2 (diagnostics): TWO pixels per lane -- (x, y) and (x + 8, y): a wavefront renders 16 x 8 pixels.
+    // One of a lane's two rays is `at hand` (the variables below, as ever), the other parked in a second set of registers; a lane whose
+    // ray at hand has ended its walk takes up the parked one's inside the walk phase, and the shade phase runs once for either set.
+    constexpr int kRaysPerLane = RT_OPT_RAYS2 ? 2 : 1;
+    constexpr int kTileW = 8 * RT_OPT_WG_WAVES * kRaysPerLane;
+    constexpr int kStackStride = kBlockThreads * kRaysPerLane;
     extern __shared__ float4 lds[];
     const uint32_t n = P.scene.n_spheres;
     const uint32_t n_lights = P.scene.n_lights;
@@ -312,7 +319,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     // (the scene index of a slot is only read for a candidate that passes the test: from HBM / L2, not staged)
     const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + bvh_index_at(n_slots));
     float4 *s_hdr = lds;
-    const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kBlockThreads * 2u + 15u) / 16u;
+    const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kStackStride * 2u + 15u) / 16u;
 #if RT_OPT_GLOBAL_TABLES
     const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
     const float4 *s_slots = P.bvh.blob + bvh_slots_at();
@@ -382,7 +389,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const unsigned block_linear = blockIdx.x + blockIdx.y * gridDim.x;
     const unsigned tile_id = P.order ? P.order[block_linear] : block_linear;
     const int tile_by = (int)(tile_id / gridDim.x), tile_bx = (int)(tile_id - (unsigned)tile_by * gridDim.x);
-    int x = tile_bx * kTileW + wave * 8 + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
+    int x = tile_bx * kTileW + wave * 8 * kRaysPerLane + (lane & 7), lrow = tile_by * kTileH + (lane >> 3);
     const int rtile = lrow / P.tile_rows;
     const int y = (rtile * P.nranks + P.rank) * P.tile_rows + (lrow - rtile * P.tile_rows);
     const bool valid = (x < P.w) && (lrow < P.local_rows) && (y < P.h);
@@ -417,6 +424,41 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     V3 nl = mk(0.f, 0.f, 1.f), ld = mk(0.f, 0.f, 0.f);
     float l_k = 0.f;
     uint16_t *my_stack = s_stack + tid;
+#if RT_OPT_RAYS2
+    // the lane's second pixel, parked: everything a ray is
+    struct Parked {
+        PathCtl ctl; V3 o, d, thr, rad; Walk W; BvhRay R; V3 nl, ld; float l_k; uint16_t *stack; uint32_t s0, s1; V3 acc; int s, s_end; uint32_t xy;
+    };
+    Parked pk{ PathCtl{ kNew | 64u }, o, d, thr, rad, W, R, nl, ld, 0.f, s_stack + tid + kBlockThreads, 0u, 0u, mk(0.f, 0.f, 0.f), P.first_sample, P.first_sample, 0u };
+    {
+        const int x2 = x + 8;
+        const bool valid2 = (x2 < P.w) && (lrow < P.local_rows) && (y < P.h);
+        pk.xy = (uint32_t)x2 | ((uint32_t)y << 16);
+        pk.s_end = valid2 ? P.first_sample + P.n_samples : P.first_sample;
+        if (valid2) {
+            const size_t gid2 = (size_t)y * (size_t)P.w + (size_t)x2, ci2 = (size_t)(P.h - y - 1) * (size_t)P.w + (size_t)x2;
+            const uint2 sd2 = *reinterpret_cast<const uint2 *>(P.seeds_in + 2 * gid2);
+            pk.s0 = sd2.x;
+            pk.s1 = sd2.y;
+            if (P.first_sample > 0) pk.acc = mk(P.colors[3 * ci2], P.colors[3 * ci2 + 1], P.colors[3 * ci2 + 2]);
+        }
+    }
+    int s_end_now = s_end;          // (`s_end` and `xy` are constants of the one-ray kernel: the two-ray one swaps them with the rest)
+    uint32_t xy_now_ = xy;
+#define RT_XY_ xy_now_
+#define RT_SWAP_(a, b) do { auto t_ = (a); (a) = (b); (b) = t_; } while (0)
+#define RT_SWAP_V3_(a, b) do { RT_SWAP_((a).x, (b).x); RT_SWAP_((a).y, (b).y); RT_SWAP_((a).z, (b).z); } while (0)
+    auto swap_rays = [&]() {
+        RT_SWAP_(ctl.v, pk.ctl.v); RT_SWAP_V3_(o, pk.o); RT_SWAP_V3_(d, pk.d); RT_SWAP_V3_(thr, pk.thr); RT_SWAP_V3_(rad, pk.rad);
+        RT_SWAP_(W.cur, pk.W.cur); RT_SWAP_(W.sp, pk.W.sp); RT_SWAP_(W.far, pk.W.far); RT_SWAP_(W.idx, pk.W.idx); RT_SWAP_(W.slot, pk.W.slot);
+        RT_SWAP_V3_(R.clo, pk.R.clo); RT_SWAP_V3_(R.chi, pk.R.chi); RT_SWAP_V3_(R.inv, pk.R.inv); RT_SWAP_(R.tback, pk.R.tback);
+        RT_SWAP_V3_(nl, pk.nl); RT_SWAP_V3_(ld, pk.ld); RT_SWAP_(l_k, pk.l_k); RT_SWAP_(my_stack, pk.stack);
+        RT_SWAP_(s0, pk.s0); RT_SWAP_(s1, pk.s1); RT_SWAP_V3_(acc, pk.acc); RT_SWAP_(s, pk.s); RT_SWAP_(s_end_now, pk.s_end); RT_SWAP_(xy_now_, pk.xy);
+    };
+#else
+    const int s_end_now = s_end;
+#define RT_XY_ xy
+#endif
 #if RT_OPT_PAIR_PLANES && !RT_OPT_GLOBAL_TABLES
     const uint32_t kPlane = P.bvh.n_leaves - 1u;
 #else
@@ -453,13 +495,34 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 
     for (;;) {
         // (a lane that has rendered its samples stays in the loop, idle, until its wavefront has: the loop's exit is a scalar branch)
+#if RT_OPT_RAYS2
+        if (__builtin_amdgcn_ballot_w64(!(ctl.st() == kNew && s >= s_end_now) || !(pk.ctl.st() == kNew && pk.s >= pk.s_end)) == 0ull) break;
+#else
         const bool finished = ctl.st() == kNew && s >= s_end;
         if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) break;
+#endif
 #if RT_OPT_WALK == 2
         cen[8] += (lane == __ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) ? 1ull : 0ull;
         const unsigned long long t_trip = __builtin_amdgcn_s_memtime();
 #endif
 
+#if RT_OPT_RAYS2
+        // ---- T, two rays per lane: round by round; a lane whose ray at hand has ended its walk takes up the parked one's ----
+        for (;;) {
+            const bool take = (W.cur == kWalkDone) & (pk.W.cur != kWalkDone);
+            if (__builtin_amdgcn_ballot_w64((W.cur != kWalkDone) | take) == 0ull) break;
+            if (take) swap_rays();
+            if (W.cur != kWalkDone) {
+#if RT_OPT_WALK == 2
+                walk_pairs(s_pairs, s_slots, s_index, my_stack, kStackStride, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
+                           W.slot, cen, hist, 0, kPlane, true);
+#else
+                walk_pairs(s_pairs, s_slots, s_index, my_stack, kStackStride, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
+                           W.slot, nullptr, nullptr, 0, kPlane, true);
+#endif
+            }
+        }
+#else
         // ---- T: every walk in flight runs to its end ----
 #if RT_OPT_WALK == 2
         const unsigned long long emu_p0 = cen[1], emu_l0 = cen[3];
@@ -501,6 +564,19 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 emu[3] += m4;
             }
         }
+#endif
+#endif      // !RT_OPT_RAYS2
+#if RT_OPT_RAYS2
+#if RT_OPT_WALK == 2
+        RT_WALK_CLOCK(cen, 6, t_trip);
+        const unsigned long long t_s = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- S, once for the ray at hand and once for the other (every walk has ended: whoever has a ray shades) ----
+#pragma nounroll
+        for (int side = 0; side < 2; ++side) {
+        const bool finished = ctl.st() == kNew && s >= s_end_now;
+#else
+        {
 #endif
         // ---- S: lanes whose walk has ended, once enough of them wait ----
         const bool ready = (W.cur == kWalkDone) & !finished;
@@ -662,7 +738,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 ctl.set_st(kNew);
                 start = 0;
             }
-            if (ctl.st() == kNew && start == 0 && s < s_end) {
+            if (ctl.st() == kNew && start == 0 && s < s_end_now) {
                 {
                     // ---- camera ray, .cl:494-549 (a finished path's next sample; the first sample of the launch); the camera
                     //      (12 floats) and 1/w, 1/h come from LDS, once per sample ----
@@ -675,7 +751,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     float j1 = next_random_centred(s0, s1);
                     float j2 = next_random_centred(s0, s1);
                     c_draws += 2;
-                    uint32_t xy_now = xy;
+                    uint32_t xy_now = RT_XY_;
                     asm volatile("; pixel coordinates unpacked per sample" : "+v"(xy_now));       // (as in rt_trace.inc.h: not hoisted into two more registers)
                     float kcx = ((float)(xy_now & 0xffffu) + j1) * inv_w - 0.5f;
                     float kcy = ((float)(xy_now >> 16) + j2) * inv_h - 0.5f;
@@ -721,6 +797,10 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 W.sp = 0;
             }
         }
+#if RT_OPT_RAYS2
+        swap_rays();
+#endif
+        }       // (the shade phase: once, or once per ray of the lane)
 #if RT_OPT_WALK == 2
         RT_WALK_CLOCK(cen, 7, t_s);
 #endif
@@ -753,9 +833,17 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         (const __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("; epilogue arguments re-read" : "+s"(qp));
     const __attribute__((address_space(4))) LaunchParams &Q = *qp;
-    const bool valid_e = s_end != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
+    uint32_t n_done = 0u;
+#if RT_OPT_RAYS2
+#pragma nounroll
+    for (int side = 0; side < 2; ++side) {
+#else
+    {
+#endif
+    const bool valid_e = s_end_now != Q.first_sample;       // (s_end was first_sample + n_samples for the lanes that own a pixel)
+    n_done += valid_e ? (uint32_t)Q.n_samples : 0u;
     if (valid_e && Q.n_samples > 0) {
-        uint32_t xy_e = xy;
+        uint32_t xy_e = RT_XY_;
         asm volatile("; pixel coordinates unpacked after the loop" : "+v"(xy_e));
         const int xe = (int)(xy_e & 0xffffu), ye = (int)(xy_e >> 16);
         int le = tile_by * kTileH + ((int)(threadIdx.x & 63u) >> 3);
@@ -770,7 +858,13 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);
     }
-    uint32_t n_done = valid_e ? (uint32_t)Q.n_samples : 0u;
+#if RT_OPT_RAYS2
+    swap_rays();
+#endif
+    }       // (the lane's pixel, or its two)
+#undef RT_XY_
+#undef RT_SWAP_
+#undef RT_SWAP_V3_
     uint32_t t_samples = wave_sum(n_done);
     uint32_t t_closest = wave_sum(c_closest);
     uint32_t t_shadow = wave_sum(c_shadow);
