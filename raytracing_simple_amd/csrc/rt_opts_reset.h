@@ -16,3 +16,4 @@
 #undef RT_OPT_EXACT_DECISIONS
 #undef RT_OPT_PAIR_PLANES
 #undef RT_OPT_RAYS2
+#undef RT_OPT_SWEEP2P
