@@ -87,23 +87,6 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
-#define RT_NS parity_coop_w1_2p      /* A/B: cooperative any-hit + the closest-hit sweep in two passes (RT_OPT_SWEEP2P) */
-#define RT_KERNEL_NAME rt_trace_parity_coop_w1_2p
-#define RT_OPT_WG_WAVES 1
-#define RT_OPT_COOP 1
-#define RT_OPT_SWEEP2P 1
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
-#define RT_NS parity_coop_2p
-#define RT_KERNEL_NAME rt_trace_parity_coop_2p
-#define RT_OPT_COOP 1
-#define RT_OPT_SWEEP2P 1
-#define RT_OPT_MINWAVES 5
-#include "rt_trace.inc.h"
-#include "rt_opts_reset.h"
-
 #define RT_NS parity_pairs_2r        /* A/B: the hierarchy walk with TWO pixels per lane (RT_OPT_RAYS2): both rays' state in registers, 3 wavefronts per SIMD */
 #define RT_KERNEL_NAME rt_trace_parity_pairs_2r
 #define RT_OPT_WALK 1
@@ -185,8 +168,6 @@ static const Instance kParityInstances[] = {
 #if RT_DIAGNOSTICS
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },
     { parity_pairs_planes::rt_trace_parity_pairs_planes, "rt_trace_parity_pairs_planes", 4, kTabPairsLds, kRoleNone, 0 },
-    { parity_coop_w1_2p::rt_trace_parity_coop_w1_2p, "rt_trace_parity_coop_w1_2p", 1, kTabSweepLds, kRoleNone, kInstStaticCoop },
-    { parity_coop_2p::rt_trace_parity_coop_2p, "rt_trace_parity_coop_2p", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_pairs_2r::rt_trace_parity_pairs_2r, "rt_trace_parity_pairs_2r", 4, kTabPairsLds, kRoleNone, kInstTwoRays },
     { parity_pairs_2r_census::rt_trace_parity_pairs_2r_census, "rt_trace_parity_pairs_2r_census", 4, kTabPairsLds, kRoleNone, kInstTwoRays },
     { parity_pairs_g_w4::rt_trace_parity_pairs_g_w4, "rt_trace_parity_pairs_g_w4", 4, kTabPairsGlobal, kRoleNone, 0 },

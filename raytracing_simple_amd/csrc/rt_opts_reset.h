@@ -16,4 +16,3 @@
 #undef RT_OPT_EXACT_DECISIONS
 #undef RT_OPT_PAIR_PLANES
 #undef RT_OPT_RAYS2
-#undef RT_OPT_SWEEP2P

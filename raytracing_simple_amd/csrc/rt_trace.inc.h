@@ -74,9 +74,6 @@
 // sample lies on (.cl:283-296), total internal reflection (.cl:438), the Fresnel roulette (.cl:470) -- in uncontracted,
 // correctly rounded binary32 as in parity mode; everything continuous (hit points, normals, directions, weights, sine / cosine,
 // gamma) fused and on the hardware's approximations as in fast mode.
-#ifndef RT_OPT_SWEEP2P
-#define RT_OPT_SWEEP2P 0                /* the closest-hit sweep in two passes: every lane its own candidates (scenes whose rays have lost each other) */
-#endif
 #ifndef RT_OPT_RAYS2
 #define RT_OPT_RAYS2 0                  /* diagnostics: the hierarchy walk with two pixels per lane (rt_walk.inc.h) */
 #endif
@@ -352,37 +349,6 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
         }
     }
 }
-
-#if RT_OPT_SWEEP2P
-// Closest hit in two passes, for rays that no longer travel together (a box of mirrors: C5).  The sweep above runs a sphere's root
-// half for the whole wavefront as soon as ONE lane's line meets the sphere -- with 64 unrelated rays that is most spheres, although
-// a single ray's line meets only a few.  Here every lane first notes, 32 spheres at a time, which discriminants are non-negative
-// (one bit each), then works off ITS OWN candidates in ascending order -- the sphere fetched per lane, the test made again in full.
-// The rule `nearer, and the lower index among equals` (.cl:215-232) only needs the candidates in ascending order, and a sphere whose
-// discriminant is negative or not a number returns 0 in the reference (.cl:185-200): same bits.
-RT_DEV void sweep_closest_2p(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id) {
-    for (uint32_t base = 0; base < n; base += 32u) {
-        const uint32_t m = n - base < 32u ? n - base : 32u;
-        uint32_t cand = 0u;
-        uint32_t i = 0;
-        for (; i + 2 <= m; i += 2) {
-            const float4 g0 = s_geom[base + i], g1 = s_geom[base + i + 1];
-            const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
-            cand |= (p0.det >= 0.f ? 1u : 0u) << i;
-            cand |= (p1.det >= 0.f ? 2u : 0u) << i;
-        }
-        if (i < m) cand |= (hit_pre(s_geom[base + i], o, d).det >= 0.f ? 1u : 0u) << i;
-        while (__builtin_amdgcn_ballot_w64(cand != 0u) != 0ull) {
-            if (cand != 0u) {
-                const uint32_t k = base + (uint32_t)__builtin_ctz(cand);
-                cand &= cand - 1u;
-                const HitRoots h = hit_roots(hit_pre(s_geom[k], o, d));
-                if (h.hit && h.t < t) { t = h.t; id = k; }
-            }
-        }
-    }
-}
-#endif
 
 // any hit closer than max_t, .cl:234-247.  Returns the index of the first blocking sphere, or n.
 // A lane stops looking at its first hit; the wavefront leaves when every active lane has one.
@@ -809,11 +775,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         uint32_t id = 0;
         RT_STAMP(1);
         st_roots_c = 0;
-#if RT_OPT_SWEEP2P
-        sweep_closest_2p(s_geom, n, o, d, t, id);
-#else
         sweep_closest(s_geom, n, o, d, t, id, st_roots_c);
-#endif
         RT_STAMP_ROOTS(10, st_roots_c);
         c_closest += 1;
 
