@@ -41,7 +41,7 @@ for cname in (sys.argv[1] if len(sys.argv) > 1 else "c2,c16,c3,c5").split(","):
                     ms[arm].append(st["last_kernel_ms"])
                 launches[arm], pix[arm] = int(st["launches"]), px
                 if arm == "priced" and r > 0:
-                    for _ in range(2):
+                    for _ in range(6):              # (the order settles over a few frames: fewer, and `steady` is not)
                         c.reset()
                         c.render_pass(spp, copy=False)
                     steady.append(c.stats()["last_kernel_ms"])
