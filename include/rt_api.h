@@ -92,8 +92,9 @@ enum rt_mode {
 };
 
 #define RT_MAX_SPHERES 262144u /* (the hierarchy numbers its leaves of 8 spheres with 15 bits.  Its tables are staged in LDS while
-                                 * five workgroups of that size fit a CU -- 31 KiB, about 1 100 spheres -- and read from HBM / L2
-                                 * beyond; the plain sweep's table fits LDS up to about 9 700 spheres)                            */
+                                 * five workgroups of that size fit a CU -- 31 KiB, about 1 100 spheres; to about 3 200 spheres its
+                                 * pairs still are and only the leaves' spheres are read from HBM / L2 ("..._pairs_m"); beyond,
+                                 * everything is ("..._pairs_g"); the plain sweep's table fits LDS up to about 9 700 spheres)     */
 
 typedef struct rt_ctx rt_ctx;
 

@@ -136,6 +136,7 @@ enum InstanceTables : uint8_t {
     kTabSweepGlobal = 1,    // ... read where they lie in HBM / L2
     kTabPairsLds = 2,       // the hierarchy (pairs, slots, stacks) staged in LDS (lds_bytes_pairs); needs BvhTables
     kTabPairsGlobal = 3,    // ... pairs and slots read where they lie; staged: header and stacks; needs BvhTables
+    kTabPairsLdsSlotsGlobal = 4,   // ... the pairs staged, the slots read where they lie (the pairs fit the LDS budget, the whole tables do not)
 };
 enum InstanceRole : uint8_t {
     kRoleNone = 0,          // diagnostics: reachable by row / name only
@@ -143,6 +144,7 @@ enum InstanceRole : uint8_t {
     kRoleCoop,              // 12 spheres and more: cooperative any-hit
     kRolePairs,             // large scenes through the hierarchy
     kRolePairsGlobal,       // ... tables beyond the LDS budget
+    kRolePairsMixed,        // ... whose pairs still fit it (rt_trace_*_pairs_m)
     kRoleSweepGlobal,       // no hierarchy (or it lost the measurement) and a table beyond LDS
     kRolePersist,           // diagnostics: persistent wavefronts (rt_debug_set_persist)
     kRolePersistCoop,

@@ -53,6 +53,14 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS fast_pairs_m           /* tables beyond LDS whose PAIRS still fit it: pairs staged, slots where they lie in HBM / L2 */
+#define RT_KERNEL_NAME rt_trace_fast_pairs_m
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 2
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS fast_g
 #define RT_KERNEL_NAME rt_trace_fast_g
 #define RT_OPT_GLOBAL_TABLES 1
@@ -115,6 +123,7 @@ static const Instance kFastInstances[] = {
     { fast_coop_w1::rt_trace_fast_coop_w1, "rt_trace_fast_coop_w1", 1, kTabSweepLds, kRoleCoop, kInstStaticCoop },
     { fast_pairs::rt_trace_fast_pairs, "rt_trace_fast_pairs", 4, kTabPairsLds, kRolePairs, 0 },
     { fast_pairs_g::rt_trace_fast_pairs_g, "rt_trace_fast_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, 0 },
+    { fast_pairs_m::rt_trace_fast_pairs_m, "rt_trace_fast_pairs_m", 4, kTabPairsLdsSlotsGlobal, kRolePairsMixed, 0 },
     { fast_g::rt_trace_fast_g, "rt_trace_fast_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { fast::rt_sched_fast, "rt_sched_fast", 4, kTabSweepLds, kRoleNone, kInstNoTileCost },

@@ -2,7 +2,7 @@
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
 // Shipped (librt_hip.so): rt_trace_parity / _w1 (small scenes, 4- / single-wavefront workgroups), rt_trace_parity_coop /
 // _coop_w1 (12 spheres and more: cooperative any-hit), rt_trace_parity_pairs (many small spheres: the hierarchy,
-// rt_walk.inc.h), rt_trace_parity_pairs_g / rt_trace_parity_g (tables beyond LDS).  Everything else exists only in the
+// rt_walk.inc.h), rt_trace_parity_pairs_m / _pairs_g / rt_trace_parity_g (tables beyond LDS).  Everything else exists only in the
 // diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1): verification, census and A/B shapes of the same arithmetic
 // and the exhaustive device-side checks of the lean square root / reciprocal.  The table at the end of this file is
 // the one place that says what each instance is and needs (rt_device.h Instance).
@@ -61,6 +61,14 @@
 #define RT_KERNEL_NAME rt_trace_parity_pairs_g
 #define RT_OPT_WALK 1
 #define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs_m          /* tables beyond LDS whose PAIRS still fit it: pairs staged, slots where they lie in HBM / L2 */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_m
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 2
 #define RT_OPT_MINWAVES 5
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
@@ -164,6 +172,7 @@ static const Instance kParityInstances[] = {
     { parity_coop_w1::rt_trace_parity_coop_w1, "rt_trace_parity_coop_w1", 1, kTabSweepLds, kRoleCoop, kInstStaticCoop },
     { parity_pairs::rt_trace_parity_pairs, "rt_trace_parity_pairs", 4, kTabPairsLds, kRolePairs, 0 },
     { parity_pairs_g::rt_trace_parity_pairs_g, "rt_trace_parity_pairs_g", 4, kTabPairsGlobal, kRolePairsGlobal, 0 },
+    { parity_pairs_m::rt_trace_parity_pairs_m, "rt_trace_parity_pairs_m", 4, kTabPairsLdsSlotsGlobal, kRolePairsMixed, 0 },
     { parity_g::rt_trace_parity_g, "rt_trace_parity_g", 4, kTabSweepGlobal, kRoleSweepGlobal, 0 },
 #if RT_DIAGNOSTICS
     { parity_pairs_census::rt_trace_parity_pairs_census, "rt_trace_parity_pairs_census", 4, kTabPairsLds, kRoleNone, 0 },

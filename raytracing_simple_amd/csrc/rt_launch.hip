@@ -108,6 +108,11 @@ bool tables_fit_lds(const rt_ctx *c, int n_samples) {
 
 // the hierarchy's tables fit the LDS budget given to them; otherwise the walk reads them from HBM / L2
 static bool bvh_fits_lds(const rt_ctx *c, int n_samples) { return pairs_lds(c, false, n_samples) <= (size_t)c->bvh_lds_limit; }
+// ... or at least its PAIRS do (header | pairs | stacks): the chain of dependent fetches a walk consists of then stays in LDS
+static size_t pairs_only_lds(const rt_ctx *c, int n_samples, int waves = 4) {
+    return rt::lds_bytes_pairs(0, 0, false, n_samples, c->bvh.n_leaves, 0, c->bvh.stack_depth, 64 * waves);
+}
+static bool bvh_pairs_fit_lds(const rt_ctx *c, int n_samples) { return c->bvh_mixed != 0 && pairs_only_lds(c, n_samples) <= (size_t)c->bvh_lds_limit; }
 
 // the scene has a hierarchy and the context may use it
 static bool bvh_usable(const rt_ctx *c) { return c->bvh_ok && c->wg_waves != 1 && c->persist == 0; }
@@ -116,7 +121,7 @@ static bool bvh_usable(const rt_ctx *c) { return c->bvh_ok && c->wg_waves != 1 &
 // dynamic LDS and hands out the hierarchy.  An instance whose tables the context lacks is refused (RT_ERR_STATE),
 // whatever route selected it -- the measured choice, a forced form, or a diagnostics mode.
 static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::LaunchParams &p, size_t *lds_out) {
-    const bool needs_bvh = inst.tables == rt::kTabPairsLds || inst.tables == rt::kTabPairsGlobal;
+    const bool needs_bvh = inst.tables == rt::kTabPairsLds || inst.tables == rt::kTabPairsGlobal || inst.tables == rt::kTabPairsLdsSlotsGlobal;
     p.bvh = rt::BvhTables{};
     if (needs_bvh) {
         if (!c->bvh_ok || !c->bvh.blob)
@@ -139,6 +144,10 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
         case rt::kTabPairsGlobal:
             p.mat_in_lds = 0;
             lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 64 * inst.waves);
+            break;
+        case rt::kTabPairsLdsSlotsGlobal:
+            p.mat_in_lds = 0;
+            lds = pairs_only_lds(c, n_samples, inst.waves);
             break;
         default:
             return fail(RT_ERR_STATE, "%s: unknown table kind %d", inst.name, inst.tables);
@@ -178,7 +187,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     int role = coop ? rt::kRoleCoop : rt::kRolePlain, waves = w1 ? 1 : 4;
     if (form != 2 && bvh_usable(c)) {
         // large scenes: the walk over the hierarchy, from LDS while its tables leave room for five workgroups per CU
-        role = bvh_fits_lds(c, n_samples) ? rt::kRolePairs : rt::kRolePairsGlobal;
+        role = bvh_fits_lds(c, n_samples) ? rt::kRolePairs : (bvh_pairs_fit_lds(c, n_samples) ? rt::kRolePairsMixed : rt::kRolePairsGlobal);
         waves = 4;
         if (c->regen_gate <= 0) p.regen_gate = c->walk_gate;
     } else if (!tables_fit_lds(c, n_samples)) {
@@ -248,7 +257,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     c->current_sample += n_samples;
     c->launches += 1;
     c->last_kernel = inst->name;
-    c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal) ? 1 : 2;
+    c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal || inst->tables == rt::kTabPairsLdsSlotsGlobal) ? 1 : 2;
     if (p.tile_cost && n_samples >= 4) {
         c->cost_valid = true;
         c->cost_tiles = n_tiles;

@@ -320,7 +320,17 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const uint32_t *s_index = reinterpret_cast<const uint32_t *>(P.bvh.blob + bvh_index_at(n_slots));
     float4 *s_hdr = lds;
     const uint32_t stack_f4 = (P.bvh.stack_depth * (uint32_t)kStackStride * 2u + 15u) / 16u;
-#if RT_OPT_GLOBAL_TABLES
+#if RT_OPT_GLOBAL_TABLES == 2
+    // the PAIRS staged (64 bytes per leaf: what a walk's chain of dependent fetches goes through), the slots -- 128 bytes per leaf, one
+    // contiguous read per leaf step -- where they lie in HBM / L2: scenes whose whole tables outgrow the LDS budget but whose pairs fit it
+    const uint32_t n_pairs = P.bvh.n_leaves - 1u;
+    float4 *s_pairs = s_hdr + 2;
+    const float4 *s_slots = P.bvh.blob + bvh_slots_at();
+    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_pairs + 4 * n_pairs);
+    const float4 *s_lightA = P.scene.lightA, *s_lightB = P.scene.lightB;
+    float4 *s_emis = s_pairs + 4 * n_pairs + stack_f4;        // (never read: the host keeps mat_in_lds off)
+    float4 *s_colr = s_emis;
+#elif RT_OPT_GLOBAL_TABLES
     const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
     const float4 *s_slots = P.bvh.blob + bvh_slots_at();
     uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_hdr + 2);
@@ -358,6 +368,12 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         s_cam[3] = make_float4(0.f, 0.f, P.inv_w, P.inv_h);
     }
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
+#if RT_OPT_GLOBAL_TABLES == 2
+    {
+        const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
+        for (uint32_t i = tid; i < 4u * n_pairs; i += kBlockThreads) s_pairs[i] = g_pairs[i];
+    }
+#endif
 #if !RT_OPT_GLOBAL_TABLES
     {
         const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);

@@ -49,7 +49,7 @@ def test_shipped_kernels_have_no_private_segment_and_fit_their_occupancy():
     from raytracing_simple_amd import _build
     meta = _build.kernel_metadata()
     trace = {k: v for k, v in meta.items() if k.startswith("rt_trace_")}
-    assert len(trace) == 14 and len(meta) >= 23, sorted(meta)
+    assert len(trace) == 16 and len(meta) >= 25, sorted(meta)
     for name, m in meta.items():
         assert m["private_segment_fixed_size"] == 0, (name, m)
         assert m["vgpr_spill_count"] == 0 and m["sgpr_spill_count"] == 0, (name, m)

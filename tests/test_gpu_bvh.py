@@ -433,11 +433,12 @@ def _many_spheres(n, seed=7):
     return sph, host.DEMO_ORIG, host.DEMO_TARGET
 
 
-@pytest.mark.parametrize("n", [5000, 9500, 30000])
+@pytest.mark.parametrize("n", [2000, 5000, 9500, 30000])
 def test_scenes_beyond_lds(n):
-    """More spheres than LDS can hold (the hierarchy's tables stop at ~2700 spheres, the sweep's at ~9700): the walk reads pairs and slots from HBM / L2
-    (rt_trace_parity_pairs_g); beyond 8192 spheres in the tree the tables are built on the host.  Frames, seeds and
-    counters are still the oracle's."""
+    """More spheres than the LDS budget holds (the hierarchy's whole tables stop at ~1100 spheres, the sweep's at ~9700): while the PAIRS
+    still fit (to ~3200 spheres) they are staged and only the slots read from HBM / L2 (rt_trace_parity_pairs_m, round 5); beyond, the
+    walk reads pairs and slots from HBM / L2 (rt_trace_parity_pairs_g); beyond 8192 spheres in the tree the tables are built on the
+    host.  Frames, seeds and counters are still the oracle's."""
     sph, orig, target = _many_spheres(n)
     w, h, spp = 48, 32, 2
     cam = host.compute_camera(orig, target, w, h)
@@ -446,8 +447,14 @@ def test_scenes_beyond_lds(n):
         ctx.set_scene(sph)
         ctx.set_camera(cam)
         got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
-        assert ctx.last_kernel == "rt_trace_parity_pairs_g"
+        assert ctx.last_kernel == ("rt_trace_parity_pairs_m" if n <= 3000 else "rt_trace_parity_pairs_g")
         _same(got, want)
+        if n <= 3000:                   # ... and the same scene with everything read from HBM / L2 (the budget set below the pairs)
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 56, 1024))
+            ctx.reset()
+            got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            assert ctx.last_kernel == "rt_trace_parity_pairs_g"
+            _same(got, want)
         b = bvh_check.read_bvh(ctx)
         assert bvh_check.check_structure(api.as_spheres(sph), b) == []
         # the plain sweep over the table in HBM / L2 (what a scene without a hierarchy gets)

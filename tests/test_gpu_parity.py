@@ -259,7 +259,7 @@ def test_every_kernel_instance_in_the_libraries_has_parity():
     n_par, n_fast = lib.rt_debug_variant_count(0), lib.rt_debug_variant_count(1)
     names = api.instance_names() + api.instance_names(fast=True)
     assert n_par >= 15 and n_fast >= 10 and len(set(names)) == n_par + n_fast
-    for shipped in ("", "_w1", "_coop", "_coop_w1", "_pairs", "_pairs_g", "_g"):
+    for shipped in ("", "_w1", "_coop", "_coop_w1", "_pairs", "_pairs_m", "_pairs_g", "_g"):
         assert "rt_trace_parity" + shipped in names and "rt_trace_fast" + shipped in names
     assert api.instance_mode("rt_trace_parity_pairs_census") >= 100
     for maker, w, h, spp in ((lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 96, 64, 6),

@@ -34,6 +34,7 @@ CONFIGS = {
     "box300": (lambda: scenes.mirror_box(300), 1920, 1080, 8),
     "box700": (lambda: scenes.mirror_box(700), 1920, 1080, 4),
     "r2048": (lambda: scenes.random_spheres(2048), 1920, 1080, 8),
+    "r3000": (lambda: scenes.random_spheres(3000), 1920, 1080, 8),
     "r8192": (lambda: scenes.random_spheres(8192), 1920, 1080, 4),
     "r262144": (lambda: scenes.random_spheres(262144), 1920, 1080, 4),
 }

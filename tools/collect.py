@@ -12,7 +12,7 @@ KERNEL = {("c2", "parity"): "rt_trace_parity_w1", ("c2", "fast"): "rt_trace_fast
           ("c3", "parity"): "rt_trace_parity_pairs", ("c5", "parity"): "rt_trace_parity_coop_w1"}
 LABEL = {"c2": "C2: Demo, 1920x1080, 64 spp", "c16": "north-star target: 16 spheres, 1920x1080, 64 spp", "c3": "C3: 1024 spheres, 1920x1080, 16 spp",
          "c5": "C5: 64-sphere mirror box, 1920x1080, 64 spp"}
-KERNEL.update({("box120", "parity"): "rt_trace_parity_coop", ("r2048", "parity"): "rt_trace_parity_pairs_g"})
+KERNEL.update({("box120", "parity"): "rt_trace_parity_coop", ("r2048", "parity"): "rt_trace_parity_pairs_m"})
 LABEL.update({"box120": "closed box of 120 mirror / glass spheres, 1920x1080, 8 spp", "r2048": "2048 random spheres, 1920x1080, 8 spp"})
 
 
