@@ -422,7 +422,10 @@ int multi_reset(rt_ctx *front, bool async) {
 // rt_stream() of a multi-device context: the stream the ASSEMBLED frame is complete on (n > 1: the root's gather stream, behind
 // the receives and the de-interleave of the last frame queued; n = 1: the one shard's render stream).  A consumer that reads
 // rt_device_pixels behind it sees whole frames, and the next frame's assembly is ordered behind that read in turn.
-void *multi_stream(rt_ctx *front) { return (void *)frame_stream(front->multi); }
+void *multi_stream(rt_ctx *front) {
+    rt_multi *m = front->multi;
+    return (void *)(m->n == 1 ? m->shard[0]->stream : m->gather_stream);     // (every shard renders on its own stream: never a caller's, never null)
+}
 
 #if RT_DIAGNOSTICS
 // rt_debug_set_rccl_library: forget the bound library (contexts created before keep the communicators of the old one: the
