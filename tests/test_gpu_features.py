@@ -292,6 +292,34 @@ def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
         _assert_same(_state(ctx, ctx.read_pixels()), O.render(sph, cam, w, h, 64))
 
 
+def test_the_order_of_a_priced_first_frame_is_sorted_once_more_from_the_whole_frame():
+    """The first frame's order comes from 4 passes' worth of costs; the frame itself leaves the costs of all its passes, and the second
+    frame sorts from those -- once: the third frame walks the second's order.  Frames are the oracle's throughout."""
+    lib = api.load_library(diag=True)
+    w, h, spp = 320, 200, 32
+    sph, orig, target = scenes.demo_plus(16)
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+
+    def order_of(ctx):
+        n, valid = C.c_uint32(), C.c_int()
+        order = np.zeros(8192, np.uint32)
+        api._check(lib.rt_debug_read_tile_order(ctx._h, order.ctypes.data_as(C.c_void_p), None, 8192, C.byref(n), C.byref(valid)), lib)
+        assert valid.value
+        return order[: n.value].copy()
+
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx.set_scene(sph); ctx.set_camera(cam)
+        orders = []
+        for k in range(4):
+            ctx.reset()
+            _assert_same(_state(ctx, ctx.render_pass(spp)), want)
+            orders.append(order_of(ctx))
+            assert ctx.stats()["launches"] == (2 if k == 0 else 1)
+        assert not np.array_equal(orders[0], orders[1])                        # sorted again: from the first frame's 28 remaining passes
+        assert np.array_equal(orders[1], orders[2]) and np.array_equal(orders[2], orders[3])
+
+
 def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_bit():
     """Long launches of one scene and camera walk the tiles in descending order of the cost the launch before measured.
     Scheduling only: pixels, colour plane, seeds and counters equal the oracle either way; a new scene drops the order until
