@@ -715,7 +715,7 @@ def main():
         try:
             time.sleep(2.0)
             res = subprocess.run([sys.executable, os.path.abspath(__file__), "--inproc-child", str(world), "--steps", str(max(5, args.steps // 2)),
-                                  "--warmup", "2", "--mode", args.mode], env=env, capture_output=True, text=True, timeout=240)
+                                  "--warmup", "2", "--mode", args.mode], env=env, capture_output=True, text=True, timeout=120)
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
             in_library = json.loads(lines[-1]) if res.returncode == 0 and lines else {"error": (res.stderr or res.stdout)[-400:]}
         except (subprocess.TimeoutExpired, ValueError, OSError) as e:
