@@ -99,6 +99,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 bvh_form = int(os.environ.get("RT_FUZZ_BVH", "0"))
 gen = {"2": family2, "3": family3, "4": family4}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
 bad = []
+kernels = {}
 for seed in range(first, first + count):
     sph, orig, target = gen(seed)
     w, h, spp = [(40, 24, 3), (33, 17, 2), (64, 32, 5), (25, 40, 4), (96, 64, 2), (17, 9, 9)][seed % 6]
@@ -110,10 +111,13 @@ for seed in range(first, first + count):
         if bvh_form:
             if os.environ.get("RT_FUZZ_TREE_SHAPE"):                     # 0: the device build's fixed shape (default: by surface area, on the host)
                 ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, int(os.environ["RT_FUZZ_TREE_SHAPE"])))
-            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+            # RT_FUZZ_LDS = a small LDS budget in bytes: trees whose whole tables exceed it but whose pairs fit run on the instance that
+            # stages the pairs and reads the slots from L2 (..._pairs_m), larger ones on ..._pairs_g -- `kernels` below says which ran
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, int(os.environ.get("RT_FUZZ_LDS", 152 * 1024))))
             ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))      # RT_FUZZ_BVH != 0: the hierarchy forced
         ctx.set_scene(sph); ctx.set_camera(cam)
         px = ctx.render_pass(spp); col = ctx.read_colors(); sd = ctx.read_seeds(); st = ctx.stats()
+        kernels[ctx.last_kernel] = kernels.get(ctx.last_kernel, 0) + 1
     o = want["stats"]
     same = (np.array_equal(px, want["pixels"]) and np.array_equal(col.view(np.uint32), want["colors"].view(np.uint32))
             and np.array_equal(sd, want["seeds"]) and
@@ -123,4 +127,4 @@ for seed in range(first, first + count):
         bad.append(seed)
         print("MISMATCH seed", seed, "n", len(sph), (w, h, spp), "pixel diffs", int((px != want["pixels"]).sum()),
               "nan in oracle colours", bool(np.isnan(want["colors"]).any()), flush=True)
-print("fuzz seeds", first, "..", first + count - 1, "mismatches:", bad)
+print("fuzz seeds", first, "..", first + count - 1, "mismatches:", bad, "kernels:", kernels)
