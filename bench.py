@@ -88,11 +88,13 @@ def walk_census(api, spheres, cam, w, h, spp):
 
 
 def scaling_bound(api, mode, spheres, cam, w, h, spp, frame_ms=None, device=0):
-    """DESIGN.md section 6's strong-scaling bound of ONE frame, as numbers: a pixel's samples consume one random stream in order
-    (.cl:143-169), so however many GPUs share the image a frame lasts at least as long as its slowest wavefront.  That time is
-    measured here -- every launch leaves the wall clock of each tile's slowest wavefront (the heavy-first order's input), read
-    through the diagnostics library after an untimed, unsharded frame on this GPU -- and the predicted ceiling of the speed-up at
-    N GPUs is frame / max(slowest wavefront, frame / N).  The first measured SCALE record is to be read against this."""
+    """The perfect-balance estimate of ONE frame on N GPUs, as numbers: a pixel's samples consume one random
+    stream in order (.cl:143-169), so however many GPUs share the image a frame lasts as long as its slowest wavefront.  That time
+    is read here from what every launch leaves -- the wall clock of each tile's slowest wavefront, from its workgroup's start (table
+    staging and barrier included), of an untimed, unsharded frame on THIS GPU AT FULL OCCUPANCY: the wavefront shared its SIMD
+    with five or six others of a VALU-bound kernel, so on a GPU that holds fewer tiles than wave slots (8 GPUs at 1080p) it is
+    shorter.  It is therefore NOT a floor and the ratio below NOT a ceiling: `predicted_from_shards` (tools/shard_prediction.py:
+    every shard of the N-way split rendered alone on this GPU) is the measured figure the first SCALE record is to be read against."""
     import ctypes as C
     import numpy as np
     with api.RtContext(w, h, device=device, diag=True) as c:
@@ -109,11 +111,12 @@ def scaling_bound(api, mode, spheres, cam, w, h, spp, frame_ms=None, device=0):
         c._check(c._lib.rt_debug_read_tile_order(c._h, None, cost.ctypes.data_as(C.c_void_p), cap, C.byref(n_tiles), C.byref(valid)))
         slowest_ms = float(cost[:n_tiles.value].max()) * 1e-5           # s_memrealtime ticks of 10 ns
     frame = frame_ms if frame_ms else one_gpu_ms
-    return {"slowest_wavefront_ms": round(slowest_ms, 4), "one_gpu_frame_ms": round(frame, 4),
-            "predicted_speedup_ceiling": {str(n): round(frame / max(slowest_ms, frame / n), 2) for n in (2, 4, 8)},
-            "predicted_ms_per_frame_floor": {str(n): round(max(slowest_ms, frame / n), 4) for n in (2, 4, 8)},
-            "note": "kernel time only: the gather of the packed rows (8.3 MB at 1080p over xGMI) and launch latency come on top; "
-                    "frames_in_flight is the figure that scales with N"}
+    return {"slowest_wavefront_under_full_occupancy_ms": round(slowest_ms, 4), "one_gpu_frame_ms": round(frame, 4),
+            "perfect_balance_speedup": {str(n): round(frame / max(slowest_ms, frame / n), 2) for n in (2, 4, 8)},
+            "perfect_balance_ms_per_frame": {str(n): round(max(slowest_ms, frame / n), 4) for n in (2, 4, 8)},
+            "note": "an estimate, neither floor nor ceiling: the slowest wavefront was timed while it shared its SIMD with 5-6 others (a GPU holding "
+                    "1/N of the tiles runs it faster), shards are taken as equally heavy, kernel time only (gather of the packed rows and launch "
+                    "latency come on top); `predicted_from_shards` holds every shard measured alone; frames_in_flight is the figure that scales with N"}
 
 
 def first_frame(api, mode, spheres, cam, w, h, spp, steady_ms):
@@ -368,9 +371,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--workload", choices=["c2", "c16", "c3", "c4", "c5", "box120", "r2048"], default="c2",
-                    help="c2 = the headline (default; what the driver measures); the other BASELINE configurations on request; box120 / r2048 = scenes "
-                         "that run on the two shipped instances no BASELINE configuration reaches (rt_trace_*_coop, rt_trace_*_pairs_g), for their profiles")
+    ap.add_argument("--workload", default="c2",
+                    help="c2 = the headline (default; what the driver measures); c16 / c3 / c4 / c5 = the other BASELINE configurations; box120 / r2048 / r8192 / "
+                         "r65536 / r262144 / q9600 = scenes that run on the shipped instances no BASELINE configuration reaches (rt_trace_*_coop, _pairs_m, _pairs_g, "
+                         "rt_trace_*_g), for their profiles; scn:<scene> = one of the reference's own scenes (demo, simple, cornell, cornell_large, caustic, "
+                         "caustic3, demo_scn, complex, cornell_test, complex_test: sphere array and camera from tests/golden/) at the reference's 800x600, 64 spp")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames kept in flight per rank in the throughput region (0 = 2 for N<=2, 3 for N<=4, 6 beyond)")
     ap.add_argument("--no-extras", action="store_true", help="headline regions only (profiling runs)")
@@ -421,8 +426,21 @@ def main():
         "c4": ("C4: Demo scene (6 spheres)", lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 3840, 2160, 256),
         "c5": ("C5: 64-sphere mirror box, depth 8", lambda: scenes.mirror_box(64), 1920, 1080, 64),
         "box120": ("closed box of 120 mirror / glass spheres (the 4-wavefront cooperative sweep)", lambda: scenes.mirror_box(120), 1920, 1080, 8),
-        "r2048": ("2048 random spheres (hierarchy tables beyond LDS: read from HBM / L2)", lambda: scenes.random_spheres(2048), 1920, 1080, 8),
+        "r2048": ("2048 random spheres (hierarchy pairs in LDS, slots read from HBM / L2)", lambda: scenes.random_spheres(2048), 1920, 1080, 8),
+        "r8192": ("8192 random spheres (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(8192), 1920, 1080, 4),
+        "r65536": ("65536 random spheres (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(65536), 1920, 1080, 4),
+        "r262144": ("262144 random spheres = RT_MAX_SPHERES (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(262144), 1920, 1080, 4),
+        "q9600": ("9600 spheres in a closed box, hierarchy switched off by the host's choice of a tiny tree: the plain sweep over a table in HBM / L2", lambda: scenes.mirror_box(9600), 640, 360, 1),
     }
+    if args.workload.startswith("scn:"):
+        from tools import reference_scenes
+        scn = args.workload[4:]
+        if scn not in reference_scenes.FIXTURES:
+            raise SystemExit(f"--workload {args.workload}: scenes are {sorted(reference_scenes.FIXTURES)}")
+        workloads[args.workload] = (f"the reference's {reference_scenes.SOURCE.get(scn, 'Scene/' + scn + '.scn')} as its loader hands it to the kernel, the reference's native window",
+                                    lambda: reference_scenes.load_scene(scn), reference_scenes.W, reference_scenes.H, reference_scenes.SPP)
+    if args.workload not in workloads:
+        raise SystemExit(f"--workload {args.workload}: one of {sorted(workloads)} or scn:<scene>")
     wl_name, wl_maker, W, H, SPP = workloads[args.workload]
     spheres, cam_orig, cam_target = wl_maker()
     cam = host.compute_camera(cam_orig, cam_target, W, H)
@@ -432,116 +450,127 @@ def main():
     # queues, which streams from torch's pool did not always do)
     F = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world <= 2 else (3 if world <= 4 else 6))
 
-    def make_contexts(sph, camera, count):
-        out = []
-        for _ in range(count):
-            c = api.RtContext(W, H, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
-            c.set_scene(sph)
-            c.set_camera(camera)
-            c.set_mode(mode)
-            out.append(c)
-        return out
+    class FrameLoop:
+        """The frame loop of one workload on this rank: `n_ctx` sharded contexts (one stream each), at N > 1 the gather buffers, the
+        unsharded frame every gathered frame is compared with (rank 0) and the timed regions over them."""
 
-    ctxs = make_contexts(spheres, cam, F)
-    ctx = ctxs[0]
-    # scenes large enough for a hierarchy: the library measures hierarchy against sweep on a new scene's first launches
-    # (four of them; a blocking call of 16 passes or more holds them all) -- one untimed blocking frame per context settles
-    # that before any timed region, whatever --warmup says
-    for c in ctxs:
-        c.reset_async()
-        c.render_pass(max(SPP, 16), copy=False)
-    side_streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+        def __init__(self, sph, camera, w, h, spp, n_ctx):
+            self.w, self.h, self.spp, self.n_ctx = w, h, spp, n_ctx
+            self.ctxs = []
+            for _ in range(n_ctx):
+                c = api.RtContext(w, h, device=local_rank, rank=rank, nranks=world, tile_rows=TILE_ROWS)
+                c.set_scene(sph)
+                c.set_camera(camera)
+                c.set_mode(mode)
+                self.ctxs.append(c)
+            # scenes large enough for a hierarchy: the library measures hierarchy against sweep on a new scene's first launches
+            # (four of them; a blocking call of 16 passes or more holds them all) -- one untimed blocking frame per context settles
+            # that before any timed region, whatever --warmup says
+            for c in self.ctxs:
+                c.reset_async()
+                c.render_pass(max(spp, 16), copy=False)
+            self.streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in self.ctxs]
+            self.gather, self.want_dev, self.mismatch, self.whole_kernel_ms = None, None, None, None
+            self.frame_no, self.frames_checked = 0, 0
+            if world > 1:
+                self.gather = rdist.FrameGatherer(h, w, rank, world, TILE_ROWS, dev, slots=2 * n_ctx)
+                self.gather.pending_check = [False] * self.gather.slots
+                if rank == 0:
+                    # the frame every gathered frame must equal: an unsharded render on this GPU
+                    with api.RtContext(w, h, device=local_rank) as whole:
+                        whole.set_scene(sph); whole.set_camera(camera); whole.set_mode(mode)
+                        whole.render_pass(spp, copy=False)
+                        whole.reset()
+                        self.want_dev = torch.from_numpy(whole.render_pass(spp).view(np.int32).reshape(h, w).copy()).to(dev)
+                        self.whole_kernel_ms = whole.stats()["last_kernel_ms"]     # the unsharded frame on this GPU (its second rendering: tiles heavy first)
+                    self.mismatch = torch.zeros((), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()        # the set-up ran on torch's stream; the contexts' streams are non-blocking
+                self.gather.gather(0)           # plumbing, not a step: RCCL builds its communicator and point-to-point
+                torch.cuda.synchronize()        # channels on first use (seconds); keep that out of every timed region
+                dist.barrier()
 
-    gather, want_dev, mismatch = None, None, None
-    if world > 1:
-        gather = rdist.FrameGatherer(H, W, rank, world, TILE_ROWS, dev, slots=2 * F)
-        if rank == 0:
-            # the frame every gathered frame must equal: an unsharded render on this GPU
-            with api.RtContext(W, H, device=local_rank) as whole:
-                whole.set_scene(spheres); whole.set_camera(cam); whole.set_mode(mode)
-                want_dev = torch.from_numpy(whole.render_pass(SPP).view(np.int32).reshape(H, W).copy()).to(dev)
-            mismatch = torch.zeros((), dtype=torch.int64, device=dev)
-        torch.cuda.synchronize()        # the set-up ran on torch's stream; the contexts' streams are non-blocking
-        gather.gather(0)                # plumbing, not a step: RCCL builds its communicator and point-to-point
-        torch.cuda.synchronize()        # channels on first use (seconds); keep that out of every timed region
-        dist.barrier()
-    frame_no = [0]
-    frames_checked = [0]
+        def collect(self, k):
+            """Frame k's gather is complete and assembled (rank 0): compare it with the unsharded frame ON THE DEVICE,
+            then poison the buffers so that a frame that is NOT written again would show."""
+            g = self.gather
+            full = g.wait(k)
+            if rank == 0 and full is not None and g.pending_check[k % g.slots]:
+                self.mismatch.add_((full != self.want_dev).sum())
+                full.fill_(-1)
+                g.pending_check[k % g.slots] = False
+                self.frames_checked += 1
 
-    def collect(k):
-        """Frame k's gather is complete and assembled (rank 0): compare it with the unsharded frame ON THE DEVICE,
-        then poison the buffers so that a frame that is NOT written again would show."""
-        full = gather.wait(k)
-        if rank == 0 and full is not None and gather.pending_check[k % gather.slots]:
-            mismatch.add_((full != want_dev).sum())
-            full.fill_(-1)
-            gather.pending_check[k % gather.slots] = False
-            frames_checked[0] += 1
+        def step(self, in_flight, ev=None):
+            k = self.frame_no
+            self.frame_no += 1
+            c, st = self.ctxs[k % in_flight], self.streams[k % in_flight]
+            with torch.cuda.stream(st):
+                if self.gather is not None:
+                    self.collect(k)                                 # slot free again (the frame that used it 2F frames ago)
+                    buf = self.gather.local_slot(k)
+                    buf.fill_(-1)                                   # poison: every pixel must come from THIS frame's launch
+                    c.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
+                c.reset_async(st.cuda_stream)
+                if ev:
+                    ev[0].record(st)
+                c.render_async(self.spp, st.cuda_stream)
+                if ev:
+                    ev[1].record(st)
+                if self.gather is not None:
+                    self.gather.gather(k, async_op=True)            # queued behind the launch, not waited for
+                    self.gather.pending_check[k % self.gather.slots] = True
+                    if in_flight == 1:
+                        self.collect(k)                             # one frame at a time: complete before the next one starts
+                        st.synchronize()
+            return c
 
-    def step(contexts, streams, in_flight, ev=None):
-        k = frame_no[0]
-        frame_no[0] += 1
-        c, st = contexts[k % in_flight], streams[k % in_flight]
-        with torch.cuda.stream(st):
-            if gather is not None:
-                collect(k)                                      # slot free again (the frame that used it 2F frames ago)
-                buf = gather.local_slot(k)
-                buf.fill_(-1)                                   # poison: every pixel must come from THIS frame's launch
-                c.set_pixel_buffer(buf.data_ptr(), buf.numel())   # render straight into the send buffer
-            c.reset_async(st.cuda_stream)
-            if ev:
-                ev[0].record(st)
-            c.render_async(SPP, st.cuda_stream)
-            if ev:
-                ev[1].record(st)
-            if gather is not None:
-                gather.gather(k, async_op=True)                 # queued behind the launch, not waited for
-                gather.pending_check[k % gather.slots] = True
-                if in_flight == 1:
-                    collect(k)                                  # one frame at a time: complete before the next one starts
-                    st.synchronize()
-        return c
+        def drain(self):
+            if self.gather is not None:
+                for k in range(self.frame_no - 2 * self.n_ctx, self.frame_no):
+                    if k >= 0:
+                        with torch.cuda.stream(self.streams[0]):
+                            self.collect(k)
 
-    def drain():
-        if gather is not None:
-            for k in range(frame_no[0] - 2 * F, frame_no[0]):
-                if k >= 0:
-                    with torch.cuda.stream(side_streams[0]):
-                        collect(k)
+        @staticmethod
+        def sync():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def timed_region(self, in_flight, steps, warmup, with_events=True):
+            """W untimed + exactly `steps` timed frames; barrier + synchronize on both sides.
+            Per-launch HIP events only where asked: an event pair around every launch costs the
+            overlapped region its overlap (measured), and a per-launch duration means little there."""
+            for _ in range(warmup):
+                self.step(in_flight)
+            self.drain()
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                      for _ in range(steps)] if with_events else None
+            self.sync()
+            t0 = time.perf_counter()
+            last = None
+            for k in range(steps):
+                last = self.step(in_flight, events[k] if events else None)
+            self.drain()                                            # every frame gathered, assembled and checked
+            self.sync()
+            elapsed = time.perf_counter() - t0
+            kernel_ms = (sum(a.elapsed_time(b) for a, b in events) / max(steps, 1)) if events else None
+            return elapsed, kernel_ms, last
 
-    def timed_region(contexts, streams, in_flight, steps, warmup, with_events=True):
-        """W untimed + exactly `steps` timed frames; barrier + synchronize on both sides.
-        Per-launch HIP events only where asked: an event pair around every launch costs the
-        overlapped region its overlap (measured), and a per-launch duration means little there."""
-        for _ in range(warmup):
-            step(contexts, streams, in_flight)
-        drain()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for _ in range(steps)] if with_events else None
-        sync()
-        t0 = time.perf_counter()
-        last = None
-        for k in range(steps):
-            last = step(contexts, streams, in_flight, events[k] if events else None)
-        drain()                                             # every frame gathered, assembled and checked
-        sync()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = (sum(a.elapsed_time(b) for a, b in events) / max(steps, 1)) if events else None
-        return elapsed, kernel_ms, last
+        def frame_counters(self, c=None):
+            """Exact ray / test counts of one frame of this rank (the same for every frame): from one more,
+            synchronous render after a synchronous reset, outside every timed region."""
+            c = c or self.ctxs[0]
+            c.set_pixel_buffer(0, 0)
+            c.reset()
+            c.render_pass(self.spp, copy=False)
+            return c.stats()
 
-    def frame_counters(c):
-        """Exact ray / test counts of one frame of this rank (the same for every frame): from one more,
-        synchronous render after a synchronous reset, outside every timed region."""
-        c.set_pixel_buffer(0, 0)
-        c.reset()
-        c.render_pass(SPP, copy=False)
-        return c.stats()
+        def close(self):
+            for c in self.ctxs:
+                c.close()
+            self.ctxs = []
 
     def all_ranks(values, op):
         t = torch.tensor(values, dtype=torch.float64, device=dev)
@@ -549,16 +578,27 @@ def main():
             dist.all_reduce(t, op=op)
         return [float(v) for v in t.tolist()]
 
+    loop = FrameLoop(spheres, cam, W, H, SPP, F)
+    ctxs, side_streams, ctx = loop.ctxs, loop.streams, loop.ctxs[0]
+
+    def timed_region(contexts, streams, in_flight, steps, warmup, with_events=True):
+        """(the extras below time other scenes through loops of their own: a FrameLoop around contexts that exist already)"""
+        lp = FrameLoop.__new__(FrameLoop)
+        lp.w, lp.h, lp.spp, lp.n_ctx, lp.ctxs, lp.streams = W, H, SPP, len(contexts), contexts, streams
+        lp.gather, lp.want_dev, lp.mismatch, lp.frame_no, lp.frames_checked = None, None, None, 0, 0
+        return lp.timed_region(in_flight, steps, warmup, with_events)
+
+    def frame_counters(c):
+        return loop.frame_counters(c)
+
     # ---- the headline: one frame at a time -------------------------------------------------------------
-    if gather is not None:
-        gather.pending_check = [False] * gather.slots
-    el1, kernel_ms, last1 = timed_region(ctxs, side_streams, 1, args.steps, args.warmup, with_events=True)
+    el1, kernel_ms, last1 = loop.timed_region(1, args.steps, args.warmup, with_events=True)
     last_pixels = last1.read_pixels() if world == 1 else None       # the last TIMED frame (checked against the oracle below)
     # ---- the same K frames with F in flight (throughput) ------------------------------------------------
     elF = None
     if F > 1 and not args.no_extras:
-        elF, _, _ = timed_region(ctxs, side_streams, F, args.steps, args.warmup, with_events=False)
-    st = frame_counters(ctx)
+        elF, _, _ = loop.timed_region(F, args.steps, args.warmup, with_events=False)
+    st = loop.frame_counters(ctx)
     kernel_name = ctx.last_kernel           # the instance the library renders this scene with (rt_last_kernel)
     choice = ctx.scene_choice()             # large scenes: what the library's own measurement of hierarchy against sweep said
 
@@ -568,8 +608,8 @@ def main():
     elF_max = all_ranks([elF], dist.ReduceOp.MAX if world > 1 else None)[0] if elF is not None else None
     frames_ok = None
     if world > 1:
-        bad = int(mismatch.item()) if rank == 0 else 0
-        frames_ok = {"frames_checked": frames_checked[0], "wrong_pixels": bad} if rank == 0 else None
+        bad = int(loop.mismatch.item()) if rank == 0 else 0
+        frames_ok = {"frames_checked": loop.frames_checked, "wrong_pixels": bad} if rank == 0 else None
 
     # ---- extras, N = 1, outside the headline's timed regions -------------------------------------------
     other, target, in_library, large, unseen, first = None, None, None, None, None, None
@@ -618,13 +658,13 @@ def main():
         if args.workload == "c2":
             sph16, o16, t16 = scenes.demo_plus(16)
             cam16 = host.compute_camera(o16, t16, W, H)
-            c16 = make_contexts(sph16, cam16, F)
-            s16 = [torch.cuda.ExternalStream(c.stream, device=dev) for c in c16]
+            loop16 = FrameLoop(sph16, cam16, W, H, SPP, F)
+            c16 = loop16.ctxs
             k16 = max(5, args.steps // 2)
-            el16, kms16, last16 = timed_region(c16, s16, 1, k16, 2, with_events=True)
+            el16, kms16, last16 = loop16.timed_region(1, k16, 2, with_events=True)
             px16 = last16.read_pixels()
-            el16F, _, _ = timed_region(c16, s16, F, k16, 2, with_events=False)
-            st16 = frame_counters(c16[0])
+            el16F, _, _ = loop16.timed_region(F, k16, 2, with_events=False)
+            st16 = loop16.frame_counters()
             rays16 = st16["samples"] + st16["shadow_rays"]
             target = {"workload": "north-star target: Demo + 10 spheres (16), 1920x1080, 64 spp, default seed stream",
                       "asked_Mray_s": 10000.0, "steps": k16, "ms_per_step": round(el16 / k16 * 1e3, 4),
@@ -638,8 +678,7 @@ def main():
                 base16, cpu16 = cpu_baseline(sph16, cam16, W, H, SPP, reference_too=False)
                 target["matches_cpu_oracle_bit_exact"] = bool(np.array_equal(px16, cpu16["pixels"]))
                 target["cpu_port_ms_per_frame"] = base16["ms_per_frame"]
-            for c in c16:
-                c.close()
+            loop16.close()
         # a large scene (BASELINE configs[2]: 1024 random spheres, 1080p x 16 spp), blocking calls: the library builds a
         # hierarchy for it, times it against the sweep on the first two frames and renders the rest with the faster form
         if args.workload == "c2":
@@ -699,11 +738,37 @@ def main():
             in_library = {"error": str(e)}
 
     my_local_rows = ctx.local_rows
+    loop.close()
+    # ---- N > 1: BASELINE configs[3] beside the headline -- C4 (Demo, 3840x2160, 256 spp), the configuration BASELINE built for the
+    # 1/2/4/8 curve: a 1080p x 64 frame is short against its slowest wavefront, this one is not.  One frame at a time, every
+    # gathered frame compared with the unsharded one on rank 0's GPU, exactly as the headline's ----
+    c4_block = None
+    if world > 1 and not args.no_extras and args.workload == "c2":
+        W4, H4, SPP4 = 3840, 2160, 256
+        sph4 = host.demo_scene()
+        cam4 = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, W4, H4)
+        loop4 = FrameLoop(sph4, cam4, W4, H4, SPP4, 1)
+        k4 = max(3, min(args.steps, 6))
+        el4, kms4, _ = loop4.timed_region(1, k4, 1, with_events=True)
+        st4 = loop4.frame_counters()
+        samples4, shadow4 = (int(v) for v in all_ranks([st4["samples"], st4["shadow_rays"]], dist.ReduceOp.SUM))
+        el4_max, kms4_max = all_ranks([el4, kms4], dist.ReduceOp.MAX)
+        kms4_min = -all_ranks([-kms4], dist.ReduceOp.MAX)[0]
+        if rank == 0:
+            bad4 = int(loop4.mismatch.item())
+            rays4 = samples4 + shadow4
+            c4_block = {"workload": f"C4: Demo scene (6 spheres), {W4}x{H4}, {SPP4} spp, default seed stream (BASELINE configs[3])",
+                        "steps": k4, "warmup": 1, "ms_per_step": round(el4_max / k4 * 1e3, 4), "value": round(rays4 * k4 / el4_max / 1e6, 1), "unit": "Mray/s",
+                        "kernel": loop4.ctxs[0].last_kernel, "kernel_ms_max_rank": round(kms4_max, 4), "kernel_ms_min_rank": round(kms4_min, 4),
+                        "shard_imbalance_max_over_min": round(kms4_max / max(kms4_min, 1e-9), 4),
+                        "unsharded_kernel_ms_on_rank0_gpu": round(loop4.whole_kernel_ms, 4),
+                        "speedup_vs_unsharded_kernel": round(loop4.whole_kernel_ms / (el4_max / k4 * 1e3), 3),
+                        "every_gathered_frame_equals_unsharded": bad4 == 0, "gathered_frames_checked": loop4.frames_checked, "wrong_pixels": bad4,
+                        "regime": "one frame at a time: gathered and assembled on rank 0 before the next starts", "rays_per_frame": rays4}
+        loop4.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
     if rank != 0:
         return 0
 
@@ -727,6 +792,20 @@ def main():
             bound = scaling_bound(api, mode, spheres, cam, W, H, SPP, kernel_ms if world == 1 else None, device=local_rank)
         except Exception as e:       # noqa: BLE001 -- a diagnostics figure never takes the headline down
             bound = {"error": repr(e)[:300]}
+    # every shard of a 2 / 4 / 8-way split rendered ALONE on this GPU (tools/shard_prediction.py): what each GPU of an N-GPU run
+    # would spend on the frame, imbalance and under-filled GPU included -- for this line's workload and for C4
+    shards = None
+    if world == 1 and not args.no_extras:
+        try:
+            from tools import shard_prediction
+            shards = {args.workload: shard_prediction.predict(api, mode, spheres, cam, W, H, SPP, whole_ms=kernel_ms, whole_pixels=last_pixels, bound=bound)}
+            if args.workload == "c2":
+                cam4 = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 3840, 2160)
+                shards["c4"] = shard_prediction.predict(api, mode, host.demo_scene(), cam4, 3840, 2160, 256, frames=2)
+            shards["what"] = ("per N: each shard of the interleaved 8-row-tile split rendered alone on this GPU, steady state (kernel ms from the context's events); "
+                              "predicted_ms_per_frame = slowest shard + measured de-interleave kernel + all packed pixels over one 153 GB/s xGMI link")
+        except Exception as e:       # noqa: BLE001 -- a diagnostics figure never takes the headline down
+            shards = {"error": repr(e)[:300]}
     rays = samples + shadow                      # primary + shadow, the metric's ray count
     ms_per_step = el1_max / args.steps * 1e3
     value = rays * args.steps / el1_max / 1e6
@@ -759,7 +838,8 @@ def main():
                    "every_gathered_frame_equals_unsharded": None if frames_ok is None else frames_ok["wrong_pixels"] == 0,
                    "gathered_frames_checked": None if frames_ok is None else frames_ok["frames_checked"],
                    "sharding": f"interleaved {TILE_ROWS}-row tiles x {world}",
-                   "strong_scaling_bound": bound,
+                   "perfect_balance_estimate": bound,
+                   "predicted_from_shards": shards,
                    "rays_per_frame": rays, "all_rays_per_frame": closest + shadow,
                    "Mray_s_all_rays": round((closest + shadow) * args.steps / el1_max / 1e6, 1),
                    "Msample_s": round(samples * args.steps / el1_max / 1e6, 1)},
@@ -779,6 +859,8 @@ def main():
         line["large_scene"] = large
     if other is not None:
         line["other_mode"] = other
+    if c4_block is not None:
+        line["c4"] = c4_block
     if in_library is not None:
         line["in_library_multi_gpu"] = in_library
     if world == 1 and not args.no_cpu:

@@ -131,14 +131,18 @@ RT_API int rt_create(rt_ctx **out, int w, int h);
  * to a one-device context by construction (pixels are independent); with ngpus = 1 there is nothing to move: no
  * communicator (RCCL is not loaded), no gather, no de-interleave -- the one shard renders straight into the frame.  One kernel instance renders the whole frame: the first shard measures hierarchy
  * against sweep (rt_scene_choice) and the others follow it.
- * STATUS of the n > 1 RCCL branch: exercised so far only as far as one GPU allows -- the rehearsal below, in which device-to-device copies stand in for ncclSend / ncclRecv.  The grouped send / receive
- * across distinct devices has not run on hardware yet (tests/test_gpu_features.py holds the test, skipped below two
- * devices); treat it as unverified until that test has passed on a multi-GPU node.
+ * STATUS of the n > 1 RCCL branch: it executes on one GPU against a test double of RCCL (tests/rccl_double.cpp, bound through the diagnostics
+ * library's rt_debug_set_rccl_library: communicator, the grouped n - 1 receives and n - 1 sends, de-interleave -- on 2, 3 and 8 shards, C4 at
+ * full size on 8 -- and every failure site: ncclGroupStart, ncclSend / ncclRecv inside the group, ncclGroupEnd); against librccl on distinct
+ * devices over xGMI it has run on no hardware yet (tests/test_gpu_features.py holds that test, skipped below two devices): treat real links as
+ * unverified until it has passed on a multi-GPU node.
  * rt_create_multi_on with ONE device listed ngpus times is that one-GPU rehearsal of the path: RCCL refuses two
  * ranks on one device, so the transfers into the root's receive slots are device-to-device copies there; everything
  * else (shards, slots, de-interleave) is unchanged.  A list that mixes repeated and distinct devices is refused
  * (RT_ERR_ARG).  If a gather fails half-way (an RCCL error inside the group or at ncclGroupEnd) the context is marked
- * unusable: every later call on it returns RT_ERR_STATE naming the failure, and only rt_destroy is meaningful.    */
+ * unusable: every later call on it returns RT_ERR_STATE naming the failure, and only rt_destroy is meaningful -- it polls the
+ * context's streams (never a blocking wait) for up to two seconds and frees everything once they have drained; only a context whose streams
+ * still hold a transfer after that keeps its device memory and streams (a teardown that returns instead of hanging).    */
 RT_API int rt_create_multi(rt_ctx **out, int w, int h, int ngpus);
 RT_API int rt_create_multi_on(rt_ctx **out, int w, int h, const int *devices, int ngpus, int tile_rows);
 RT_API int rt_shard_count(const rt_ctx *ctx);                     /* 1 for a plain context        */

@@ -59,7 +59,7 @@ RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
  * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, stack depth, root pair } (slots = always + 8 * leaves), all 0 without a hierarchy */
 RT_API int rt_debug_set_bvh(rt_ctx *ctx, int min_spheres, int lds_limit);
 RT_API int rt_debug_set_tree_shape(rt_ctx *ctx, int by_area);        /* the hierarchy's shape: 1 (default) by surface area -- uploads below 1500 tree spheres on the host, larger ones and every device-resident update on the device; 2: on the device for every upload too; 0: the fixed (halved) shape everywhere */
-RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* steps: ignored since round 4 (it was the per-trip step budget; a walk now runs to its end within the trip); gate: ready lanes that make a wavefront shade (0 = keep); forced 0 = hierarchy or plain sweep by estimate / measurement (default), 1 = the hierarchy whenever the scene has one */
+RT_API int rt_debug_set_walk(rt_ctx *ctx, int steps, int gate, int forced);   /* steps: TAIL LANES since round 5, 0..63 -- a trip's walk phase ends once no more than `steps` lanes still walk, their walks go on in the next trip (0, the default: every walk runs to its end within the trip; an experiment's knob); gate: ready lanes that make a wavefront shade (0 = keep); forced 0 = hierarchy or plain sweep by estimate / measurement (default), 1 = the hierarchy whenever the scene has one */
 RT_API int rt_debug_set_walk_round(rt_ctx *ctx, int steps);   /* pair steps a lane takes in a row before the leaf step of the lanes that hold a leaf (default 3; large = until every lane has one) */
 /* n_rays rays { o.xyz, t_max, d.xyz, shadow != 0 } (8 floats each; the last as a bit pattern) through the hierarchy walk
  * AND the plain sweep, one lane per ray; out4 (4 words per ray) = the walk's answer, then the sweep's -- closest hit:

@@ -147,7 +147,7 @@ def kernel_metadata(lib=None):
     """What the gfx950 code objects inside a built library say about every kernel: registers, LDS, and the private
     segment (scratch) -- {symbol: {vgpr_count, sgpr_count, private_segment_fixed_size, vgpr_spill_count, ...}}.
     Read with the image's llvm-objdump / llvm-readelf in a scratch directory (tests/test_abi.py holds DESIGN.md's
-    "no scratch, <= 96 registers" to it; tools/profile_gpu.sh prints it beside every profile)."""
+    "no scratch, <= 96 registers" to it)."""
     import re
     import tempfile
     lib = lib or OUT
@@ -162,7 +162,7 @@ def kernel_metadata(lib=None):
                 continue
             notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(tmp, name)], check=True,
                                    capture_output=True, text=True).stdout
-            for block in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+            for block in re.split(r"\n(?=\s+- \.agpr_count:)", notes)[1:]:      # (one block per kernel; the look-ahead keeps the entry's first key)
                 fields = dict(re.findall(r"\.([a-z_]+):\s+(\S+)", block))
                 out[fields["name"]] = {k: int(v) for k, v in fields.items() if re.fullmatch(r"\d+", v)}
     return out

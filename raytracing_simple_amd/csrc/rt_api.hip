@@ -256,9 +256,10 @@ RT_API void rt_destroy(rt_ctx *c) {
         return;
     }
     if (c->abandon_streams) {
-        // a shard of a multi-device context whose gather failed (rt_multi.hip mark_broken): its stream may hold a transfer that
-        // never completes, and hipFree / hipHostFree / hipStreamDestroy synchronise with the device's work -- so nothing on the
-        // device is waited for or freed; the shard's device memory and stream are leaked, the call returns
+        // a shard of a multi-device context whose gather failed AND whose streams had not drained two seconds later (rt_multi.hip
+        // multi_destroy polls them): a stream may hold a transfer that never completes, and hipFree / hipHostFree / hipStreamDestroy
+        // synchronise with the device's work -- so nothing on the device is waited for or freed; the shard's device memory and stream
+        // are leaked, the call returns
         delete c;
         return;
     }

@@ -266,10 +266,10 @@ static int dbg_set_walk_forced(rt_ctx *c, int v) { c->walk_forced = v ? 1 : 0; r
 // rt_walk.inc.h: pair steps per lane per loop trip, ready lanes that make a wavefront shade (0 = keep either), and
 // forced: 0 = hierarchy or plain sweep by measurement (the library's behaviour), 1 = the hierarchy whenever the scene has one
 RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int forced) {
-    if (!c || steps < 0 || gate < 0 || gate > 64 || forced < 0 || forced > 1) return fail(RT_ERR_ARG, "steps %d, gate %d, forced %d", steps, gate, forced);
-    // `steps`: rounds 2-3, the per-trip step budget; round 5: the walk phase of a trip ends once no more than `steps` lanes still walk (0 = every walk
-    // runs to its end within the trip) -- it rides in the high bits of walk_round
-    if (steps < 0 || steps > 63) return fail(RT_ERR_ARG, "tail lanes %d", steps);
+    // `steps` = TAIL LANES since round 5 (rounds 2-3: the per-trip step budget): the walk phase of a trip ends once no more than `steps` lanes
+    // still walk (0 = every walk runs to its end within the trip) -- it rides in the high bits of walk_round
+    if (!c || steps < 0 || steps > 63 || gate < 0 || gate > 64 || forced < 0 || forced > 1)
+        return fail(RT_ERR_ARG, "tail lanes %d (0..63), gate %d (0..64), forced %d (0 / 1)", steps, gate, forced);
     int rc = dbg_apply(c, dbg_set_walk_tail, steps);
     if (rc != RT_OK) return rc;
     rc = dbg_apply(c, dbg_set_walk_gate, gate);

@@ -10,6 +10,9 @@
 #define RT_NS fast
 #define RT_KERNEL_NAME rt_trace_fast
 #define RT_PACK_KERNEL_NAME rt_pack_fast
+#if !RT_DIAGNOSTICS
+#define RT_NO_RENDER_KERNEL 1        /* as in rt_kernel_parity.hip: the 4-wavefront plain sweep is an A/B shape */
+#endif
 #include "rt_trace.inc.h"
 #if RT_DIAGNOSTICS
 #define RT_SCHED_KERNEL_NAME rt_sched_fast
@@ -117,7 +120,9 @@
 namespace rt {
 
 static const Instance kFastInstances[] = {
+#if RT_DIAGNOSTICS
     { fast::rt_trace_fast, "rt_trace_fast", 4, kTabSweepLds, kRolePlain, 0 },
+#endif
     { fast_w1::rt_trace_fast_w1, "rt_trace_fast_w1", 1, kTabSweepLds, kRolePlain, 0 },
     { fast_coop::rt_trace_fast_coop, "rt_trace_fast_coop", 4, kTabSweepLds, kRoleCoop, kInstStaticCoop },
     { fast_coop_w1::rt_trace_fast_coop_w1, "rt_trace_fast_coop_w1", 1, kTabSweepLds, kRoleCoop, kInstStaticCoop },

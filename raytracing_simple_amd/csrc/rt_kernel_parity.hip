@@ -1,8 +1,11 @@
 // rt_kernel_parity.hip -- strict-arithmetic instances of the path-trace kernel.
 // MUST be compiled with -ffp-contract=off (see _build.py); the pragma below is a second lock.
-// Shipped (librt_hip.so): rt_trace_parity / _w1 (small scenes, 4- / single-wavefront workgroups), rt_trace_parity_coop /
-// _coop_w1 (12 spheres and more: cooperative any-hit), rt_trace_parity_pairs (many small spheres: the hierarchy,
-// rt_walk.inc.h), rt_trace_parity_pairs_m / _pairs_g / rt_trace_parity_g (tables beyond LDS).  Everything else exists only in the
+// Shipped (librt_hip.so): rt_trace_parity_w1 (fewer than 12 spheres: single-wavefront workgroups), rt_trace_parity_coop_w1 / _coop
+// (12 spheres and more: cooperative any-hit, single- / 4-wavefront workgroups), rt_trace_parity_pairs (many small spheres: the
+// hierarchy, rt_walk.inc.h), rt_trace_parity_pairs_m / _pairs_g (its tables beyond LDS), rt_trace_parity_g (the plain sweep over a table
+// beyond LDS: more than about 9 700 records of which fewer than 56 are finite spheres -- the fallback that keeps every input
+// renderable).  The 4-wavefront PLAIN sweep (rt_trace_parity) is not shipped since round 6: a scene of fewer than 12 spheres never
+// outgrows the single-wavefront workgroup's LDS budget, so nothing selected it (rt_launch.hip).  Everything else exists only in the
 // diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1): verification, census and A/B shapes of the same arithmetic
 // and the exhaustive device-side checks of the lean square root / reciprocal.  The table at the end of this file is
 // the one place that says what each instance is and needs (rt_device.h Instance).
@@ -16,6 +19,9 @@
 #define RT_KERNEL_NAME rt_trace_parity
 #define RT_PACK_KERNEL_NAME rt_pack_parity
 #define RT_OPT_MINWAVES 6            /* <= 80 VGPRs: 6 wavefronts per SIMD */
+#if !RT_DIAGNOSTICS
+#define RT_NO_RENDER_KERNEL 1        /* product: helpers and the pack kernel only (no scene selects the 4-wavefront plain sweep) */
+#endif
 #include "rt_trace.inc.h"
 #if RT_DIAGNOSTICS
 #undef RT_OPT_MINWAVES
@@ -166,7 +172,9 @@ namespace rt {
 
 // what each instance is and needs: { kernel, symbol, wavefronts per workgroup, tables, role, flags }
 static const Instance kParityInstances[] = {
-    { parity::rt_trace_parity, "rt_trace_parity", 4, kTabSweepLds, kRolePlain, 0 },
+#if RT_DIAGNOSTICS
+    { parity::rt_trace_parity, "rt_trace_parity", 4, kTabSweepLds, kRolePlain, 0 },      // A/B only (rt_debug_set_wg_waves(ctx, 4) on a scene below 12 spheres)
+#endif
     { parity_w1::rt_trace_parity_w1, "rt_trace_parity_w1", 1, kTabSweepLds, kRolePlain, 0 },
     { parity_coop::rt_trace_parity_coop, "rt_trace_parity_coop", 4, kTabSweepLds, kRoleCoop, kInstStaticCoop },
     { parity_coop_w1::rt_trace_parity_coop_w1, "rt_trace_parity_coop_w1", 1, kTabSweepLds, kRoleCoop, kInstStaticCoop },

@@ -209,6 +209,9 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     }
 #endif
     if (!inst) inst = find_role(fast, role, waves);
+    // (the product library ships no 4-wavefront PLAIN sweep: below 12 spheres the tables always fit the single-wavefront budget above; should a
+    // launch get here all the same, the cooperative instance of that shape renders any scene -- same bits, it only shares its shadow sweeps)
+    if (!inst && role == rt::kRolePlain) inst = find_role(fast, rt::kRoleCoop, waves);
     if (!inst) return fail(RT_ERR_STATE, "this library holds no %s instance of role %d with %d wavefronts per workgroup", fast ? "fast" : "parity", role, waves);
     size_t lds_use = 0;
     rc = bind_tables(c, *inst, n_samples, p, &lds_use);

@@ -21,6 +21,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "rt_internal.h"
@@ -345,16 +347,48 @@ RT_API int rt_create_multi(rt_ctx **out, int w, int h, int ngpus) {
 
 namespace rt {
 
+// Has everything queued on `s` (a stream of `device`) completed?  Asked without blocking, for at most `budget_ms` in all.
+static bool stream_drains(int device, hipStream_t s, double *budget_ms) {
+    if (!s) return true;
+    if (hipSetDevice(device) != hipSuccess) return false;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return true;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (*budget_ms <= 0.0) return false;
+        std::this_thread::sleep_for(std::chrono::microseconds(500));
+        *budget_ms -= 0.5;
+    }
+}
+
 void multi_destroy(rt_ctx *front) {
     rt_multi *m = front->multi;
     if (!m) return;
+    // A broken context (mark_broken) MAY hold a transfer that never completes on the gather stream or on a shard's -- hipFree,
+    // hipHostFree and hipStreamDestroy synchronise with such work and would hang with it.  Whether it does is asked, not assumed:
+    // its streams are polled (hipStreamQuery, never a blocking wait) for up to two seconds.  When they have all drained -- the
+    // failure came before anything was posted, or ncclCommAbort tore the transfers down -- teardown is the ordinary one and
+    // nothing is lost; only a context whose streams are still busy after that keeps (leaks) its device memory, page-locked
+    // staging, events and streams, and the caller's output buffer stays registered: its teardown returns, it does not tidy up.
+    bool stuck = false;
+    if (m->broken) {
+        double budget_ms = 2000.0;
+        for (size_t r = 0; r < m->shard.size() && !stuck; ++r) {
+            rt_ctx *s = m->shard[r];
+            stuck = !stream_drains(s->device, s->stream, &budget_ms) ||
+                    (s->last_stream && s->last_stream != s->stream && !stream_drains(s->device, s->last_stream, &budget_ms));
+        }
+        if (!stuck && m->gather_stream && !m->devices.empty()) stuck = !stream_drains(m->devices[0], m->gather_stream, &budget_ms);
+        if (!stuck)
+            for (rt_ctx *s : m->shard) s->abandon_streams = false;      // (rt_destroy of a shard then frees as ever)
+    }
     if (m->gather_stream && !m->broken && !m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess)
         (void)hipStreamSynchronize(m->gather_stream);   // (it reads the shards' buffers: before they go)
-    for (rt_ctx *s : m->shard) rt_destroy(s);           // waits for each shard's stream (a broken context's shards: neither wait nor free, rt_api.hip)
-    // A broken context (mark_broken) may hold a transfer that never completes on the gather stream or on a shard's: hipFree and
-    // hipStreamDestroy synchronise with such work and would hang with it, so the root's buffers, events and stream are LEAKED
-    // there -- teardown of a failed multi-device context returns, it does not tidy up.
-    if (!m->broken && !m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess) {
+    for (rt_ctx *s : m->shard) rt_destroy(s);           // waits for each shard's stream (a stuck context's shards: neither wait nor free, rt_api.hip)
+    if (!stuck && !m->devices.empty() && hipSetDevice(m->devices[0]) == hipSuccess) {
         if (m->pinned_out) (void)hipHostUnregister(m->pinned_out);
         (void)hipFree(m->d_gathered[0]);
         (void)hipFree(m->d_gathered[1]);
@@ -367,7 +401,7 @@ void multi_destroy(rt_ctx *front) {
         if (m->gather_stream) (void)hipStreamDestroy(m->gather_stream);
     }
     // (mark_broken has aborted and cleared the communicators where the library has ncclCommAbort; where it has not, a
-    // communicator that sits in a failed group is not handed to ncclCommDestroy, which may wait for that group: leaked too)
+    // communicator that sits in a failed group is not handed to ncclCommDestroy, which may wait for that group: leaked)
     for (rcclComm c : m->comm)
         if (c && !m->broken) (void)g_rccl.CommDestroy(c);
     delete m;

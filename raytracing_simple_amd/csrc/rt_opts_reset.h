@@ -16,3 +16,5 @@
 #undef RT_OPT_EXACT_DECISIONS
 #undef RT_OPT_PAIR_PLANES
 #undef RT_OPT_RAYS2
+
+#undef RT_NO_RENDER_KERNEL

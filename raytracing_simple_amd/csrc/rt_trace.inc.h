@@ -512,7 +512,7 @@ RT_DEV uint32_t wave_sum(uint32_t v) {
 
 #if RT_OPT_WALK
 #include "rt_walk.inc.h"       // large scenes: the walk of the hierarchy as lane state (its own kernel body)
-#else
+#elif !defined(RT_NO_RENDER_KERNEL)     // (the first instantiation of a product library carries the helpers and the pack kernel only)
 extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAVES) RT_KERNEL_NAME(const LaunchParams P) {
     constexpr int kBlockThreads = 64 * RT_OPT_WG_WAVES;      // (shadow the 4-wavefront constants of rt_device.h)
     constexpr int kTileW = 8 * RT_OPT_WG_WAVES;

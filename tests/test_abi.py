@@ -41,6 +41,10 @@ def test_library_exports_exactly_the_declared_symbols():
     assert not any(n.startswith("rt_debug") for n in _exports(api.lib_path()))
 
 
+SHIPPED_PARITY = ["rt_trace_parity" + k for k in ("_w1", "_coop", "_coop_w1", "_pairs", "_pairs_m", "_pairs_g", "_g")]
+SHIPPED_FAST = [k.replace("parity", "fast") for k in SHIPPED_PARITY]
+
+
 def test_shipped_kernels_have_no_private_segment_and_fit_their_occupancy():
     """no kernel of the product library uses scratch (no register spills, no private arrays), the
     sweep instances fit 80 vector registers (6 wavefronts per SIMD), the instances that walk the hierarchy 96 (5 per SIMD).
@@ -49,11 +53,12 @@ def test_shipped_kernels_have_no_private_segment_and_fit_their_occupancy():
     from raytracing_simple_amd import _build
     meta = _build.kernel_metadata()
     trace = {k: v for k, v in meta.items() if k.startswith("rt_trace_")}
-    assert len(trace) == 16 and len(meta) >= 25, sorted(meta)
+    assert sorted(trace) == sorted(SHIPPED_PARITY + SHIPPED_FAST), sorted(trace)        # the instances that ship, by name (rt_kernel_parity.hip / rt_kernel_fast.hip)
+    assert len(meta) >= 23, sorted(meta)
     for name, m in meta.items():
         assert m["private_segment_fixed_size"] == 0, (name, m)
         assert m["vgpr_spill_count"] == 0 and m["sgpr_spill_count"] == 0, (name, m)
-        assert m.get("agpr_count", 0) == 0, (name, m)
+        assert "agpr_count" in m and m["agpr_count"] == 0, (name, m)
     for name, m in trace.items():
         assert m["vgpr_count"] <= (96 if "_pairs" in name else 80), (name, m["vgpr_count"])
 
@@ -273,5 +278,5 @@ def test_profile_counters_are_bound_to_the_code_they_describe(tmp_path, monkeypa
     stale = bench.roofline_block("rt_trace_parity_w1", 2.6, 1788296212, 1920 * 1080, 6, "c2", "parity")
     assert stale["traffic"] is None and "executed" not in stale and lib_id in stale["counters_withheld"]
     monkeypatch.setattr(bench, "library_build_id", lambda: lib_id)                       # same library, another kernel instance
-    other = bench.roofline_block("rt_trace_parity", 2.6, 1788296212, 1920 * 1080, 6, "c2", "parity")
+    other = bench.roofline_block("rt_trace_parity_coop_w1", 2.6, 1788296212, 1920 * 1080, 6, "c2", "parity")
     assert other["traffic"] is None and "executed" not in other

@@ -36,6 +36,7 @@ CONFIGS = {
     "r2048": (lambda: scenes.random_spheres(2048), 1920, 1080, 8),
     "r3000": (lambda: scenes.random_spheres(3000), 1920, 1080, 8),
     "r8192": (lambda: scenes.random_spheres(8192), 1920, 1080, 4),
+    "r65536": (lambda: scenes.random_spheres(65536), 1920, 1080, 4),
     "r262144": (lambda: scenes.random_spheres(262144), 1920, 1080, 4),
 }
 
