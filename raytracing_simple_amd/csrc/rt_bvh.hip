@@ -10,6 +10,10 @@
 
 #include "rt_internal.h"
 
+#ifndef RT_DIAGNOSTICS
+#define RT_DIAGNOSTICS 0
+#endif
+
 namespace {
 
 // The hierarchy of rt_device.h BvhTables from the raw records, ONE workgroup of 1024 threads:
@@ -28,6 +32,15 @@ __host__ __device__ inline bool bvh_outside(float rad, float px, float py, float
     const bool finite = (fabsf(rad) <= big) && (fabsf(px) <= big) && (fabsf(py) <= big) && (fabsf(pz) <= big);   // false for NaN
     return !(finite && fabsf(rad) <= r_cut);
 }
+// Half the width of a sphere's box.  The walk grows every box by a per-ray pad min(sqrt(eps), eps / 2 r_min) (rt_walk.inc.h), r_min the
+// smallest radius in the tree -- so ONE zero-radius record (the .scn loader's doubling puts N of them at the origin, Utility.cpp:120,154)
+// would turn that into sqrt(eps) for every box of the tree and every ray: complex.scn's walk took 18 % more pair steps and 46 % more leaf
+// visits for its 783 phantoms (profiles/r06_reference_scenes.jsonl).  Instead the header's r_min is the smallest REGULAR radius R
+// (|rad| >= r_floor = 1/16 of the median radius) and the boxes of the smaller spheres are grown by g = R / 2 at build time: for a sphere of
+// radius r_s < R the point X of the derivation lies within r_s + min(sqrt(eps), eps / 2 r_s) <= r_s + sqrt(eps) of its centre, and
+// g + min(s, s^2 / 2R) >= s for every s = sqrt(eps) >= 0 (the difference s - s^2 / 2R peaks at s = R with R / 2; beyond s = 2R the pad is s itself).
+// A tree without a regular sphere keeps the true minimum and g = 0, as before.
+__host__ __device__ inline float bvh_half_width(float ar, float r_floor, float g) { return ar >= r_floor ? ar : ar + g; }
 __device__ inline unsigned bvh_ordered(float f) {          // unsigned order = float order
     const unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -50,25 +63,27 @@ __device__ inline uint32_t bvh_node_of(uint32_t leaf, uint32_t level, uint32_t n
     return (rank << (level - s2)) | ((b - a == 1) ? 0x80000000u : 0u);
 }
 
-__global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, uint32_t n, float r_cut, uint32_t n_always,
+__global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, uint32_t n, float r_cut, float r_floor, uint32_t n_always,
                                                             uint32_t n_tree, uint32_t n_pad, float4 *blob) {
     extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, later 2 float4 per leaf
-    __shared__ unsigned s_rmin, s_rmax;
+    __shared__ unsigned s_rmin, s_rmax, s_rmin_all;         // (s_rmin: over the regular radii, >= r_floor; s_rmin_all: over all of the tree's)
     __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad;
     const unsigned tid = threadIdx.x, wave = tid >> 6;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
     const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
     float4 *hdr = blob, *slots = blob + rt::bvh_slots_at();
     uint32_t *index = reinterpret_cast<uint32_t *>(blob + rt::bvh_index_at(n_slots));
-    if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; }
+    if (tid == 0) { s_rmin = 0xffffffffu; s_rmin_all = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; }
     for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
     __syncthreads();
     // ---- 1. radius range of the tree's spheres ----
     for (uint32_t i = tid; i < n; i += 1024) {
         const float *r = reinterpret_cast<const float *>(sph + i);
         if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
-            atomicMin(&s_rmin, __float_as_uint(fabsf(r[0])));
-            atomicMax(&s_rmax, __float_as_uint(fabsf(r[0])));
+            const float ar = fabsf(r[0]);
+            atomicMin(&s_rmin_all, __float_as_uint(ar));
+            if (ar >= r_floor) atomicMin(&s_rmin, __float_as_uint(ar));
+            atomicMax(&s_rmax, __float_as_uint(ar));
         }
     }
     // ---- 2. the always list in scene order, the tree's spheres in scene order for a start (ballot prefix per 1024 records) ----
@@ -190,6 +205,8 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
     __threadfence_block();                                  // the index written above is read back below by other threads
     __syncthreads();                                        // the keys are dead: the same LDS now holds the leaf boxes
     float4 *s_leaf = reinterpret_cast<float4 *>(s_keys);
+    const bool have_regular = s_rmin != 0xffffffffu;
+    const float r_min = __uint_as_float(have_regular ? s_rmin : s_rmin_all), grow = have_regular ? 0.5f * r_min : 0.f;       // (bvh_half_width)
     for (uint32_t leaf = tid; leaf < n_leaves; leaf += 1024) {
         float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
         uint32_t low = 0xffffffffu;
@@ -197,7 +214,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
             const uint32_t ix = index[n_always + rt::kBvhLeaf * leaf + k];
             if (ix == 0xffffffffu) continue;
             const float *r = reinterpret_cast<const float *>(sph + ix);
-            const float ar = fabsf(r[0]);
+            const float ar = bvh_half_width(fabsf(r[0]), r_floor, grow);
             for (int a = 0; a < 3; ++a) {
                 lo[a] = fminf(lo[a], bvh_down(r[1 + a] - ar));
                 hi[a] = fmaxf(hi[a], bvh_up(r[1 + a] + ar));
@@ -220,7 +237,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
             const float cx = 0.5f * lo[0] + 0.5f * hi[0], cy = 0.5f * lo[1] + 0.5f * hi[1], cz = 0.5f * lo[2] + 0.5f * hi[2];
             const float ex = hi[0] - cx, ey = hi[1] - cy, ez = hi[2] - cz;
             hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
-            const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
+            const float rmin = r_min, rmax = __uint_as_float(s_rmax);
             hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float((n_leaves > 1 ? n_leaves / 2u - 1u : rt::kBvhLeafRef) | bvh_complaints(s_bad)));
         } else {
             hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -280,10 +297,10 @@ __device__ inline unsigned bvh_longest(const float *b) {
     if (ez > e) axis = 2;
     return axis;
 }
-__global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere *sph, uint32_t n, float r_cut, uint32_t n_always, uint32_t n_tree,
+__global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere *sph, uint32_t n, float r_cut, float r_floor, uint32_t n_always, uint32_t n_tree,
                                                                 uint32_t n_pad, uint32_t depth_cap, float4 *blob) {
     extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, then the per-leaf arrays below
-    __shared__ unsigned s_rmin, s_rmax, s_rb[6];
+    __shared__ unsigned s_rmin, s_rmin_all, s_rmax, s_rb[6];
     __shared__ uint32_t s_wave_a[16], s_wave_t[16], s_base_a, s_base_t, s_bad, s_any, s_root, s_levels;
     const unsigned tid = threadIdx.x, wave = tid >> 6;
     const uint32_t L = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
@@ -297,7 +314,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
     uint16_t *s_na = reinterpret_cast<uint16_t *>(s_best + L), *s_nb = s_na + L;             // per leaf: the range of leaves of the node it is in
     uint16_t *s_refl = s_nb + L, *s_refr = s_refl + L;                                       // per cut: the references of the pair's two children
     uint8_t *s_side = reinterpret_cast<uint8_t *>(s_refr + L), *s_axis = s_side + L;         // per leaf: its node is the left (0) / right (1) child, or the root (2); per node: the axis
-    if (tid == 0) { s_rmin = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; s_root = rt::kBvhLeafRef; s_levels = 0; }
+    if (tid == 0) { s_rmin = 0xffffffffu; s_rmin_all = 0xffffffffu; s_rmax = 0u; s_base_a = 0; s_base_t = 0; s_bad = 0; s_root = rt::kBvhLeafRef; s_levels = 0; }
     if (tid < 3) { s_rb[tid] = 0xffffffffu; s_rb[3 + tid] = 0u; }
     for (uint32_t i = tid; i < n_pad; i += 1024) s_keys[i] = ~0ull;
     for (uint32_t l = tid; l < L; l += 1024) { s_na[l] = 0; s_nb[l] = (uint16_t)L; s_side[l] = 2; s_axis[l] = 0; s_refl[l] = s_refr[l] = 0xffffu; }
@@ -307,11 +324,13 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
         const float *r = reinterpret_cast<const float *>(sph + i);
         if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
             const float ar = fabsf(r[0]);
-            atomicMin(&s_rmin, __float_as_uint(ar));
+            atomicMin(&s_rmin_all, __float_as_uint(ar));
+            if (ar >= r_floor) atomicMin(&s_rmin, __float_as_uint(ar));
             atomicMax(&s_rmax, __float_as_uint(ar));
+            const float hw = bvh_half_width(ar, r_floor, 8.f * r_floor);        // (the growth of a small sphere's box is R / 2 <= median / 2 = 8 r_floor: R is not known yet)
             for (int a3 = 0; a3 < 3; ++a3) {
-                atomicMin(&s_rb[a3], bvh_ordered(bvh_down(r[1 + a3] - ar)));
-                atomicMax(&s_rb[3 + a3], bvh_ordered(bvh_up(r[1 + a3] + ar)));
+                atomicMin(&s_rb[a3], bvh_ordered(bvh_down(r[1 + a3] - hw)));
+                atomicMax(&s_rb[3 + a3], bvh_ordered(bvh_up(r[1 + a3] + hw)));
             }
         }
     }
@@ -398,7 +417,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
                 if (j >= n_tree) break;
                 const uint32_t ix = (uint32_t)(s_keys[j] & kIdxMask);
                 const float *r = reinterpret_cast<const float *>(sph + ix);
-                const float ar = fabsf(r[0]);
+                const float ar = bvh_half_width(fabsf(r[0]), r_floor, s_rmin != 0xffffffffu ? 0.5f * __uint_as_float(s_rmin) : 0.f);
                 for (int a3 = 0; a3 < 3; ++a3) {
                     lo[a3] = fminf(lo[a3], bvh_down(r[1 + a3] - ar));
                     hi[a3] = fmaxf(hi[a3], bvh_up(r[1 + a3] + ar));
@@ -514,13 +533,94 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
             const float cx = 0.5f * rb[0] + 0.5f * rb[3], cy = 0.5f * rb[1] + 0.5f * rb[4], cz = 0.5f * rb[2] + 0.5f * rb[5];
             const float ex = rb[3] - cx, ey = rb[4] - cy, ez = rb[5] - cz;
             hdr[0] = make_float4(cx, cy, cz, sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f);
-            const float rmin = __uint_as_float(s_rmin), rmax = __uint_as_float(s_rmax);
+            const float rmin = __uint_as_float(s_rmin != 0xffffffffu ? s_rmin : s_rmin_all), rmax = __uint_as_float(s_rmax);
             hdr[1] = make_float4(rmin, rmax, 1.f / (2.f * rmin), __uint_as_float(last));
         } else {
             hdr[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             hdr[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(last));
         }
     }
+}
+
+// The TOP of the tree to the front of the pair table (BvhTables::n_top), for the walk that reads its tables from HBM / L2 and stages only
+// this much of them in LDS (rt_walk.inc.h RT_OPT_TOP_PAIRS).  Every builder numbers the pairs by their leaves (pair of a node = first leaf
+// of its right child - 1), which is what lets the host lay the blob out before the tree exists; that order scatters the top levels over
+// the whole table.  This pass renumbers AFTER any builder, host or device, on the stream behind it: the first `n_top` pairs in
+// breadth-first order from the root take the places [0, n_top) (the root's pair becomes pair 0), every other pair keeps its place in the
+// builders' order behind them, the child references and the header's root are rewritten -- a permutation of the table, so every offset
+// into the blob, the leaf numbers and the stack depth are what they were.  n_top = min(top_max, pairs): a breadth-first walk from the root
+// reaches every pair, so the host knows the count without reading anything back.  ONE workgroup; `scratch`: 4 float4 per pair, then one
+// u16 per pair (the old -> new map).
+__global__ void __launch_bounds__(1024) rt_bvh_promote_kernel(float4 *blob, uint32_t n_slots, uint32_t n_leaves, uint32_t top_max, float4 *scratch) {
+    __shared__ uint16_t s_bfs[256], s_sorted[256], s_rank_bfs[256], s_refs[2 * 256];
+    __shared__ uint32_t s_count;
+    const unsigned tid = threadIdx.x;
+    const uint32_t n_pairs = n_leaves ? n_leaves - 1u : 0u;
+    float4 *hdr = blob, *pairs = blob + rt::bvh_pairs_at(n_slots);
+    uint16_t *map = reinterpret_cast<uint16_t *>(scratch + 4 * (size_t)n_pairs);
+    const uint32_t last = __float_as_uint(hdr[1].w), root = last & 0xffffu;
+    if (n_pairs == 0u || (root & rt::kBvhLeafRef) || top_max == 0u) return;
+    if (top_max > 256u) top_max = 256u;
+    // ---- breadth-first from the root, level by level: the level's references read by its threads, appended in order by one ----
+    if (tid == 0) { s_bfs[0] = (uint16_t)root; s_count = 1u; }
+    __syncthreads();
+    uint32_t lo = 0u;
+    for (;;) {
+        const uint32_t hi = s_count;
+        if (lo >= hi || hi >= top_max) break;
+        if (lo + tid < hi) {
+            const uint32_t p = s_bfs[lo + tid];
+            s_refs[2 * tid] = (uint16_t)(__float_as_uint(pairs[4 * (size_t)p].w) & 0xffffu);
+            s_refs[2 * tid + 1] = (uint16_t)(__float_as_uint(pairs[4 * (size_t)p + 2].w) & 0xffffu);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cnt = hi;
+            for (uint32_t k = 0; k < 2u * (hi - lo) && cnt < top_max; ++k) {
+                const uint32_t r = s_refs[k];
+                if (!(r & rt::kBvhLeafRef)) s_bfs[cnt++] = (uint16_t)r;
+            }
+            s_count = cnt;
+        }
+        lo = hi;
+        __syncthreads();
+    }
+    const uint32_t T = s_count;
+    // ---- the promoted pairs sorted by their old number (rank by counting: they are distinct), and each one's breadth-first place ----
+    if (tid < T) {
+        const uint32_t mine = s_bfs[tid];
+        uint32_t rank = 0u;
+        for (uint32_t j = 0; j < T; ++j) rank += s_bfs[j] < mine ? 1u : 0u;
+        s_sorted[rank] = (uint16_t)mine;
+        s_rank_bfs[rank] = (uint16_t)tid;
+    }
+    __syncthreads();
+    // ---- old -> new for every pair: a promoted pair goes to its breadth-first place, any other moves up by the promoted pairs behind it ----
+    for (uint32_t p = tid; p < n_pairs; p += 1024) {
+        uint32_t a = 0u, b = T;                 // first index whose entry is >= p
+        while (a < b) {
+            const uint32_t m = (a + b) / 2u;
+            if (s_sorted[m] < p) a = m + 1u;
+            else b = m;
+        }
+        const bool top = a < T && s_sorted[a] == p;
+        map[p] = (uint16_t)(top ? s_rank_bfs[a] : T + p - a);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- the permuted table into the scratch copy (references rewritten), and back ----
+    for (uint32_t p = tid; p < n_pairs; p += 1024) {
+        float4 r0 = pairs[4 * (size_t)p], r1 = pairs[4 * (size_t)p + 1], r2 = pairs[4 * (size_t)p + 2], r3 = pairs[4 * (size_t)p + 3];
+        const uint32_t c0 = __float_as_uint(r0.w) & 0xffffu, c1 = __float_as_uint(r2.w) & 0xffffu;
+        r0.w = __uint_as_float((c0 & rt::kBvhLeafRef) ? c0 : (uint32_t)map[c0]);
+        r2.w = __uint_as_float((c1 & rt::kBvhLeafRef) ? c1 : (uint32_t)map[c1]);
+        float4 *q = scratch + 4 * (size_t)map[p];
+        q[0] = r0; q[1] = r1; q[2] = r2; q[3] = r3;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (size_t i = tid; i < 4 * (size_t)n_pairs; i += 1024) pairs[i] = scratch[i];
+    if (tid == 0) hdr[1].w = __uint_as_float((last & 0xffff0000u) | (uint32_t)map[root]);
 }
 
 // Trees beyond what one workgroup sorts in LDS (more than 8192 spheres in the tree): the same tables from the host
@@ -565,7 +665,7 @@ inline double host_box_area(const HostBox &b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, uint32_t n_tree, hipStream_t stream) {
+int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, float r_floor, uint32_t n_always, uint32_t n_tree, hipStream_t stream) {
     const std::vector<rt_sphere> &sph = c->h_spheres;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
     const uint32_t n_slots = n_always + rt::kBvhLeaf * n_leaves;
@@ -587,7 +687,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
     // split; radius range
     std::vector<uint32_t> order;
     order.reserve(n_tree);
-    float rmin = 3.4e38f, rmax = 0.f;
+    float rmin = 3.4e38f, rmin_all = 3.4e38f, rmax = 0.f;
     uint32_t na = 0;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = sph[i];
@@ -597,10 +697,14 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
             na += 1;
         } else {
             order.push_back(i);
-            rmin = fminf(rmin, fabsf(s.rad));
+            rmin_all = fminf(rmin_all, fabsf(s.rad));
+            if (fabsf(s.rad) >= r_floor) rmin = fminf(rmin, fabsf(s.rad));
             rmax = fmaxf(rmax, fabsf(s.rad));
         }
     }
+    const bool have_regular = rmin < 3.4e38f;          // (bvh_half_width: the header's r_min is the smallest regular radius, smaller spheres' boxes grow by half of it)
+    if (!have_regular) rmin = rmin_all;
+    const float grow = have_regular ? 0.5f * rmin : 0.f;
     if (na != n_always || order.size() != n_tree) return rt::fail(RT_ERR_STATE, "hierarchy: the split changed under the build");
     // order: top-down, every node's spheres partitioned at the median along the longest axis of the box of their centres
     // (the left child takes the first half of the node's leaves; ties go by scene index), as the device build does
@@ -649,7 +753,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, u
             const rt_sphere &s = sph[ix];
             slots[n_always + j] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
             index[n_always + j] = ix;
-            const float p[3] = { s.p.x, s.p.y, s.p.z }, ar = fabsf(s.rad);
+            const float p[3] = { s.p.x, s.p.y, s.p.z }, ar = bvh_half_width(fabsf(s.rad), r_floor, grow);
             for (int a = 0; a < 3; ++a) {
                 b.lo[a] = fminf(b.lo[a], host_down(p[a] - ar));
                 b.hi[a] = fmaxf(b.hi[a], host_up(p[a] + ar));
@@ -718,28 +822,32 @@ struct SahOut {
     uint32_t ref;
     uint32_t depth;
 };
-int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, uint32_t n_always, uint32_t n_tree, hipStream_t stream, uint32_t *n_leaves_out,
+int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, float r_floor, uint32_t n_always, uint32_t n_tree, hipStream_t stream, uint32_t *n_leaves_out,
                       uint32_t *depth_out, bool *built) {
     *built = false;
     const std::vector<rt_sphere> &sph = c->h_spheres;
     std::vector<uint32_t> order, always;
     order.reserve(n_tree);
-    float rmin = 3.4e38f, rmax = 0.f;
+    float rmin = 3.4e38f, rmin_all = 3.4e38f, rmax = 0.f;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = sph[i];
         if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) {
             always.push_back(i);
         } else {
             order.push_back(i);
-            rmin = fminf(rmin, fabsf(s.rad));
+            rmin_all = fminf(rmin_all, fabsf(s.rad));
+            if (fabsf(s.rad) >= r_floor) rmin = fminf(rmin, fabsf(s.rad));
             rmax = fmaxf(rmax, fabsf(s.rad));
         }
     }
+    const bool have_regular = rmin < 3.4e38f;          // (bvh_half_width)
+    if (!have_regular) rmin = rmin_all;
+    const float grow_small = have_regular ? 0.5f * rmin : 0.f;
     if (always.size() != n_always || order.size() != n_tree) return rt::fail(RT_ERR_STATE, "hierarchy: the split changed under the build");
     auto coord = [&](uint32_t ix, int axis) { const rt_sphere &s = sph[ix]; return axis == 0 ? s.p.x : (axis == 1 ? s.p.y : s.p.z); };
     auto grow = [&](HostBox &b, uint32_t ix) {
         const rt_sphere &s = sph[ix];
-        const float p[3] = { s.p.x, s.p.y, s.p.z }, ar = fabsf(s.rad);
+        const float p[3] = { s.p.x, s.p.y, s.p.z }, ar = bvh_half_width(fabsf(s.rad), r_floor, grow_small);
         for (int a = 0; a < 3; ++a) {
             b.lo[a] = fminf(b.lo[a], host_down(p[a] - ar));
             b.hi[a] = fmaxf(b.hi[a], host_up(p[a] + ar));
@@ -904,7 +1012,36 @@ hipError_t prepare_bvh_build() {
 // The hierarchy of a large scene (rt_bvh_build_kernel), on `stream` behind the records.  Which spheres stay outside
 // the tree is decided here, from the host mirror, with the test the device applies to the same bits: 16 times the
 // median |radius| is the cut (ground, walls, big lights), non-finite records stay outside as well.
+// After any builder: the top of the tree to the front of the pair table, where the walk will read its tables from HBM / L2 -- i.e. where not even
+// the pairs fit the LDS budget the context gives the hierarchy (rt_launch.hip makes the same comparison per launch).  Costs one small launch per
+// build (20-60 us); trees that are walked from LDS keep the builders' numbering.
+static int promote_top(rt_ctx *c, hipStream_t stream) {
+    c->bvh.n_top = 0;
+    if (!c->bvh_ok || c->bvh.n_leaves < 2 || c->bvh_top_pairs <= 0) return RT_OK;
+    const uint32_t n_pairs = c->bvh.n_leaves - 1u;
+    const size_t pairs_lds = rt::lds_bytes_pairs(0, 0, false, 64, c->bvh.n_leaves, 0, c->bvh.stack_depth, 256);
+    if (c->bvh_mixed != 0 && pairs_lds <= (size_t)c->bvh_lds_limit) return RT_OK;       // (rt_trace_*_pairs / _pairs_m will walk it: everything it chases is in LDS)
+    const size_t used = rt::bvh_blob_float4s(c->bvh.n_leaves, c->bvh.n_slots);
+    const size_t scratch4 = 4 * (size_t)n_pairs + ((size_t)n_pairs * 2 + 15) / 16 + 1;
+    if (used + scratch4 > (size_t)c->scene_cap * 6 + 64) return RT_OK;                   // (no room behind the blob: the tree stays as it is, nothing is staged)
+    uint32_t top = std::min<uint32_t>((uint32_t)c->bvh_top_pairs, rt::kBvhTopPairs);
+#if RT_DIAGNOSTICS
+    if (const char *e = getenv("RT_TOP_PAIRS")) top = std::min<uint32_t>((uint32_t)atoi(e), 256u);       // (experiments: how much of the top is worth staging)
+    if (top == 0u) return RT_OK;
+#endif
+    hipLaunchKernelGGL(rt_bvh_promote_kernel, dim3(1), dim3(1024), 0, stream, c->d_bvh, c->bvh.n_slots, c->bvh.n_leaves, top, c->d_bvh + used);
+    HIP_TRY(hipGetLastError());
+    c->bvh.n_top = std::min(top, n_pairs);
+    return RT_OK;
+}
+
+static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload);
 int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
+    const int rc = build_bvh_tables(c, n_total, stream, full_upload);
+    return rc != RT_OK ? rc : promote_top(c, stream);
+}
+
+static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
     c->bvh_ok = false;
     c->bvh = rt::BvhTables{};
     c->bvh_n_tree = 0;
@@ -914,11 +1051,12 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     radii.reserve(n_total);
     for (uint32_t i = 0; i < n_total; ++i) {
         const float r = fabsf(c->h_spheres[i].rad);
-        if (r <= 3.0e38f) radii.push_back(r);
+        if (r <= 3.0e38f && r > 0.f) radii.push_back(r);       // (zero-radius records -- the loader's phantoms -- say nothing about the scene's scale)
     }
     if (radii.empty()) return RT_OK;
     std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
     const float r_cut = 16.f * radii[radii.size() / 2];
+    const float r_floor = radii[radii.size() / 2] / 16.f;          // radii below this are "small": bvh_half_width
     uint32_t n_tree = 0;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = c->h_spheres[i];
@@ -932,7 +1070,7 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
     if (full_upload && c->bvh_sah == 1 && n_tree >= kSahMinTree && n_tree <= kSahMaxTree) {
         uint32_t sah_leaves = 0, sah_depth = 0;
         bool built = false;
-        const int rc = build_on_host_sah(c, n_total, r_cut, n_always, n_tree, stream, &sah_leaves, &sah_depth, &built);
+        const int rc = build_on_host_sah(c, n_total, r_cut, r_floor, n_always, n_tree, stream, &sah_leaves, &sah_depth, &built);
         if (rc != RT_OK) return rc;
         if (built) {
             c->bvh = rt::BvhTables{ c->d_bvh, n_always, sah_leaves, n_always + rt::kBvhLeaf * sah_leaves, sah_depth,
@@ -956,7 +1094,7 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
 #endif
         depth_cap += margin;
         const size_t lds = (size_t)n_pad * 8 + (size_t)n_leaves * 74;
-        hipLaunchKernelGGL(rt_bvh_build_sah_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, depth_cap, c->d_bvh);
+        hipLaunchKernelGGL(rt_bvh_build_sah_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, r_floor, n_always, n_tree, n_pad, depth_cap, c->d_bvh);
         HIP_TRY(hipGetLastError());
         c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth_cap + 1, rt::bvh_emis_at(n_leaves, n_always + rt::kBvhLeaf * n_leaves) };
         c->bvh_ok = true;
@@ -968,10 +1106,10 @@ int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload)
         uint32_t level_nodes = 1;
         while (level_nodes < n_leaves) level_nodes *= 2;
         const size_t lds = std::max((size_t)n_pad * 8 + (size_t)level_nodes * 28, (size_t)n_leaves * 32);
-        hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, n_always, n_tree, n_pad, c->d_bvh);
+        hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, r_floor, n_always, n_tree, n_pad, c->d_bvh);
         HIP_TRY(hipGetLastError());
     } else {
-        const int rc = build_on_host(c, n_total, r_cut, n_always, n_tree, stream);
+        const int rc = build_on_host(c, n_total, r_cut, r_floor, n_always, n_tree, stream);
         if (rc != RT_OK) return rc;
     }
     uint32_t depth = 1;

@@ -61,7 +61,11 @@ struct BvhTables {
     uint32_t n_always, n_leaves, n_slots;
     uint32_t stack_depth;   // entries a lane's stack needs (tree depth + 1; an upper bound for trees shaped on the device)
     uint32_t emis_at;       // bvh_emis_at(n_leaves, n_slots), formed on the host: the kernel has no scalar registers to spare for it
+    uint32_t n_top;         // pairs [0, n_top) are the TOP of the tree in breadth-first order (pair 0 = the root's), the rest keep the builders' order
+                            // behind them (rt_bvh.hip rt_bvh_promote_kernel): the walk that reads its tables from HBM / L2 stages exactly these in LDS.
+                            // 0 = the builders' numbering, nothing promoted
 };
+constexpr uint32_t kBvhTopPairs = 255;      // eight full levels: 16 KiB of LDS beside the stacks, five workgroups per CU still fit
 // offsets into the blob, in float4 units
 __host__ __device__ inline uint32_t bvh_slots_at() { return 2u; }
 __host__ __device__ inline uint32_t bvh_index_at(uint32_t n_slots) { return 2u + n_slots; }
@@ -137,6 +141,7 @@ enum InstanceTables : uint8_t {
     kTabPairsLds = 2,       // the hierarchy (pairs, slots, stacks) staged in LDS (lds_bytes_pairs); needs BvhTables
     kTabPairsGlobal = 3,    // ... pairs and slots read where they lie; staged: header and stacks; needs BvhTables
     kTabPairsLdsSlotsGlobal = 4,   // ... the pairs staged, the slots read where they lie (the pairs fit the LDS budget, the whole tables do not)
+    kTabPairsTopLds = 5,    // ... pairs and slots read where they lie but for the promoted top of the tree (BvhTables::n_top pairs), which is staged
 };
 enum InstanceRole : uint8_t {
     kRoleNone = 0,          // diagnostics: reachable by row / name only

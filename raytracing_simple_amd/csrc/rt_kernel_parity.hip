@@ -124,6 +124,34 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs_gt        /* A/B: the L2 walk with the promoted top of the tree (BvhTables::n_top pairs) staged in LDS */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_gt
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_TOP_PAIRS 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs_gp        /* A/B: the L2 walk with both children's records requested one level ahead */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_gp
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_PREFETCH 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
+#define RT_NS parity_pairs_gtp       /* ... both arms together */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_gtp
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_TOP_PAIRS 1
+#define RT_OPT_PREFETCH 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_coop_check      /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coop_check
 #define RT_OPT_COOP 2
@@ -188,6 +216,9 @@ static const Instance kParityInstances[] = {
     { parity_pairs_2r::rt_trace_parity_pairs_2r, "rt_trace_parity_pairs_2r", 4, kTabPairsLds, kRoleNone, kInstTwoRays },
     { parity_pairs_2r_census::rt_trace_parity_pairs_2r_census, "rt_trace_parity_pairs_2r_census", 4, kTabPairsLds, kRoleNone, kInstTwoRays },
     { parity_pairs_g_w4::rt_trace_parity_pairs_g_w4, "rt_trace_parity_pairs_g_w4", 4, kTabPairsGlobal, kRoleNone, 0 },
+    { parity_pairs_gt::rt_trace_parity_pairs_gt, "rt_trace_parity_pairs_gt", 4, kTabPairsTopLds, kRoleNone, 0 },
+    { parity_pairs_gp::rt_trace_parity_pairs_gp, "rt_trace_parity_pairs_gp", 4, kTabPairsGlobal, kRoleNone, 0 },
+    { parity_pairs_gtp::rt_trace_parity_pairs_gtp, "rt_trace_parity_pairs_gtp", 4, kTabPairsTopLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },
     { parity_coop_census::rt_trace_parity_coop_census, "rt_trace_parity_coop_census", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },

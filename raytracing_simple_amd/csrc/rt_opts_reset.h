@@ -18,3 +18,5 @@
 #undef RT_OPT_RAYS2
 
 #undef RT_NO_RENDER_KERNEL
+#undef RT_OPT_TOP_PAIRS
+#undef RT_OPT_PREFETCH

@@ -77,6 +77,12 @@
 #ifndef RT_OPT_RAYS2
 #define RT_OPT_RAYS2 0                  /* diagnostics: the hierarchy walk with two pixels per lane (rt_walk.inc.h) */
 #endif
+#ifndef RT_OPT_TOP_PAIRS
+#define RT_OPT_TOP_PAIRS 0          /* with RT_OPT_WALK and RT_OPT_GLOBAL_TABLES 1: the promoted top of the tree (BvhTables::n_top pairs) staged in LDS */
+#endif
+#ifndef RT_OPT_PREFETCH
+#define RT_OPT_PREFETCH 0           /* diagnostics, with RT_OPT_WALK and RT_OPT_GLOBAL_TABLES 1: both children's records requested one level ahead (rt_walk.inc.h) */
+#endif
 #ifndef RT_OPT_PAIR_PLANES
 #define RT_OPT_PAIR_PLANES 0            /* diagnostics: the walk's staged pairs in four 16-byte planes (rt_walk.inc.h) */
 #endif

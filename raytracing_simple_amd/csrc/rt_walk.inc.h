@@ -156,10 +156,17 @@ constexpr uint32_t kWalkDone = 0xffffffffu;
 RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint32_t *index, uint16_t *my_stack, int stack_stride,
                        uint32_t n_always, V3 o, V3 d, const BvhRay &R, bool shadow, int round_len, uint32_t &cur, int &sp, float &w_far,
                        uint32_t &w_idx, uint32_t &w_slot, unsigned long long *cen, unsigned long long *hist, int tail = 0, uint32_t plane = 0,
-                       bool once = false) {
+                       bool once = false, const float4 *s_top = nullptr, uint32_t n_top = 0u) {
     const int lane_ = threadIdx.x & 63;
     uint32_t kind_m = shadow ? 0xffffffffu : 0u;        // all ones: a shadow ray (as a value the compiler does not see through)
     asm("" : "+v"(kind_m));
+#if RT_OPT_PREFETCH
+    // A/B ("a prefetch of both children's pairs one level ahead"): as soon as a pair's two references are in registers -- before
+    // its box tests -- one dword of EACH child's record is requested (the child's pair, or its leaf's first sphere): the line is then on its way
+    // into the vector L1 / L2 while the boxes are tested, whichever child the walk takes next and for the sibling it keeps.  The values are
+    // never used: they are held in two registers until the next step has issued its own loads (loads return in order, so that costs no wait).
+    float pf0 = 0.f, pf1 = 0.f;
+#endif
     while (cur != kWalkDone) {
         for (int round = round_len; cur < kBvhLeafRef && round > 0; --round) {
             if (cen) {
@@ -171,11 +178,45 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                 }
                 cen[1] += 1ull;
             }
-#if RT_OPT_PAIR_PLANES
+#if RT_OPT_TOP_PAIRS
+            // the promoted top of the tree (pairs [0, n_top), breadth-first: rt_bvh.hip) from LDS, everything below it where it lies in
+            // HBM / L2: a ray's first steps from the root -- and the kept siblings it returns to last -- never leave the CU
+            // (two blocks under the lanes' own masks -- ds_read_b128 for the lanes in the top, global_load_dwordx4 for the others.  The pointers
+            // carry their address spaces in their types: left generic, the compiler folds both blocks into ONE flat load through a selected
+            // pointer, and a flat load occupies the vector memory path for every lane -- the unit this kernel is bound by)
+            float4 A0, B0, A1, B1;
+            if (cur < n_top) {
+                typedef float F4v __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(3))) F4v *LdsF4;
+                const LdsF4 pp = (LdsF4)(s_top + 4u * cur);
+                const F4v a0 = pp[0], b0 = pp[1], a1 = pp[2], b1 = pp[3];
+                A0 = make_float4(a0.x, a0.y, a0.z, a0.w); B0 = make_float4(b0.x, b0.y, b0.z, b0.w);
+                A1 = make_float4(a1.x, a1.y, a1.z, a1.w); B1 = make_float4(b1.x, b1.y, b1.z, b1.w);
+            } else {
+                typedef float F4v __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(1))) F4v *GlobalF4;
+                const GlobalF4 pp = (GlobalF4)(s_pairs + 4u * cur);
+                const F4v a0 = pp[0], b0 = pp[1], a1 = pp[2], b1 = pp[3];
+                A0 = make_float4(a0.x, a0.y, a0.z, a0.w); B0 = make_float4(b0.x, b0.y, b0.z, b0.w);
+                A1 = make_float4(a1.x, a1.y, a1.z, a1.w); B1 = make_float4(b1.x, b1.y, b1.z, b1.w);
+            }
+#elif RT_OPT_PAIR_PLANES
             const float4 A0 = s_pairs[cur], B0 = s_pairs[cur + plane], A1 = s_pairs[cur + 2u * plane], B1 = s_pairs[cur + 3u * plane];
 #else
             const float4 *pp = s_pairs + 4u * cur;
             const float4 A0 = pp[0], B0 = pp[1], A1 = pp[2], B1 = pp[3];
+#endif
+#if RT_OPT_PREFETCH
+            asm volatile("; prefetched dwords of the step before retire here" :: "v"(pf0), "v"(pf1));
+            {
+                const uint32_t q0 = __float_as_uint(A0.w) & 0xffffu, q1 = __float_as_uint(A1.w) & 0xffffu;
+                const float *c0 = (q0 & kBvhLeafRef) ? reinterpret_cast<const float *>(s_slots + n_always + (uint32_t)kBvhLeaf * (q0 & (kBvhLeafRef - 1u)))
+                                                     : reinterpret_cast<const float *>(s_pairs + 4u * q0);
+                const float *c1 = (q1 & kBvhLeafRef) ? reinterpret_cast<const float *>(s_slots + n_always + (uint32_t)kBvhLeaf * (q1 & (kBvhLeafRef - 1u)))
+                                                     : reinterpret_cast<const float *>(s_pairs + 4u * q1);
+                pf0 = *c0;
+                pf1 = *c1;
+            }
 #endif
             float tn0, tn1;
             const float t_hi = w_far + R.tback;
@@ -333,9 +374,16 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #elif RT_OPT_GLOBAL_TABLES
     const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
     const float4 *s_slots = P.bvh.blob + bvh_slots_at();
-    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_hdr + 2);
+#if RT_OPT_TOP_PAIRS
+    const uint32_t n_top = P.bvh.n_top;         // staged: hdr | the promoted top of the tree (64 bytes per pair) | stacks
+    float4 *s_top = s_hdr + 2;
+#else
+    constexpr uint32_t n_top = 0u;
+    float4 *s_top = s_hdr + 2;
+#endif
+    uint16_t *s_stack = reinterpret_cast<uint16_t *>(s_top + 4 * n_top);
     const float4 *s_lightA = P.scene.lightA, *s_lightB = P.scene.lightB;
-    float4 *s_emis = s_hdr + 2 + stack_f4;        // (never read: the host keeps mat_in_lds off)
+    float4 *s_emis = s_top + 4 * n_top + stack_f4;        // (never read: the host keeps mat_in_lds off)
     float4 *s_colr = s_emis;
 #else
     // staged: hdr | pairs | slots | one stack of P.bvh.stack_depth u16 per lane ([level][lane]) | lights | materials
@@ -373,6 +421,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
         for (uint32_t i = tid; i < 4u * n_pairs; i += kBlockThreads) s_pairs[i] = g_pairs[i];
     }
+#endif
+#if RT_OPT_GLOBAL_TABLES == 1 && RT_OPT_TOP_PAIRS
+    for (uint32_t i = tid; i < 4u * n_top; i += kBlockThreads) s_top[i] = s_pairs[i];
 #endif
 #if !RT_OPT_GLOBAL_TABLES
     {
@@ -548,8 +599,13 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
                        W.slot, cen, hist, P.walk_round >> 8, kPlane);
 #else
+#if RT_OPT_TOP_PAIRS
+            walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
+                       W.slot, nullptr, nullptr, P.walk_round >> 8, kPlane, false, s_top, n_top);
+#else
             walk_pairs(s_pairs, s_slots, s_index, my_stack, kBlockThreads, n_always, o, d, R, ctl.st() == kShadow, P.walk_round & 0xff, W.cur, W.sp, W.far, W.idx,
                        W.slot, nullptr, nullptr, P.walk_round >> 8, kPlane);
+#endif
 #endif
         }
 

@@ -57,7 +57,8 @@ def _worker(rank, world, port, h, w, tile_rows, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h,w,tile_rows", [(64, 40, 8), (50, 33, 8), (17, 5, 16), (8, 8, 8)])
+@pytest.mark.parametrize("h,w,tile_rows", [(64, 40, 8), (50, 33, 8), (17, 5, 16), (8, 8, 8),
+                                           (2160, 3840, 8)])        # C4's frame (BASELINE configs[3]): what bench.py --gpus N gathers in its `c4` block
 def test_two_rank_gather_reassembles_image(h, w, tile_rows):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

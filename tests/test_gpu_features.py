@@ -62,9 +62,10 @@ def test_multi_device_context_equals_the_oracle(devices, tile_rows, w, h):
         _assert_same(_state(ctx, ctx.render_pass(spp)), want)
 
 
-def test_multi_device_context_at_full_size_equals_the_single_device_frame():
-    """C2 (1080p, 64 spp) on 8 emulated shards = the unsharded frame, bit for bit, counters included."""
-    w, h, spp = 1920, 1080, 64
+@pytest.mark.parametrize("w,h,spp", [(1920, 1080, 64), (3840, 2160, 256)], ids=["C2", "C4"])
+def test_multi_device_context_at_full_size_equals_the_single_device_frame(w, h, spp):
+    """C2 (1080p, 64 spp) and C4 (2160p, 256 spp: BASELINE's scaling configuration) on 8 emulated shards = the unsharded frame,
+    bit for bit, counters included."""
     sph = host.demo_scene()
     cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
     with api.RtContext(w, h) as one:
@@ -526,10 +527,8 @@ def test_consumer_behind_rt_stream_sees_whole_frames_of_a_multi_device_context()
 
 
 @pytest.fixture(scope="module")
-def rccl_double(tmp_path_factory):
-    """tests/rccl_double.cpp built into a scratch directory and bound in the place of RCCL by the diagnostics library, with a
-    repeated device list taken as distinct devices: rt_multi.hip's grouped ncclRecv / ncclSend branch and its failure handling
-    run on this one GPU.  Yields the double's own handle (call counts, failure injection); RCCL is restored afterwards."""
+def rccl_double_so(tmp_path_factory):
+    """tests/rccl_double.cpp built once per module into a scratch directory."""
     import os
     import subprocess
     from raytracing_simple_amd import _build
@@ -537,6 +536,16 @@ def rccl_double(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("rccl_double") / "librccl_double.so")
     subprocess.run([_build.hipcc(), "-O1", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
                     os.path.join(root, "tests", "rccl_double.cpp"), "-o", so], check=True, capture_output=True)
+    return so
+
+
+@pytest.fixture
+def rccl_double(rccl_double_so):
+    """The double bound in the place of RCCL by the diagnostics library FOR ONE TEST, with a repeated device list taken as distinct
+    devices: rt_multi.hip's grouped ncclRecv / ncclSend branch and its failure handling run on this one GPU.  Yields the double's own
+    handle (call counts, failure injection); RCCL -- and with it the one-GPU rehearsal's meaning of a repeated device list -- is
+    restored when the test ends, so the rehearsal tests of the diagnostics library keep exercising the emulated path."""
+    so = rccl_double_so
     lib = api.load_library(diag=True)
     assert lib.rt_debug_set_rccl_library(so.encode(), 1) == 0
     dbl = C.CDLL(so)                                        # the same handle the library binds (dlopen counts references)
@@ -580,6 +589,29 @@ def test_grouped_send_receive_branch_runs_against_the_double(rccl_double):
         assert got["destroy"] == n and got["abort"] == 0
 
 
+def test_c4_at_full_size_through_the_double_equals_the_single_device_frame(rccl_double):
+    """BASELINE configs[3] -- Demo, 3840x2160, 256 spp, 8 shards -- through the in-library grouped receive / send branch (against the
+    double): the assembled frame, the colour plane, the seeds and the counters are the one-device context's, and the double saw one
+    group of 7 receives and 7 sends."""
+    w, h, spp = 3840, 2160, 256
+    sph = host.demo_scene()
+    cam = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, w, h)
+    with api.RtContext(w, h) as one:
+        one.set_scene(sph); one.set_camera(cam)
+        want = _state(one, one.render_pass(spp))
+    rccl_double.rccl_double_reset()
+    with api.RtContext(w, h, devices=[0] * 8, diag=True) as ctx:
+        ctx.set_scene(sph); ctx.set_camera(cam)
+        got = _state(ctx, ctx.render_pass(spp))
+    assert np.array_equal(got["pixels"], want["pixels"])
+    assert np.array_equal(got["colors"].view(np.uint32), want["colors"].view(np.uint32))
+    assert np.array_equal(got["seeds"], want["seeds"])
+    assert {k: v for k, v in got["stats"].items() if k not in ("launches", "last_kernel_ms")} == \
+           {k: v for k, v in want["stats"].items() if k not in ("launches", "last_kernel_ms")}
+    calls = _double_counts(rccl_double)
+    assert calls["init"] == 1 and calls["group_start"] == calls["group_end"] == 1 and calls["recv"] == calls["send"] == 7 and calls["destroy"] == 8
+
+
 @pytest.mark.parametrize("where,kth", [("ncclSend", 2), ("ncclRecv", 4), ("ncclGroupEnd", 2), ("ncclGroupStart", 3)])
 def test_a_failing_rccl_call_breaks_the_context_and_teardown_returns(rccl_double, where, kth):
     """mark_broken for real: the k-th call of one RCCL function fails -- inside the group, at its end, at its
@@ -589,10 +621,17 @@ def test_a_failing_rccl_call_breaks_the_context_and_teardown_returns(rccl_double
     w, h = 96, 64
     cam = host.compute_camera(orig, target, w, h)
     rccl_double.rccl_double_reset()
+    import torch
+    with api.RtContext(w, h, devices=[0, 0, 0], diag=True) as first:        # (a first context pays the process-wide allocations: not part of the baseline)
+        first.set_scene(sph); first.set_camera(cam); first.render_pass(1)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(0)[0]
+    rccl_double.rccl_double_reset()
     ctx = api.RtContext(w, h, devices=[0, 0, 0], diag=True)
     ctx.set_scene(sph)
     ctx.set_camera(cam)
     assert np.array_equal(ctx.render_pass(1), O.render(sph, cam, w, h, 1)["pixels"])
+    assert torch.cuda.mem_get_info(0)[0] < free_before                          # (the context holds device memory now)
     assert rccl_double.rccl_double_fail(where.encode(), kth) == 0             # the kth call from now (a frame = 1 start, 2 receives, 2 sends, 1 end)
     with pytest.raises(api.RtError) as e:
         for _ in range(3):
@@ -605,6 +644,9 @@ def test_a_failing_rccl_call_breaks_the_context_and_teardown_returns(rccl_double
     t0 = time.time()
     ctx.close()
     assert time.time() - t0 < 5.0
+    # the double's transfers are done (or were never posted): the broken context's streams drain, so its teardown frees what it held --
+    # device memory is back at the baseline (a host that destroys and re-creates after a failure must not lose memory per failure)
+    assert torch.cuda.mem_get_info(0)[0] >= free_before - (1 << 20), (free_before, torch.cuda.mem_get_info(0)[0])
     got = _double_counts(rccl_double)
     assert got["abort"] == 3 and got["destroy"] == 0
     rccl_double.rccl_double_reset()

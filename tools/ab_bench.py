@@ -22,6 +22,8 @@ CONFIGS = {
     "c2": (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), 1920, 1080, 64),
     "c16": (lambda: scenes.demo_plus(16), 1920, 1080, 64),
     "c9": (lambda: scenes.demo_plus(9), 1920, 1080, 64),
+    "c10": (lambda: scenes.demo_plus(10), 1920, 1080, 64),
+    "c11": (lambda: scenes.demo_plus(11), 1920, 1080, 64),
     "c12": (lambda: scenes.demo_plus(12), 1920, 1080, 64),
     "c32": (lambda: scenes.demo_plus(32), 1920, 1080, 64),
     "c3": (lambda: scenes.random_spheres(1024), 1920, 1080, 16),

@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--mode", choices=["parity", "fast"], default="parity")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
+    import torch                        # (first: torch's HIP runtime must be the one the process initialises -- with the library's own context
+    torch.cuda.init()                   #  created before it, torch.cuda reported "No HIP GPUs are available" on the GPU box)
     from raytracing_simple_amd import api, host
     from tools.ab_bench import CONFIGS
     import bench
