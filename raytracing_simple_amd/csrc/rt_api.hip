@@ -286,6 +286,7 @@ RT_API void rt_destroy(rt_ctx *c) {
         for (int k = 0; k < 4; ++k)
             if (c->probe_ev[k]) (void)hipEventDestroy(c->probe_ev[k]);
         if (c->bvh_stage_ev) (void)hipEventDestroy(c->bvh_stage_ev);
+        if (c->dup_ev) (void)hipEventDestroy(c->dup_ev);
         if (c->h_bvh_stage) (void)hipHostFree(c->h_bvh_stage);
         if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
         for (int k = 0; k < 4; ++k)

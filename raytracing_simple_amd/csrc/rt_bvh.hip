@@ -63,7 +63,7 @@ __device__ inline uint32_t bvh_node_of(uint32_t leaf, uint32_t level, uint32_t n
     return (rank << (level - s2)) | ((b - a == 1) ? 0x80000000u : 0u);
 }
 
-__global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, uint32_t n, float r_cut, float r_floor, uint32_t n_always,
+__global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph, const uint8_t *dup, uint32_t n, float r_cut, float r_floor, uint32_t n_always,
                                                             uint32_t n_tree, uint32_t n_pad, float4 *blob) {
     extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, later 2 float4 per leaf
     __shared__ unsigned s_rmin, s_rmax, s_rmin_all;         // (s_rmin: over the regular radii, >= r_floor; s_rmin_all: over all of the tree's)
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
     // ---- 1. radius range of the tree's spheres ----
     for (uint32_t i = tid; i < n; i += 1024) {
         const float *r = reinterpret_cast<const float *>(sph + i);
-        if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
+        if (!(dup && dup[i]) && !bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
             const float ar = fabsf(r[0]);
             atomicMin(&s_rmin_all, __float_as_uint(ar));
             if (ar >= r_floor) atomicMin(&s_rmin, __float_as_uint(ar));
@@ -94,8 +94,9 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_kernel(const rt_sphere *sph
         if (i < n) {
             const float *r = reinterpret_cast<const float *>(sph + i);
             rad = r[0]; px = r[1]; py = r[2]; pz = r[3];
-            out = bvh_outside(rad, px, py, pz, r_cut);
-            in = !out;
+            const bool repeated = dup && dup[i];                // (a record an earlier one repeats bit for bit: in neither list, mark_duplicates)
+            out = !repeated && bvh_outside(rad, px, py, pz, r_cut);
+            in = !repeated && !out;
         }
         const unsigned long long ma = __builtin_amdgcn_ballot_w64(out), mt = __builtin_amdgcn_ballot_w64(in);
         const uint32_t before_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
@@ -297,7 +298,7 @@ __device__ inline unsigned bvh_longest(const float *b) {
     if (ez > e) axis = 2;
     return axis;
 }
-__global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere *sph, uint32_t n, float r_cut, float r_floor, uint32_t n_always, uint32_t n_tree,
+__global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere *sph, const uint8_t *dup, uint32_t n, float r_cut, float r_floor, uint32_t n_always, uint32_t n_tree,
                                                                 uint32_t n_pad, uint32_t depth_cap, float4 *blob) {
     extern __shared__ unsigned long long s_keys[];          // n_pad sort keys, then the per-leaf arrays below
     __shared__ unsigned s_rmin, s_rmin_all, s_rmax, s_rb[6];
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
     // ---- 1. radius range of the tree's spheres, and their box (the root's, whatever the order: it also gives the root's axis) ----
     for (uint32_t i = tid; i < n; i += 1024) {
         const float *r = reinterpret_cast<const float *>(sph + i);
-        if (!bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
+        if (!(dup && dup[i]) && !bvh_outside(r[0], r[1], r[2], r[3], r_cut)) {
             const float ar = fabsf(r[0]);
             atomicMin(&s_rmin_all, __float_as_uint(ar));
             if (ar >= r_floor) atomicMin(&s_rmin, __float_as_uint(ar));
@@ -342,8 +343,9 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
         if (i < n) {
             const float *r = reinterpret_cast<const float *>(sph + i);
             rad = r[0]; px = r[1]; py = r[2]; pz = r[3];
-            out = bvh_outside(rad, px, py, pz, r_cut);
-            in = !out;
+            const bool repeated = dup && dup[i];                // (a record an earlier one repeats bit for bit: in neither list, mark_duplicates)
+            out = !repeated && bvh_outside(rad, px, py, pz, r_cut);
+            in = !repeated && !out;
         }
         const unsigned long long ma = __builtin_amdgcn_ballot_w64(out), mt = __builtin_amdgcn_ballot_w64(in);
         const uint32_t before_a = __builtin_amdgcn_mbcnt_hi((uint32_t)(ma >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ma, 0u));
@@ -691,6 +693,7 @@ int build_on_host(rt_ctx *c, uint32_t n_total, float r_cut, float r_floor, uint3
     uint32_t na = 0;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = sph[i];
+        if (c->have_dups && c->h_dup_stage[i]) continue;
         if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) {
             slots[na] = make_float4(s.p.x, s.p.y, s.p.z, s.rad * s.rad);
             index[na] = i;
@@ -831,6 +834,7 @@ int build_on_host_sah(rt_ctx *c, uint32_t n_total, float r_cut, float r_floor, u
     float rmin = 3.4e38f, rmin_all = 3.4e38f, rmax = 0.f;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = sph[i];
+        if (c->have_dups && c->h_dup_stage[i]) continue;
         if (bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) {
             always.push_back(i);
         } else {
@@ -1035,6 +1039,59 @@ static int promote_top(rt_ctx *c, hipStream_t stream) {
     return RT_OK;
 }
 
+// Records that repeat an EARLIER record bit for bit in everything a ray test reads -- centre and radius^2 (SceneTables geom) -- can never be
+// the answer to a ray: the test returns the same distance for both, and the reference's loops keep the first of equals (a closest hit
+// takes a strictly nearer one only, .cl:215-232; a shadow ray stops at the first blocker, .cl:234-247) -- the lowest scene index wins.  So
+// they stay out of the hierarchy altogether, always-list included: nothing observable changes (the counters are formed from scene indices, not
+// from what the walk executes), and what the reference's own loader does to every scene file -- N zero-radius records at the origin in
+// front of the N real ones, Utility.cpp:120,154 -- stops costing complex.scn's walk 98 leaves stacked on one point.  One byte per record, from
+// the host mirror (open addressing over the four words; 3 ns per record), uploaded through page-locked staging only while the scene has
+// such records.  Materials play no part: a repeated record's material is never read.
+static int mark_duplicates(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
+    const bool had = c->have_dups;
+    c->have_dups = false;
+    c->n_dups = 0;
+    if (n_total < 2 || !c->d_dup) return RT_OK;
+    uint32_t cap = 16;
+    while (cap < 2u * n_total) cap *= 2;
+    static thread_local std::vector<uint32_t> table;
+    table.assign(cap, 0u);                      // record index + 1
+    static thread_local std::vector<uint8_t> flags;
+    flags.assign(n_total, 0);
+    auto key_of = [&](uint32_t i, uint32_t k[4]) {
+        const rt_sphere &s = c->h_spheres[i];
+        const float rr = s.rad * s.rad;
+        memcpy(&k[0], &s.p.x, 4); memcpy(&k[1], &s.p.y, 4); memcpy(&k[2], &s.p.z, 4); memcpy(&k[3], &rr, 4);
+    };
+    uint32_t found = 0;
+    for (uint32_t i = 0; i < n_total; ++i) {
+        uint32_t k[4];
+        key_of(i, k);
+        const rt_sphere &s = c->h_spheres[i];
+        if (!(fabsf(s.rad) <= 3.0e38f && fabsf(s.p.x) <= 3.0e38f && fabsf(s.p.y) <= 3.0e38f && fabsf(s.p.z) <= 3.0e38f)) continue;    // (NaN never equals itself; infinities stay as they are)
+        uint32_t h = k[0] * 0x9E3779B1u ^ (k[1] + 0x7F4A7C15u) * 0x85EBCA77u ^ (k[2] + 0x165667B1u) * 0xC2B2AE3Du ^ (k[3] + 0x27D4EB2Fu) * 0x2545F491u;
+        h ^= h >> 15;
+        for (uint32_t at = h & (cap - 1);; at = (at + 1) & (cap - 1)) {
+            const uint32_t e = table[at];
+            if (e == 0u) { table[at] = i + 1u; break; }
+            uint32_t q[4];
+            key_of(e - 1u, q);
+            if (q[0] == k[0] && q[1] == k[1] && q[2] == k[2] && q[3] == k[3]) { flags[i] = 1; found += 1; break; }
+        }
+    }
+    if (found == 0 && !had) return RT_OK;       // (nothing to say, and the device holds no flags of an earlier scene)
+    if (!c->h_dup_stage) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_dup_stage), (size_t)c->scene_cap, hipHostMallocDefault));
+    if (c->dup_stage_used) HIP_TRY(hipEventSynchronize(c->dup_ev));
+    memcpy(c->h_dup_stage, flags.data(), n_total);
+    HIP_TRY(hipMemcpyAsync(c->d_dup, c->h_dup_stage, n_total, hipMemcpyHostToDevice, stream));
+    if (!c->dup_ev) HIP_TRY(hipEventCreate(&c->dup_ev));
+    HIP_TRY(hipEventRecord(c->dup_ev, stream));
+    c->dup_stage_used = true;
+    c->have_dups = found != 0;
+    c->n_dups = found;
+    return RT_OK;
+}
+
 static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload);
 int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
     const int rc = build_bvh_tables(c, n_total, stream, full_upload);
@@ -1047,6 +1104,12 @@ static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, boo
     c->bvh_n_tree = 0;
     if (full_upload) c->bvh_est_valid = false;          // (a device-resident update keeps the upload's estimate: the probe logic decides when it is stale)
     if (c->bvh_min <= 0 || n_total < (uint32_t)c->bvh_min || !c->d_bvh) return RT_OK;
+    {
+        const int rc = mark_duplicates(c, n_total, stream);
+        if (rc != RT_OK) return rc;
+    }
+    const uint8_t *d_dup = c->have_dups ? c->d_dup : nullptr;
+    auto repeated = [&](uint32_t i) { return c->have_dups && c->h_dup_stage[i] != 0; };
     std::vector<float> radii;
     radii.reserve(n_total);
     for (uint32_t i = 0; i < n_total; ++i) {
@@ -1060,10 +1123,10 @@ static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, boo
     uint32_t n_tree = 0;
     for (uint32_t i = 0; i < n_total; ++i) {
         const rt_sphere &s = c->h_spheres[i];
-        n_tree += bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut) ? 0u : 1u;
+        n_tree += (repeated(i) || bvh_outside(s.rad, s.p.x, s.p.y, s.p.z, r_cut)) ? 0u : 1u;
     }
     if (n_tree < (uint32_t)c->bvh_min) return RT_OK;
-    const uint32_t n_always = n_total - n_tree;
+    const uint32_t n_always = n_total - c->n_dups - n_tree;
     const uint32_t n_leaves = (n_tree + rt::kBvhLeaf - 1) / rt::kBvhLeaf;
     c->bvh_n_tree = n_tree;
     // a full upload (rt_set_scene: the call blocks and the host has every record): the shape by surface area, on the host
@@ -1094,7 +1157,7 @@ static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, boo
 #endif
         depth_cap += margin;
         const size_t lds = (size_t)n_pad * 8 + (size_t)n_leaves * 74;
-        hipLaunchKernelGGL(rt_bvh_build_sah_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, r_floor, n_always, n_tree, n_pad, depth_cap, c->d_bvh);
+        hipLaunchKernelGGL(rt_bvh_build_sah_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, d_dup, n_total, r_cut, r_floor, n_always, n_tree, n_pad, depth_cap, c->d_bvh);
         HIP_TRY(hipGetLastError());
         c->bvh = rt::BvhTables{ c->d_bvh, n_always, n_leaves, n_always + rt::kBvhLeaf * n_leaves, depth_cap + 1, rt::bvh_emis_at(n_leaves, n_always + rt::kBvhLeaf * n_leaves) };
         c->bvh_ok = true;
@@ -1106,7 +1169,7 @@ static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, boo
         uint32_t level_nodes = 1;
         while (level_nodes < n_leaves) level_nodes *= 2;
         const size_t lds = std::max((size_t)n_pad * 8 + (size_t)level_nodes * 28, (size_t)n_leaves * 32);
-        hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, n_total, r_cut, r_floor, n_always, n_tree, n_pad, c->d_bvh);
+        hipLaunchKernelGGL(rt_bvh_build_kernel, dim3(1), dim3(1024), lds, stream, c->d_spheres, d_dup, n_total, r_cut, r_floor, n_always, n_tree, n_pad, c->d_bvh);
         HIP_TRY(hipGetLastError());
     } else {
         const int rc = build_on_host(c, n_total, r_cut, r_floor, n_always, n_tree, stream);

@@ -38,6 +38,12 @@ struct rt_ctx {
     size_t bvh_stage_cap = 0;           // float4
     hipEvent_t bvh_stage_ev = nullptr;
     bool bvh_stage_used = false;
+    // records that repeat an EARLIER record bit for bit in what a ray test reads ({centre, radius^2}) stay out of the hierarchy (rt_bvh.hip mark_duplicates):
+    // one byte per record on the device, uploaded only while the scene has such records
+    uint8_t *d_dup = nullptr, *h_dup_stage = nullptr;       // [scene_cap] each; the second page-locked
+    hipEvent_t dup_ev = nullptr;
+    bool dup_stage_used = false, have_dups = false;
+    uint32_t n_dups = 0;
     int bvh_sah = 1;                    // the hierarchy's shape is chosen by surface area (rt_bvh.hip): 1 = uploads below kAlwaysWalkFrom tree spheres on the host,
                                         // larger uploads and every device-resident update on the device; 2 = the device for uploads too; 0 = the fixed (halved) shape
     uint32_t bvh_n_tree = 0;            // spheres inside the tree (the slots are padded to whole leaves)

@@ -70,6 +70,12 @@ void free_scene(rt_ctx *c) {
     (void)hipFree(c->d_spheres);
     (void)hipFree(c->d_tables);
     (void)hipFree(c->d_bvh);
+    (void)hipFree(c->d_dup);
+    if (c->h_dup_stage) (void)hipHostFree(c->h_dup_stage);
+    c->d_dup = nullptr;
+    c->h_dup_stage = nullptr;
+    c->dup_stage_used = false;
+    c->have_dups = false;
     c->d_spheres = nullptr;
     c->d_tables = nullptr;
     c->d_bvh = nullptr;
@@ -91,15 +97,19 @@ int ensure_scene_capacity(rt_ctx *c, uint32_t count) {
     // blob: hdr 2 + slots (< cap + 8; up to twice that with the partial leaves of the shaped tree) + index (a quarter of the
     // slots) + pairs (< cap / 2 + 4) + two material records per slot, in float4
     if (e == hipSuccess) e = hipMalloc(&nb, ((size_t)cap * 6 + 64) * sizeof(float4));
+    uint8_t *nd = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&nd, (size_t)cap);
     if (e != hipSuccess) {
         (void)hipFree(ns);
         (void)hipFree(nt);
+        (void)hipFree(nb);
         return fail(RT_ERR_ALLOC, "scene tables for %u spheres: %s", cap, hipGetErrorString(e));
     }
     free_scene(c);
     c->d_spheres = ns;
     c->d_tables = nt;
     c->d_bvh = nb;
+    c->d_dup = nd;
     c->scene_cap = cap;
     return RT_OK;
 }

@@ -61,7 +61,7 @@ def test_device_built_tables_are_a_valid_hierarchy(maker):
             b = bvh_check.read_bvh(ctx)
         assert b is not None
         assert bvh_check.check_structure(sph, b) == []
-        assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(sph)
+        assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(bvh_check.first_of_equals(sph))
         leaves[by_area] = b["n_leaves"]
         area[by_area] = bvh_check.sum_of_box_areas(b)
         if by_area == 0 and b["n_leaves"] > 1:
@@ -139,6 +139,80 @@ def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
     _same(_render(sph, cam, w, h, spp, by_area=0), want)
     r = bvh_check.agreement(sph, cam, w, h, 60000)
     assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
+
+
+def _with_repeats(seed):
+    """A scene in which later records repeat earlier ones bit for bit in centre and radius^2 but NOT in material (a repeated diffuse sphere that
+    is glass, black, a light), a repeated light, a repeated ground (always-list), a record with the negated radius (same radius^2) and the
+    reference loader's own pattern: a block of zero-radius records at the origin in FRONT of everything (Utility.cpp:120,154)."""
+    rng = np.random.default_rng(100 + seed)
+    n_real, n_ph = 90, 40
+    real = np.zeros(n_real, api.SPHERE_DT)
+    real["rad"] = rng.uniform(0.8, 5.0, n_real).astype(np.float32)
+    real["p"] = rng.uniform(-30, 30, (n_real, 3)).astype(np.float32)
+    real["p"][:, 1] = np.abs(real["p"][:, 1])
+    real["c"] = rng.uniform(0.1, 0.95, (n_real, 3)).astype(np.float32)
+    real["refl"] = rng.integers(0, 3, n_real)
+    real["rad"][0], real["p"][0], real["refl"][0] = 1000.0, (0, -1000, 0), 0         # ground
+    real["rad"][1], real["p"][1], real["e"][1], real["refl"][1] = 8.0, (0, 45, 0), (10, 10, 10), 0          # light
+    for k, src in enumerate(rng.integers(2, 40, 12)):                                # repeats with OTHER materials, at higher indices
+        dst = 60 + k
+        real[dst] = real[src]
+        real["refl"][dst] = (int(real["refl"][src]) + 1 + k % 2) % 3
+        real["c"][dst] = (0.05, 0.9, 0.05)
+        if k % 4 == 0:
+            real["e"][dst] = (3, 3, 3)                                               # a repeat that is a light (it is sampled as one; never hit)
+        if k % 3 == 0:
+            real["rad"][dst] = -real["rad"][dst]                                     # same radius^2
+    real[75] = real[1]                                                               # the light, repeated
+    real[76] = real[0]                                                               # the ground, repeated (always-list)
+    real["c"][76] = (0.9, 0.1, 0.1)
+    phantoms = np.zeros(n_ph, api.SPHERE_DT)
+    return np.concatenate([phantoms, real]), (20.0, 40.0, 90.0), (0.0, 8.0, 0.0)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_repeated_records_stay_out_of_the_hierarchy_and_change_no_bit(seed):
+    """rt_bvh.hip mark_duplicates: a record that repeats an earlier one in centre and radius^2 is never a ray's answer (the reference keeps the
+    first of equals), so the hierarchy leaves it out -- whatever its material says.  Frames, colour plane, seeds and counters are the oracle's
+    through every builder; the tables hold exactly the first of each set of equals; and a device-resident update that ends a repeat (the record
+    moves away) or creates one brings the record back / takes it out."""
+    sph, orig, target = _with_repeats(seed)
+    w, h, spp = 80, 56, 4
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp)
+    for by_area in (1, 0, 2):
+        _same(_render(sph, cam, w, h, spp, by_area=by_area), want)
+    keep = bvh_check.first_of_equals(sph)
+    assert len(keep) == len(sph) - 39 - 12 - 2                                     # 39 of the 40 phantoms, the 12 repeats, the repeated light and ground
+    for by_area in (0, 1, 2):
+        with api.RtContext(64, 64, diag=True) as ctx:
+            ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
+            ctx.set_scene(sph)
+            b = bvh_check.read_bvh(ctx)
+        assert bvh_check.check_structure(sph, b) == []
+        assert b["n_always"] == 1                                                    # ONE ground
+    # updates: record 100 (a repeat) moves away -> it must be rendered; record 50 becomes a repeat of record 45 -> out again
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 152 * 1024))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        assert np.array_equal(ctx.render_pass(spp), want["pixels"])
+        moved = api.as_spheres(sph).copy()
+        moved["p"][100] = (5.0, 12.0, 20.0)
+        moved["rad"][100] = 6.0
+        ctx.update_spheres(100, moved[100:101])
+        ctx.reset()
+        assert np.array_equal(ctx.render_pass(spp), O.render(moved, cam, w, h, spp)["pixels"])
+        moved[50] = moved[45]
+        moved["refl"][50] = 1
+        ctx.update_spheres(50, moved[50:51])
+        ctx.reset()
+        got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        _same(got, O.render(moved, cam, w, h, spp))
+        assert bvh_check.check_structure(moved, bvh_check.read_bvh(ctx)) == []
 
 
 def test_measured_choice_changes_no_bit_and_probes_split_a_blocking_call():

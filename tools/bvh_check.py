@@ -57,6 +57,23 @@ def sum_of_box_areas(b):
     return total
 
 
+def first_of_equals(sph):
+    """Scene indices the hierarchy holds: every record but those that repeat an EARLIER finite record bit for bit in centre and radius^2
+    (rt_bvh.hip mark_duplicates: the reference's loops keep the first of equals, so a repeated record is never a ray's answer)."""
+    rad = sph["rad"].astype(np.float32)
+    key = np.concatenate([np.ascontiguousarray(sph["p"]).astype(np.float32).view(np.uint32).reshape(-1, 3), (rad * rad).view(np.uint32).reshape(-1, 1)], axis=1)
+    finite = np.isfinite(rad) & np.all(np.isfinite(np.ascontiguousarray(sph["p"]).astype(np.float32)), axis=1) & (np.abs(rad) <= 3.0e38)
+    seen, keep = set(), []
+    for i in range(len(sph)):
+        k = tuple(int(v) for v in key[i])
+        if finite[i] and k in seen:
+            continue
+        if finite[i]:
+            seen.add(k)
+        keep.append(i)
+    return keep
+
+
 def check_structure(sph, b):
     """Host-side walk of the tables the library built; returns a list of complaints (empty = fine)."""
     bad = []
@@ -70,8 +87,8 @@ def check_structure(sph, b):
         bad.append("always list not in scene order")
     tree_idx = idx[na:]
     real = tree_idx[tree_idx != 0xffffffff]
-    if sorted(list(al) + list(real)) != list(range(n)):
-        bad.append("slots do not hold every sphere exactly once")
+    if sorted(list(al) + list(real)) != first_of_equals(sph):
+        bad.append("slots do not hold every sphere (the first of bit-equal records) exactly once")
     rad = sph["rad"].astype(np.float32)
     p = np.ascontiguousarray(sph["p"]).astype(np.float32)
     for j in range(b["n_slots"]):
