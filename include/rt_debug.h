@@ -71,6 +71,7 @@ RT_API int rt_debug_tree_estimate(rt_ctx *ctx, double *out4);   /* { expected pa
 RT_API int rt_debug_set_choice_estimate(rt_ctx *ctx, int on);  /* 0: the surface-area estimate never decides hierarchy against sweep (every undecided scene is measured) */
 RT_API int rt_debug_bvh_pick(rt_ctx *ctx);   /* 0 = not decided yet, 1 = the hierarchy, 2 = the plain sweep (of this scene, by measurement) */
 RT_API int rt_debug_read_bvh(rt_ctx *ctx, float *blob_out, uint32_t cap_float4, uint32_t *counts4);
+RT_API int rt_debug_read_packed_pairs(rt_ctx *ctx, void *out, uint32_t cap_bytes, uint32_t *n_pairs);   /* the packed pair table of the walk that reads its tables from HBM / L2 (csrc/rt_device.h BvhTables::packed_at): 32 bytes of frame { r0.xyz, - }, { scale.xyz, - }, then 32 bytes per pair in the pairs' order; *n_pairs = 0 when the scene's hierarchy has none */
 RT_API int rt_debug_set_wg_waves(rt_ctx *ctx, int waves);          /* 0 = automatic, 1 or 4 wavefronts per workgroup */
 RT_API int rt_debug_set_tile_order(rt_ctx *ctx, int on);           /* 0 = natural tile order; 1 = heavy first (the default) */
 RT_API int rt_debug_read_tile_order(rt_ctx *ctx, uint32_t *order_out, uint32_t *cost_out, uint32_t cap, uint32_t *n_tiles, int *valid);

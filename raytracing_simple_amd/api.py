@@ -24,7 +24,7 @@ SYMBOLS = ["rt_render", "rt_release_cache", "rt_create", "rt_create_multi", "rt_
 # include/rt_debug.h: what librt_hip_diag.so exports on top of that
 DEBUG_SYMBOLS = ["rt_debug_variant_count", "rt_debug_instance", "rt_debug_instance_name", "rt_debug_shard_kernel", "rt_debug_break_gather", "rt_debug_set_rccl_library", "rt_debug_stage_tables", "rt_debug_eval", "rt_debug_sqrt_mismatches", "rt_debug_hitpost_mismatches",
                  "rt_debug_rcp_probe", "rt_debug_set_regen_gate", "rt_debug_set_mat_lds_limit", "rt_debug_set_persist",
-                 "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_set_bvh", "rt_debug_set_tree_shape", "rt_debug_set_walk", "rt_debug_set_walk_round", "rt_debug_bvh_pick", "rt_debug_tree_estimate", "rt_debug_set_choice_estimate", "rt_debug_create_breakdown", "rt_debug_walk_rays", "rt_debug_read_bvh", "rt_debug_set_tile_order", "rt_debug_read_tile_order", "rt_debug_set_wg_waves", "rt_debug_counters", "rt_debug_counters_raw",
+                 "rt_debug_set_ncus", "rt_debug_set_coop_min", "rt_debug_set_bvh", "rt_debug_set_tree_shape", "rt_debug_set_walk", "rt_debug_set_walk_round", "rt_debug_bvh_pick", "rt_debug_tree_estimate", "rt_debug_set_choice_estimate", "rt_debug_create_breakdown", "rt_debug_walk_rays", "rt_debug_read_bvh", "rt_debug_read_packed_pairs", "rt_debug_set_tile_order", "rt_debug_read_tile_order", "rt_debug_set_wg_waves", "rt_debug_counters", "rt_debug_counters_raw",
                  "rt_debug_reset_by_copy", "rt_debug_probe_seeds", "rt_debug_sidelog_read", "rt_debug_timelog_enable", "rt_debug_timelog_tag",
                  "rt_debug_timelog_read", "rt_debug_wavelog_read"]
 
@@ -137,6 +137,7 @@ def load_library(diag=False):
             "rt_debug_walk_rays": (i32, [vp, vp, u32, vp]),
             "rt_debug_set_walk_round": (i32, [vp, i32]),
             "rt_debug_read_bvh": (i32, [vp, vp, u32, vp]),
+            "rt_debug_read_packed_pairs": (i32, [vp, vp, u32, C.POINTER(u32)]),
             "rt_debug_set_tile_order": (i32, [vp, i32]),
             "rt_debug_set_wg_waves": (i32, [vp, i32]),
             "rt_debug_read_tile_order": (i32, [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(i32)]),

@@ -625,6 +625,57 @@ __global__ void __launch_bounds__(1024) rt_bvh_promote_kernel(float4 *blob, uint
     if (tid == 0) hdr[1].w = __uint_as_float((last & 0xffff0000u) | (uint32_t)map[root]);
 }
 
+// The PACKED pair table (rt_device.h BvhTables::packed_at) from the finished pairs, behind any builder and the promotion above, on the same stream:
+// per pair 32 bytes -- the two child boxes as twelve 16-bit grid coordinates in the frame of the ROOT box (plane = r0 + q * scale per axis),
+// the two references, the two lowest scene indices >> kBvhLowShift.  Every box of the tree lies inside the root's (unions of unions, exact), so
+// 16 bits per axis always cover it; a low plane is rounded DOWN to the grid and then one whole cell further, a high plane up and one cell further
+// (the quotient's own rounding is a hundredth of a cell), clamped to the frame's ends, which hold the root box by construction: the packed box
+// contains the stored one, and culling with it stays one-sided.  What it costs is tightness: a cell is 1 / 65 535 of the root box's extent.
+// One thread per pair; every thread forms the frame from the root pair itself (two cached reads), thread 0 of the grid stores it.
+__global__ void __launch_bounds__(256) rt_bvh_pack_pairs_kernel(const float4 *blob, uint32_t n_slots, uint32_t n_leaves, float4 *packed) {
+    const uint32_t n_pairs = n_leaves ? n_leaves - 1u : 0u;
+    const float4 *pairs = blob + rt::bvh_pairs_at(n_slots);
+    const uint32_t root = __float_as_uint(blob[1].w) & 0xffffu;
+    if (n_pairs == 0u || (root & rt::kBvhLeafRef)) return;
+    const float4 ra = pairs[4 * (size_t)root], rb = pairs[4 * (size_t)root + 1], rc = pairs[4 * (size_t)root + 2], rd = pairs[4 * (size_t)root + 3];
+    const float r0[3] = { fminf(ra.x, rc.x), fminf(ra.y, rc.y), fminf(ra.z, rc.z) };
+    const float r1[3] = { fmaxf(rb.x, rd.x), fmaxf(rb.y, rd.y), fmaxf(rb.z, rd.z) };
+    float scale[3], inv_scale[3];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = r1[a] - r0[a];
+        scale[a] = ext > 0.f ? (ext / 65535.f) * 1.000001f : 0.f;          // (r0 + 65535 * scale >= the root's high plane)
+        inv_scale[a] = scale[a] > 0.f ? 1.f / scale[a] : 0.f;
+    }
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid == 0u) {
+        packed[0] = make_float4(r0[0], r0[1], r0[2], 0.f);
+        packed[1] = make_float4(scale[0], scale[1], scale[2], 0.f);
+    }
+    uint4 *out = reinterpret_cast<uint4 *>(packed + 2);
+    for (uint32_t p = gid; p < n_pairs; p += gridDim.x * 256u) {
+        const float4 A0 = pairs[4 * (size_t)p], B0 = pairs[4 * (size_t)p + 1], A1 = pairs[4 * (size_t)p + 2], B1 = pairs[4 * (size_t)p + 3];
+        auto down = [&](float v, int a) -> uint32_t {
+            const float t = floorf((v - r0[a]) * inv_scale[a]);
+            const float q = t - 1.f;                                        // (NaN / negative / beyond the frame: the ends)
+            return q > 0.f ? (q < 65535.f ? (uint32_t)q : 65535u) : 0u;
+        };
+        auto up = [&](float v, int a) -> uint32_t {
+            const float t = ceilf((v - r0[a]) * inv_scale[a]);
+            const float q = t + 1.f;
+            return q < 65535.f ? (q > 0.f ? (uint32_t)q : 0u) : 65535u;
+        };
+        auto low16 = [](float w) -> uint32_t {
+            const uint32_t q = __float_as_uint(w) >> rt::kBvhLowShift;
+            return q < 0xffffu ? q : 0xffffu;
+        };
+        const uint32_t l0x = down(A0.x, 0), l0y = down(A0.y, 1), l0z = down(A0.z, 2), h0x = up(B0.x, 0), h0y = up(B0.y, 1), h0z = up(B0.z, 2);
+        const uint32_t l1x = down(A1.x, 0), l1y = down(A1.y, 1), l1z = down(A1.z, 2), h1x = up(B1.x, 0), h1y = up(B1.y, 1), h1z = up(B1.z, 2);
+        const uint32_t c0 = __float_as_uint(A0.w) & 0xffffu, c1 = __float_as_uint(A1.w) & 0xffffu;
+        out[2 * (size_t)p] = make_uint4(l0x | (l0y << 16), l0z | (h0x << 16), h0y | (h0z << 16), l1x | (l1y << 16));
+        out[2 * (size_t)p + 1] = make_uint4(l1z | (h1x << 16), h1y | (h1z << 16), c0 | (c1 << 16), low16(B0.w) | (low16(B1.w) << 16));
+    }
+}
+
 // Trees beyond what one workgroup sorts in LDS (more than 8192 spheres in the tree): the same tables from the host
 // mirror of the records -- same split, same top-down median ordering, same leaves, same sibling pairs, boxes rounded
 // outwards the same way -- written into a page-locked buffer and
@@ -1024,7 +1075,7 @@ static int promote_top(rt_ctx *c, hipStream_t stream) {
     if (!c->bvh_ok || c->bvh.n_leaves < 2 || c->bvh_top_pairs <= 0) return RT_OK;
     const uint32_t n_pairs = c->bvh.n_leaves - 1u;
     const size_t pairs_lds = rt::lds_bytes_pairs(0, 0, false, 64, c->bvh.n_leaves, 0, c->bvh.stack_depth, 256);
-    if (c->bvh_mixed != 0 && pairs_lds <= (size_t)c->bvh_lds_limit) return RT_OK;       // (rt_trace_*_pairs / _pairs_m will walk it: everything it chases is in LDS)
+    if (!RT_DIAGNOSTICS && c->bvh_mixed != 0 && pairs_lds <= (size_t)c->bvh_lds_limit) return RT_OK;       // (rt_trace_*_pairs / _pairs_m will walk it: everything it chases is in LDS; the diagnostics library, where any instance may be asked for by name, always promotes)
     const size_t used = rt::bvh_blob_float4s(c->bvh.n_leaves, c->bvh.n_slots);
     const size_t scratch4 = 4 * (size_t)n_pairs + ((size_t)n_pairs * 2 + 15) / 16 + 1;
     if (used + scratch4 > (size_t)c->scene_cap * 6 + 64) return RT_OK;                   // (no room behind the blob: the tree stays as it is, nothing is staged)
@@ -1036,6 +1087,22 @@ static int promote_top(rt_ctx *c, hipStream_t stream) {
     hipLaunchKernelGGL(rt_bvh_promote_kernel, dim3(1), dim3(1024), 0, stream, c->d_bvh, c->bvh.n_slots, c->bvh.n_leaves, top, c->d_bvh + used);
     HIP_TRY(hipGetLastError());
     c->bvh.n_top = std::min(top, n_pairs);
+    return RT_OK;
+}
+
+// ... and the packed pair table behind the blob (where the promotion's scratch was: it is dead by then -- same stream), for the same trees
+static int pack_pairs(rt_ctx *c, hipStream_t stream) {
+    c->bvh.packed_at = 0;
+    if (!c->bvh_ok || c->bvh.n_leaves < 2 || c->bvh_packed == 0) return RT_OK;
+    const uint32_t n_pairs = c->bvh.n_leaves - 1u;
+    const size_t pairs_lds = rt::lds_bytes_pairs(0, 0, false, 64, c->bvh.n_leaves, 0, c->bvh.stack_depth, 256);
+    if (!RT_DIAGNOSTICS && c->bvh_mixed != 0 && pairs_lds <= (size_t)c->bvh_lds_limit) return RT_OK;       // (walked from LDS: nothing reads a packed table -- but for an instance asked for by name in the diagnostics library)
+    const size_t used = rt::bvh_blob_float4s(c->bvh.n_leaves, c->bvh.n_slots);
+    if (used + 2 + 2 * (size_t)n_pairs > (size_t)c->scene_cap * 6 + 64) return RT_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n_pairs + 255) / 256, 1024);
+    hipLaunchKernelGGL(rt_bvh_pack_pairs_kernel, dim3(blocks), dim3(256), 0, stream, c->d_bvh, c->bvh.n_slots, c->bvh.n_leaves, c->d_bvh + used);
+    HIP_TRY(hipGetLastError());
+    c->bvh.packed_at = (uint32_t)used;
     return RT_OK;
 }
 
@@ -1094,8 +1161,9 @@ static int mark_duplicates(rt_ctx *c, uint32_t n_total, hipStream_t stream) {
 
 static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload);
 int build_bvh(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
-    const int rc = build_bvh_tables(c, n_total, stream, full_upload);
-    return rc != RT_OK ? rc : promote_top(c, stream);
+    int rc = build_bvh_tables(c, n_total, stream, full_upload);
+    if (rc == RT_OK) rc = promote_top(c, stream);
+    return rc != RT_OK ? rc : pack_pairs(c, stream);
 }
 
 static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {

@@ -330,6 +330,23 @@ RT_API int rt_debug_set_bvh(rt_ctx *c, int min_spheres, int lds_limit) {
     int rc = dbg_apply(c, dbg_set_bvh_lds, lds_limit);
     return rc != RT_OK ? rc : dbg_apply(c, dbg_set_bvh_min, min_spheres);
 }
+// the packed pair table (rt_device.h BvhTables::packed_at) as it lies in HBM: 2 float4 of frame, then 32 bytes per pair; *n_pairs = 0 without one
+RT_API int rt_debug_read_packed_pairs(rt_ctx *c, void *out, uint32_t cap_bytes, uint32_t *n_pairs) {
+    if (!c || c->multi || !n_pairs) return fail(RT_ERR_ARG, "null / multi-device context");
+    int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = wait_all(c);
+    if (rc != RT_OK) return rc;
+    *n_pairs = 0;
+    if (!c->bvh_ok || c->bvh.packed_at == 0 || c->bvh.n_leaves < 2) return RT_OK;
+    const size_t need = 32 + 32 * (size_t)(c->bvh.n_leaves - 1);
+    *n_pairs = c->bvh.n_leaves - 1;
+    if (out) {
+        if (cap_bytes < need) return fail(RT_ERR_ARG, "the packed table takes %zu bytes", need);
+        HIP_TRY(hipMemcpy(out, c->d_bvh + c->bvh.packed_at, need, hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
 // the blob of rt_device.h BvhTables as it lies in HBM (float4 units), and four numbers {always, leaves, stack depth, root pair}
 // (slots = always + 8 * leaves);
 // counts of 0 = the scene has no hierarchy

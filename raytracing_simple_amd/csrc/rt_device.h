@@ -64,7 +64,12 @@ struct BvhTables {
     uint32_t n_top;         // pairs [0, n_top) are the TOP of the tree in breadth-first order (pair 0 = the root's), the rest keep the builders' order
                             // behind them (rt_bvh.hip rt_bvh_promote_kernel): the walk that reads its tables from HBM / L2 stages exactly these in LDS.
                             // 0 = the builders' numbering, nothing promoted
+    uint32_t packed_at;     // float4 offset into the blob of the PACKED pair table (rt_bvh.hip rt_bvh_pack_pairs_kernel), 0 = none: frame { r0.xyz, - },
+                            // { scale.xyz, - }, then 32 bytes per pair in the pairs' own order -- twelve 16-bit grid coordinates of the two child
+                            // boxes (plane = r0 + q * scale, lows rounded down and highs up by a whole cell), the two references, the two lowest
+                            // scene indices >> kBvhLowShift.  Half the bytes per pair step for the walk that reads its tables from HBM / L2
 };
+constexpr uint32_t kBvhLowShift = 2;        // (262 144 scene indices in 16 bits: a lower bound of the lowest index below a child prunes as safely as the index itself)
 constexpr uint32_t kBvhTopPairs = 255;      // eight full levels: 16 KiB of LDS beside the stacks, five workgroups per CU still fit
 // offsets into the blob, in float4 units
 __host__ __device__ inline uint32_t bvh_slots_at() { return 2u; }
@@ -142,6 +147,7 @@ enum InstanceTables : uint8_t {
     kTabPairsGlobal = 3,    // ... pairs and slots read where they lie; staged: header and stacks; needs BvhTables
     kTabPairsLdsSlotsGlobal = 4,   // ... the pairs staged, the slots read where they lie (the pairs fit the LDS budget, the whole tables do not)
     kTabPairsTopLds = 5,    // ... pairs and slots read where they lie but for the promoted top of the tree (BvhTables::n_top pairs), which is staged
+    kTabPairsPacked = 6,    // ... the PACKED pair table (BvhTables::packed_at) and the slots read where they lie; staged: header, frame and stacks
 };
 enum InstanceRole : uint8_t {
     kRoleNone = 0,          // diagnostics: reachable by row / name only

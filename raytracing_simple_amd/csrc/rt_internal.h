@@ -55,6 +55,7 @@ struct rt_ctx {
     int bvh_lds_limit = 31 * 1024;      // its tables are staged in LDS while five workgroups of that size fit a CU (2048 spheres: 6.2 ms from L2 with
                                         // 4-5 waves per SIMD against 9.5 ms from LDS with two workgroups per CU); larger ones are read from HBM / L2
     int bvh_top_pairs = (int)rt::kBvhTopPairs;   // pairs promoted to the front of the table for the walk that reads it from HBM / L2 (rt_bvh.hip promote_top; diagnostics knob: 0 = none)
+    int bvh_packed = 1;                 // the packed pair table is built for trees the walk reads from HBM / L2 (rt_bvh.hip pack_pairs; diagnostics knob: 0 = never)
     int bvh_mixed = 1;                  // tables beyond that limit whose PAIRS fit it: pairs staged, slots from HBM / L2 (rt_trace_*_pairs_m); diagnostics knob: 0 = everything from L2
     int walk_gate = 16, walk_round = 4; // rt_walk.inc.h: ready lanes that make the wavefront shade; pair steps in a row before a leaf step
                                         // (round 4, this kernel: 2 / 3 / 4 / 6 in a row = 5.42 / 5.37 / 5.22 / 5.45 ms on C3, profiles/r04k_walk_sweep.jsonl)

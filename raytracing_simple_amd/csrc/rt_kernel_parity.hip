@@ -152,6 +152,15 @@
 #include "rt_trace.inc.h"
 #include "rt_opts_reset.h"
 
+#define RT_NS parity_pairs_gq        /* A/B: the L2 walk over the PACKED pair table (32 bytes per pair step instead of 64) */
+#define RT_KERNEL_NAME rt_trace_parity_pairs_gq
+#define RT_OPT_WALK 1
+#define RT_OPT_GLOBAL_TABLES 1
+#define RT_OPT_PACKED_PAIRS 1
+#define RT_OPT_MINWAVES 5
+#include "rt_trace.inc.h"
+#include "rt_opts_reset.h"
+
 #define RT_NS parity_coop_check      /* coop + the sequential sweep beside it (verification) */
 #define RT_KERNEL_NAME rt_trace_parity_coop_check
 #define RT_OPT_COOP 2
@@ -218,6 +227,7 @@ static const Instance kParityInstances[] = {
     { parity_pairs_g_w4::rt_trace_parity_pairs_g_w4, "rt_trace_parity_pairs_g_w4", 4, kTabPairsGlobal, kRoleNone, 0 },
     { parity_pairs_gt::rt_trace_parity_pairs_gt, "rt_trace_parity_pairs_gt", 4, kTabPairsTopLds, kRoleNone, 0 },
     { parity_pairs_gp::rt_trace_parity_pairs_gp, "rt_trace_parity_pairs_gp", 4, kTabPairsGlobal, kRoleNone, 0 },
+    { parity_pairs_gq::rt_trace_parity_pairs_gq, "rt_trace_parity_pairs_gq", 4, kTabPairsPacked, kRoleNone, 0 },
     { parity_pairs_gtp::rt_trace_parity_pairs_gtp, "rt_trace_parity_pairs_gtp", 4, kTabPairsTopLds, kRoleNone, 0 },
     { parity_coop_check::rt_trace_parity_coop_check, "rt_trace_parity_coop_check", 4, kTabSweepLds, kRoleNone, kInstStaticCoop },
     { parity_census::rt_trace_parity_census, "rt_trace_parity_census", 4, kTabSweepLds, kRoleNone, 0 },

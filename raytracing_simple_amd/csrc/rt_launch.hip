@@ -122,7 +122,7 @@ static bool bvh_usable(const rt_ctx *c) { return c->bvh_ok && c->wg_waves != 1 &
 // whatever route selected it -- the measured choice, a forced form, or a diagnostics mode.
 static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::LaunchParams &p, size_t *lds_out) {
     const bool needs_bvh = inst.tables == rt::kTabPairsLds || inst.tables == rt::kTabPairsGlobal || inst.tables == rt::kTabPairsLdsSlotsGlobal ||
-                           inst.tables == rt::kTabPairsTopLds;
+                           inst.tables == rt::kTabPairsTopLds || inst.tables == rt::kTabPairsPacked;
     p.bvh = rt::BvhTables{};
     if (needs_bvh) {
         if (!c->bvh_ok || !c->bvh.blob)
@@ -149,6 +149,11 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
         case rt::kTabPairsLdsSlotsGlobal:
             p.mat_in_lds = 0;
             lds = pairs_only_lds(c, n_samples, inst.waves);
+            break;
+        case rt::kTabPairsPacked:           // header | the packed table's frame | stacks
+            if (c->bvh.packed_at == 0) return fail(RT_ERR_STATE, "%s reads the packed pair table and this scene's hierarchy has none", inst.name);
+            p.mat_in_lds = 0;
+            lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 64 * inst.waves) + 32;
             break;
         case rt::kTabPairsTopLds:           // header | the promoted top of the tree (n_top pairs = "n_top + 1 leaves") | stacks
             p.mat_in_lds = 0;
@@ -266,7 +271,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     c->launches += 1;
     c->last_kernel = inst->name;
     c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal || inst->tables == rt::kTabPairsLdsSlotsGlobal ||
-                    inst->tables == rt::kTabPairsTopLds) ? 1 : 2;
+                    inst->tables == rt::kTabPairsTopLds || inst->tables == rt::kTabPairsPacked) ? 1 : 2;
     if (p.tile_cost && n_samples >= 4) {
         c->cost_valid = true;
         c->cost_tiles = n_tiles;

@@ -20,3 +20,4 @@
 #undef RT_NO_RENDER_KERNEL
 #undef RT_OPT_TOP_PAIRS
 #undef RT_OPT_PREFETCH
+#undef RT_OPT_PACKED_PAIRS

@@ -80,6 +80,9 @@
 #ifndef RT_OPT_TOP_PAIRS
 #define RT_OPT_TOP_PAIRS 0          /* with RT_OPT_WALK and RT_OPT_GLOBAL_TABLES 1: the promoted top of the tree (BvhTables::n_top pairs) staged in LDS */
 #endif
+#ifndef RT_OPT_PACKED_PAIRS
+#define RT_OPT_PACKED_PAIRS 0       /* with RT_OPT_WALK and RT_OPT_GLOBAL_TABLES 1: the walk reads the packed pair table (32 bytes per pair, rt_device.h) */
+#endif
 #ifndef RT_OPT_PREFETCH
 #define RT_OPT_PREFETCH 0           /* diagnostics, with RT_OPT_WALK and RT_OPT_GLOBAL_TABLES 1: both children's records requested one level ahead (rt_walk.inc.h) */
 #endif

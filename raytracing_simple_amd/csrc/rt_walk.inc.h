@@ -78,6 +78,24 @@ RT_DEV BvhRay bvh_ray(const float4 *s_hdr, V3 o, V3 d) {
     R.clo = mk(-(o.x + pad) * R.inv.x, -(o.y + pad) * R.inv.y, -(o.z + pad) * R.inv.z);
     R.chi = mk(-(o.x - pad) * R.inv.x, -(o.y - pad) * R.inv.y, -(o.z - pad) * R.inv.z);
     R.tback = tback;
+#if RT_OPT_PACKED_PAIRS
+    // The packed pair table stores a box plane as a grid coordinate q: plane = r0 + q * scale (the frame: s_hdr[2], s_hdr[3]).  Its slab distance
+    // (plane - (o +- pad)) / d = q * (scale / d) + (r0 - (o +- pad)) / d is ONE fused multiply-add on q with the two constants folded per ray
+    // into the places of 1 / d and -(o +- pad) / d -- bvh_misses_upto then runs unchanged on the grid coordinates.  Rounding: the plane the
+    // computed distance belongs to lies within u (4 far + 6 |o|) of the stored one (one rounding each of scale / d, of the folded offset -- a
+    // fused multiply-add on r0 --, and of the step's own), inside the pad's linear term 64 u (|o| + far + r_max) like the unfolded form's
+    // 4u |plane - o| + 2u |o|.  A ray that is not `sane` (infinite pad: it visits everything) gets 0 and -+infinity: q * 0 -+ inf leaves every
+    // axis unconstrained whatever the frame holds (scale / d may overflow there).
+    {
+        const float4 f0 = s_hdr[2], f1 = s_hdr[3];
+        const V3 k = mk(f1.x * R.inv.x, f1.y * R.inv.y, f1.z * R.inv.z);
+        const V3 cl = mk(__builtin_fmaf(f0.x, R.inv.x, R.clo.x), __builtin_fmaf(f0.y, R.inv.y, R.clo.y), __builtin_fmaf(f0.z, R.inv.z, R.clo.z));
+        const V3 ch = mk(__builtin_fmaf(f0.x, R.inv.x, R.chi.x), __builtin_fmaf(f0.y, R.inv.y, R.chi.y), __builtin_fmaf(f0.z, R.inv.z, R.chi.z));
+        R.inv = sane ? k : mk(0.f, 0.f, 0.f);
+        R.clo = sane ? cl : mk(-inf, -inf, -inf);
+        R.chi = sane ? ch : mk(inf, inf, inf);
+    }
+#endif
     return R;
 }
 // True when the ray stretch [-tback, t_far + tback] misses the grown box for certain.  A slab distance is
@@ -178,7 +196,20 @@ RT_DEV void walk_pairs(const float4 *s_pairs, const float4 *s_slots, const uint3
                 }
                 cen[1] += 1ull;
             }
-#if RT_OPT_TOP_PAIRS
+#if RT_OPT_PACKED_PAIRS
+            // 32 bytes per pair instead of 64 (rt_device.h BvhTables::packed_at): the kernel is bound by the bytes its lanes pull through the
+            // vector memory path -- 64 bytes per clock and CU, whatever hits where -- and has vector ALU to spare, so
+            // the boxes travel as 16-bit grid coordinates and are tested as such (bvh_ray folds the frame into the ray's constants)
+            float4 A0, B0, A1, B1;
+            {
+                const uint4 *pq = reinterpret_cast<const uint4 *>(s_pairs) + 2u * cur;
+                const uint4 w0 = pq[0], w1 = pq[1];
+                A0 = make_float4((float)(w0.x & 0xffffu), (float)(w0.x >> 16), (float)(w0.y & 0xffffu), __uint_as_float(w1.z & 0xffffu));
+                B0 = make_float4((float)(w0.y >> 16), (float)(w0.z & 0xffffu), (float)(w0.z >> 16), __uint_as_float((w1.w & 0xffffu) << kBvhLowShift));
+                A1 = make_float4((float)(w0.w & 0xffffu), (float)(w0.w >> 16), (float)(w1.x & 0xffffu), __uint_as_float(w1.z >> 16));
+                B1 = make_float4((float)(w1.x >> 16), (float)(w1.y & 0xffffu), (float)(w1.y >> 16), __uint_as_float((w1.w >> 16) << kBvhLowShift));
+            }
+#elif RT_OPT_TOP_PAIRS
             // the promoted top of the tree (pairs [0, n_top), breadth-first: rt_bvh.hip) from LDS, everything below it where it lies in
             // HBM / L2: a ray's first steps from the root -- and the kept siblings it returns to last -- never leave the CU
             // (two blocks under the lanes' own masks -- ds_read_b128 for the lanes in the top, global_load_dwordx4 for the others.  The pointers
@@ -372,11 +403,18 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     float4 *s_emis = s_pairs + 4 * n_pairs + stack_f4;        // (never read: the host keeps mat_in_lds off)
     float4 *s_colr = s_emis;
 #elif RT_OPT_GLOBAL_TABLES
+#if RT_OPT_PACKED_PAIRS
+    const float4 *s_pairs = P.bvh.blob + P.bvh.packed_at + 2;      // (the packed table's records: 2 x 16 bytes per pair, behind its frame)
+#else
     const float4 *s_pairs = P.bvh.blob + bvh_pairs_at(n_slots);
+#endif
     const float4 *s_slots = P.bvh.blob + bvh_slots_at();
 #if RT_OPT_TOP_PAIRS
     const uint32_t n_top = P.bvh.n_top;         // staged: hdr | the promoted top of the tree (64 bytes per pair) | stacks
     float4 *s_top = s_hdr + 2;
+#elif RT_OPT_PACKED_PAIRS
+    constexpr uint32_t n_top = 0u;              // staged: hdr | the packed table's frame | stacks
+    float4 *s_top = s_hdr + 4;
 #else
     constexpr uint32_t n_top = 0u;
     float4 *s_top = s_hdr + 2;
@@ -416,6 +454,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         s_cam[3] = make_float4(0.f, 0.f, P.inv_w, P.inv_h);
     }
     if (tid < 2) s_hdr[tid] = P.bvh.blob[tid];
+#if RT_OPT_PACKED_PAIRS
+    if (tid >= 2 && tid < 4) s_hdr[tid] = P.bvh.blob[P.bvh.packed_at + tid - 2];
+#endif
 #if RT_OPT_GLOBAL_TABLES == 2
     {
         const float4 *g_pairs = P.bvh.blob + bvh_pairs_at(n_slots);

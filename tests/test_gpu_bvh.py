@@ -17,7 +17,9 @@ import bvh_check  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None, by_area=1, estimate=1):
+def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, passes=None, by_area=1, estimate=1, inst=None):
+    if inst:
+        mode = api.instance_mode(inst)           # a kernel instance of the diagnostics library by its symbol
     with api.RtContext(w, h, diag=True) as ctx:
         ctx._check(ctx._lib.rt_debug_set_choice_estimate(ctx._h, estimate))
         ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
@@ -31,6 +33,9 @@ def _render(sph, cam, w, h, spp, bvh_min=1, form=1, mode=api.RT_MODE_PARITY, pas
             px = ctx.render_pass(n)
         return {"pixels": px, "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats(),
                 "pick": ctx._lib.rt_debug_bvh_pick(ctx._h)}
+
+
+L2_WALKS = ["rt_trace_parity_pairs_g", "rt_trace_parity_pairs_gq", "rt_trace_parity_pairs_gt", "rt_trace_parity_pairs_gp"]
 
 
 def _same(got, want):
@@ -59,13 +64,15 @@ def test_device_built_tables_are_a_valid_hierarchy(maker):
             ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 1, 0))
             ctx.set_scene(sph)
             b = bvh_check.read_bvh(ctx)
+            pk = bvh_check.read_packed(ctx)
         assert b is not None
         assert bvh_check.check_structure(sph, b) == []
+        if b["n_leaves"] > 1:               # the diagnostics library promotes the top of EVERY tree and packs its pairs (rt_bvh.hip promote_top, pack_pairs)
+            assert b["root"] == 0
+            assert pk is not None and bvh_check.check_packed(b, pk) == []
         assert b["n_always"] + sum(1 for i in b["index"][b["n_always"]:] if i != 0xffffffff) == len(bvh_check.first_of_equals(sph))
         leaves[by_area] = b["n_leaves"]
         area[by_area] = bvh_check.sum_of_box_areas(b)
-        if by_area == 0 and b["n_leaves"] > 1:
-            assert b["root"] == b["n_leaves"] // 2 - 1
     assert leaves[0] <= leaves[1] <= 2 * leaves[0]              # partial leaves only where they pay (below 128 tree spheres both are the device's)
     assert leaves[2] == leaves[0]                               # the device cuts between whole leaves
     n_tree = len(sph) - b["n_always"]
@@ -137,6 +144,8 @@ def test_adversarial_scenes_equal_the_oracle_with_the_hierarchy_forced(seed):
     want = O.render(sph, cam, w, h, spp)
     _same(_render(sph, cam, w, h, spp), want)
     _same(_render(sph, cam, w, h, spp, by_area=0), want)
+    for inst in L2_WALKS:                                                           # the walks that read their tables from HBM / L2, every form of them
+        _same(_render(sph, cam, w, h, spp, inst=inst), want)
     r = bvh_check.agreement(sph, cam, w, h, 60000)
     assert r["closest_differ"] == 0 and r["shadow_differ"] == 0, r
 

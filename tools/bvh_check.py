@@ -47,6 +47,52 @@ def read_bvh(ctx):
             "n_always": n_always, "n_leaves": n_leaves, "stack_depth": depth, "n_slots": n_slots, "root": root}
 
 
+def read_packed(ctx):
+    """The packed pair table (rt_debug_read_packed_pairs): {"r0", "scale" (float32[3]), "words" (uint32[n_pairs, 8])} or None."""
+    n = C.c_uint32()
+    ctx._check(ctx._lib.rt_debug_read_packed_pairs(ctx._h, None, 0, C.byref(n)))
+    if n.value == 0:
+        return None
+    raw = np.zeros(8 + 8 * n.value, np.uint32)
+    ctx._check(ctx._lib.rt_debug_read_packed_pairs(ctx._h, raw.ctypes.data_as(C.c_void_p), raw.nbytes, C.byref(n)))
+    return {"r0": raw[0:3].view(np.float32), "scale": raw[4:7].view(np.float32), "words": raw[8:].reshape(n.value, 8)}
+
+
+def check_packed(b, pk, low_shift=2):
+    """The packed table against the pairs it was made from (rt_bvh.hip rt_bvh_pack_pairs_kernel): every packed box CONTAINS its pair's box
+    (in exact arithmetic: plane = r0 + q * scale), by no more than three cells a side; references equal; the packed lowest scene index is a
+    lower bound of the pair's, at most 2^shift - 1 below it (or saturated).  Returns a list of complaints."""
+    bad = []
+    pr = b["pairs"].reshape(-1, 4, 4)
+    w = pk["words"]
+    if len(w) != len(pr):
+        return ["%d packed records for %d pairs" % (len(w), len(pr))]
+    r0, sc = pk["r0"].astype(np.float64), pk["scale"].astype(np.float64)
+    lo16, hi16 = (lambda v: (v & 0xffff).astype(np.float64)), (lambda v: (v >> 16).astype(np.float64))
+    # words: l0x|l0y, l0z|h0x, h0y|h0z, l1x|l1y, l1z|h1x, h1y|h1z, ref0|ref1, low0|low1
+    q_lo = [np.stack([lo16(w[:, 0]), hi16(w[:, 0]), lo16(w[:, 1])], 1), np.stack([lo16(w[:, 3]), hi16(w[:, 3]), lo16(w[:, 4])], 1)]
+    q_hi = [np.stack([hi16(w[:, 1]), lo16(w[:, 2]), hi16(w[:, 2])], 1), np.stack([hi16(w[:, 4]), lo16(w[:, 5]), hi16(w[:, 5])], 1)]
+    for side in (0, 1):
+        lo, hi = pr[:, 2 * side, :3].astype(np.float64), pr[:, 2 * side + 1, :3].astype(np.float64)
+        plo, phi = r0 + q_lo[side] * sc, r0 + q_hi[side] * sc
+        if np.any(plo > lo) or np.any(phi < hi):
+            bad.append("side %d: %d packed boxes do not contain their pair's" % (side, int(np.sum(np.any(plo > lo, 1) | np.any(phi < hi, 1)))))
+        slack = np.maximum(lo - plo, phi - hi) / np.maximum(sc, 1e-300)
+        inner = (q_lo[side] > 0) & (q_hi[side] < 65535)
+        if np.any(slack[inner] > 3.01):
+            bad.append("side %d: a packed plane lies %.2f cells off its pair's" % (side, float(slack[inner].max())))
+        ref = pr[:, 2 * side, 3].view(np.uint32) & 0xffff
+        got = (w[:, 6] & 0xffff) if side == 0 else (w[:, 6] >> 16)
+        if np.any(ref != got):
+            bad.append("side %d: references differ" % side)
+        low = pr[:, 2 * side + 1, 3].view(np.uint32).astype(np.int64)
+        lq = ((w[:, 7] & 0xffff) if side == 0 else (w[:, 7] >> 16)).astype(np.int64)
+        bound = lq << low_shift
+        if np.any(bound > low) or np.any((low - bound >= (1 << low_shift)) & (lq != 0xffff)):
+            bad.append("side %d: the packed lowest scene index is not a tight lower bound" % side)
+    return bad
+
+
 def sum_of_box_areas(b):
     """Surface areas of every child box of every pair, summed: what a random ray's expected number of box visits goes with."""
     pr = b["pairs"].reshape(-1, 4, 4)
