@@ -280,8 +280,11 @@ RT_API int rt_read_seeds(rt_ctx *ctx, uint32_t *out_host);
 RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 /* The kernel instance the context's last launch used, by its symbol (what a profiler lists): the library picks it
  * from the scene -- "rt_trace_parity_w1" (few spheres: one wavefront per workgroup), "..._coop_w1" / "..._coop"
- * (12 and more: wave-ballot any-hit sharing), "..._pairs" (hundreds of small spheres: a hierarchy, where it measured
- * faster than the sweep on this scene), the same with "fast".  "" before the first launch.  Frames do not depend on it. */
+ * (12 and more: wave-ballot any-hit sharing; with 4 to 11 spheres whichever of the two the scene's first launches timed
+ * faster -- coop warm, coop timed, plain warm, plain timed: passes of the frame like any other), "..._pairs" (hundreds of
+ * small spheres: a hierarchy, where it measured faster than the sweep on this scene; "..._pairs_m" / "..._pairs_g" when its
+ * tables outgrow LDS), "..._g" (a plain sweep over a table beyond LDS), the same with "fast".  "" before the first launch.
+ * Frames do not depend on it. */
 RT_API const char *rt_last_kernel(const rt_ctx *ctx);
 /* Hierarchy or plain sweep for the current scene (scenes with 56 to 1500 small spheres; larger ones always walk the
  * hierarchy).  rt_set_scene builds the tree on the host and with it a surface-area estimate of what a ray costs either

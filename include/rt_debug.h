@@ -53,7 +53,7 @@ RT_API int rt_debug_set_regen_gate(rt_ctx *ctx, int gate);        /* 0 = automat
 RT_API int rt_debug_set_mat_lds_limit(rt_ctx *ctx, int bytes);
 RT_API int rt_debug_set_persist(rt_ctx *ctx, int on);
 RT_API int rt_debug_set_ncus(rt_ctx *ctx, int n);
-RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);
+RT_API int rt_debug_set_coop_min(rt_ctx *ctx, int min_spheres);    /* the cooperative any-hit instances from this many spheres on (0 = never); a threshold set here decides alone -- the library's own measurement of coop against plain on scenes of 4 .. 11 spheres (rt_launch.hip launch_small) is switched off for the context */
 /* hierarchy over the small spheres of large scenes: smallest tree that is built and used (0 = never; library default
  * 56), largest LDS footprint it is used at (0 = keep; default 31 KiB = five workgroups per CU).  rt_debug_read_bvh: the tables as the kernels
  * stage them (csrc/rt_device.h BvhTables) and counts4 = { always, leaves, stack depth, root pair } (slots = always + 8 * leaves), all 0 without a hierarchy */

@@ -544,6 +544,9 @@ __global__ void __launch_bounds__(1024) rt_bvh_build_sah_kernel(const rt_sphere 
     }
 }
 
+#if RT_DIAGNOSTICS
+// ---- Two arms of the A/B on the walk that reads its tables from HBM / L2 (measured, not adopted) --
+// they exist in the diagnostics library only: the product's trees keep the builders' numbering and carry no packed table. ----
 // The TOP of the tree to the front of the pair table (BvhTables::n_top), for the walk that reads its tables from HBM / L2 and stages only
 // this much of them in LDS (rt_walk.inc.h RT_OPT_TOP_PAIRS).  Every builder numbers the pairs by their leaves (pair of a node = first leaf
 // of its right child - 1), which is what lets the host lay the blob out before the tree exists; that order scatters the top levels over
@@ -675,6 +678,8 @@ __global__ void __launch_bounds__(256) rt_bvh_pack_pairs_kernel(const float4 *bl
         out[2 * (size_t)p + 1] = make_uint4(l1z | (h1x << 16), h1y | (h1z << 16), c0 | (c1 << 16), low16(B0.w) | (low16(B1.w) << 16));
     }
 }
+
+#endif   // RT_DIAGNOSTICS
 
 // Trees beyond what one workgroup sorts in LDS (more than 8192 spheres in the tree): the same tables from the host
 // mirror of the records -- same split, same top-down median ordering, same leaves, same sibling pairs, boxes rounded
@@ -1072,6 +1077,10 @@ hipError_t prepare_bvh_build() {
 // build (20-60 us); trees that are walked from LDS keep the builders' numbering.
 static int promote_top(rt_ctx *c, hipStream_t stream) {
     c->bvh.n_top = 0;
+#if !RT_DIAGNOSTICS
+    (void)stream;
+    return RT_OK;           // (the arm that stages the promoted top lost its A/B: the product library promotes nothing)
+#else
     if (!c->bvh_ok || c->bvh.n_leaves < 2 || c->bvh_top_pairs <= 0) return RT_OK;
     const uint32_t n_pairs = c->bvh.n_leaves - 1u;
     const size_t pairs_lds = rt::lds_bytes_pairs(0, 0, false, 64, c->bvh.n_leaves, 0, c->bvh.stack_depth, 256);
@@ -1088,11 +1097,16 @@ static int promote_top(rt_ctx *c, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     c->bvh.n_top = std::min(top, n_pairs);
     return RT_OK;
+#endif
 }
 
 // ... and the packed pair table behind the blob (where the promotion's scratch was: it is dead by then -- same stream), for the same trees
 static int pack_pairs(rt_ctx *c, hipStream_t stream) {
     c->bvh.packed_at = 0;
+#if !RT_DIAGNOSTICS
+    (void)stream;
+    return RT_OK;           // (likewise: no product kernel reads a packed table)
+#else
     if (!c->bvh_ok || c->bvh.n_leaves < 2 || c->bvh_packed == 0) return RT_OK;
     const uint32_t n_pairs = c->bvh.n_leaves - 1u;
     const size_t pairs_lds = rt::lds_bytes_pairs(0, 0, false, 64, c->bvh.n_leaves, 0, c->bvh.stack_depth, 256);
@@ -1104,6 +1118,7 @@ static int pack_pairs(rt_ctx *c, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     c->bvh.packed_at = (uint32_t)used;
     return RT_OK;
+#endif
 }
 
 // Records that repeat an EARLIER record bit for bit in everything a ray test reads -- centre and radius^2 (SceneTables geom) -- can never be

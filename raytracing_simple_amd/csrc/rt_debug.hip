@@ -185,7 +185,7 @@ static int dbg_set_gate(rt_ctx *c, int v) { c->regen_gate = v; return RT_OK; }
 static int dbg_set_matlds(rt_ctx *c, int v) { c->mat_lds_limit = v; return RT_OK; }
 static int dbg_set_persist(rt_ctx *c, int v) { c->persist = v ? 1 : 0; return RT_OK; }
 static int dbg_set_ncus(rt_ctx *c, int v) { c->n_cus = v; return RT_OK; }
-static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v & 0xffffff; c->coop_kmax = v >> 24; return RT_OK; }
+static int dbg_set_coop(rt_ctx *c, int v) { c->coop_min = v & 0xffffff; c->coop_kmax = v >> 24; c->coop_probe = 0; rearm_probe(c); return RT_OK; }     // (a threshold set by hand decides alone: no measurement)
 static int dbg_set_wg(rt_ctx *c, int v) { c->wg_waves = v; return RT_OK; }
 static int dbg_set_order(rt_ctx *c, int v) { c->use_order = v ? 1 : 0; c->order_valid = false; return RT_OK; }
 static int dbg_apply(rt_ctx *c, int (*fn)(rt_ctx *, int), int v) { return c->multi ? rt::multi_debug_each(c, fn, v) : fn(c, v); }

@@ -68,6 +68,13 @@ struct rt_ctx {
     int use_estimate = 1;               // diagnostics knob: 0 = every undecided scene is measured
     double est_ratio = 0.0;             // the estimate's predicted walk / sweep time (0 = none made)
     int probe_state = 0;                // probe launches issued (0..4)
+    // ... and for a scene WITHOUT a hierarchy and fewer spheres than coop_min: cooperative any-hit or not, by the same four launches (rt_launch.hip).
+    // Below 12 spheres the threshold alone picks wrongly either way -- the Demo scene is 2 % faster without the sharing, the reference's simple.scn,
+    // caustic.scn and caustic3.scn (6 and 10 records) 7-11 % faster with it (profiles/r06_reference_scenes.jsonl) -- so it is measured.
+    int coop_pick = 0;                  // 0 = not decided yet, 1 = cooperative any-hit, 2 = plain
+    bool probing_coop = false;          // the probe launches in flight time coop against plain (not hierarchy against sweep)
+    bool last_coop = false;             // the last launch was a cooperative any-hit instance (what a multi-device context's other shards follow)
+    int coop_probe = 1;                 // diagnostics knob: 0 = the threshold alone decides (round 5's behaviour)
     uint32_t probe_tree = 0, probe_always = 0;   // the tree the verdict was measured on
     int probe_updates = 0;              // device-resident updates since the verdict (it is measured again after 256)
     rt_ctx *choice_leader = nullptr;    // a shard of a multi-device context: the shard whose verdict it follows (null: its own)

@@ -151,7 +151,8 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
             lds = pairs_only_lds(c, n_samples, inst.waves);
             break;
         case rt::kTabPairsPacked:           // header | the packed table's frame | stacks
-            if (c->bvh.packed_at == 0) return fail(RT_ERR_STATE, "%s reads the packed pair table and this scene's hierarchy has none", inst.name);
+            if (c->bvh.packed_at == 0 && c->bvh.n_leaves >= 2)      // (a tree of one leaf has no pairs: the walk starts at the leaf and the frame is never used)
+                return fail(RT_ERR_STATE, "%s reads the packed pair table and this scene's hierarchy has none", inst.name);
             p.mat_in_lds = 0;
             lds = rt::lds_bytes_pairs(0, 0, false, n_samples, 1, 0, c->bvh.stack_depth, 64 * inst.waves) + 32;
             break;
@@ -170,7 +171,8 @@ static int bind_tables(rt_ctx *c, const rt::Instance &inst, int n_samples, rt::L
     return RT_OK;
 }
 
-// `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one), 2 = the plain sweep
+// `form`: 0 = the context's choice, 1 = the hierarchy (if the scene has one), 2 = the plain sweep; 3 / 4 = the sweep WITH / WITHOUT cooperative
+// any-hit whatever the sphere count says (the small-scene measurement below)
 static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, bool natural_order = false) {
     if (!c->have_scene || !c->have_cam)
         return fail(RT_ERR_STATE, "rt_set_scene and rt_set_camera must precede rendering");
@@ -192,10 +194,10 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     // slots of a CU full (a 4-wavefront workgroup waits for four free slots at once) and give the heavy-first order a
     // finer granule; each stages its own copy of the tables, so only while 24 copies fit a CU.
     bool fast = c->mode == RT_MODE_FAST;
-    const bool coop = c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min;
+    const bool coop = form == 3 ? true : (form == 4 ? false : (c->coop_min > 0 && c->scene.n_spheres >= (uint32_t)c->coop_min));
     const bool w1 = c->wg_waves == 1 || (c->wg_waves == 0 && lds_sweep + (coop ? 1536u : 256u) <= 6 * 1024);   // + the instance's static LDS
     int role = coop ? rt::kRoleCoop : rt::kRolePlain, waves = w1 ? 1 : 4;
-    if (form != 2 && bvh_usable(c)) {
+    if (form != 2 && form < 3 && bvh_usable(c)) {
         // large scenes: the walk over the hierarchy, from LDS while its tables leave room for five workgroups per CU
         role = bvh_fits_lds(c, n_samples) ? rt::kRolePairs : (bvh_pairs_fit_lds(c, n_samples) ? rt::kRolePairsMixed : rt::kRolePairsGlobal);
         waves = 4;
@@ -270,6 +272,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     c->current_sample += n_samples;
     c->launches += 1;
     c->last_kernel = inst->name;
+    c->last_coop = inst->role == rt::kRoleCoop || inst->role == rt::kRolePersistCoop;
     c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal || inst->tables == rt::kTabPairsLdsSlotsGlobal ||
                     inst->tables == rt::kTabPairsTopLds || inst->tables == rt::kTabPairsPacked) ? 1 : 2;
     if (p.tile_cost && n_samples >= 4) {
@@ -292,7 +295,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
 constexpr int kProbeSteps = 4;          // hierarchy warm, hierarchy timed, sweep warm, sweep timed
 
 void probe_poll(rt_ctx *c, bool wait) {
-    if (c->bvh_pick != 0 || c->probe_state < kProbeSteps) return;
+    if ((c->probing_coop ? c->coop_pick : c->bvh_pick) != 0 || c->probe_state < kProbeSteps) return;
     if (wait) {
         if (hipEventSynchronize(c->probe_ev[3]) != hipSuccess) return;
     } else if (hipEventQuery(c->probe_ev[3]) != hipSuccess) {
@@ -305,6 +308,10 @@ void probe_poll(rt_ctx *c, bool wait) {
         return;
     }
     const double ta = (double)a / c->probe_samples[0], tb = (double)b / c->probe_samples[1];
+    if (c->probing_coop) {                      // (arm 0 = cooperative any-hit, arm 1 = plain; the plain instance keeps a tie: it is what the threshold says)
+        c->coop_pick = ta < 0.98 * tb ? 1 : 2;
+        return;
+    }
     c->probe_ms[0] = ta;
     c->probe_ms[1] = tb;
     c->bvh_pick = ta <= 1.05 * tb ? 1 : 2;      // (a dead band of 5 % towards the usual winner: no flipping on a tie)
@@ -321,7 +328,7 @@ static int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
     int rc = chain(c, stream);
     if (rc != RT_OK) return rc;
     if (timed) HIP_TRY(hipEventRecord(c->probe_ev[2 * arm], stream));
-    rc = launch_form(c, n_samples, stream, arm == 0 ? 1 : 2, true);
+    rc = launch_form(c, n_samples, stream, c->probing_coop ? (arm == 0 ? 3 : 4) : (arm == 0 ? 1 : 2), true);
     if (rc != RT_OK) return rc;
     if (timed) {
         HIP_TRY(hipEventRecord(c->probe_ev[2 * arm + 1], stream));
@@ -332,6 +339,8 @@ static int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
 }
 
 void rearm_probe(rt_ctx *c) {
+    c->coop_pick = 0;
+    c->probing_coop = false;
     c->bvh_pick = 0;
     c->pick_estimated = false;
     c->probe_state = 0;
@@ -341,6 +350,7 @@ void rearm_probe(rt_ctx *c) {
 
 // after a device-resident update rebuilt the hierarchy: is the verdict still about this tree?
 void rearm_probe_if_changed(rt_ctx *c) {
+    if (c->probing_coop) return;                // (coop against plain on a scene without a hierarchy: an update cannot change the sphere count -- the verdict stays)
     if (c->bvh_pick == 0 && c->probe_state == 0) return;
     if (!c->bvh_ok) {
         rearm_probe(c);
@@ -393,8 +403,39 @@ double estimate_ratio(const rt_ctx *c) {
     return (kEstPair * c->bvh_est_pairs + kEstAlways * (double)c->bvh.n_always) / ((double)c->scene.n_spheres + kEstSweepFixed);
 }
 
+// Cooperative any-hit or not for a scene of fewer than coop_min spheres (rt_internal.h coop_pick): the four launches of the hierarchy's probe --
+// coop warm, coop timed, plain warm, plain timed; passes of the frame like any other, natural tile order -- and the faster one renders the rest.
+// A blocking call of 32 passes or more times 4 passes per arm (2 from 16): a pass of a six-sphere scene at 800x600 lasts 20 microseconds.
+constexpr uint32_t kCoopProbeFrom = 4;          // (below four spheres a shadow sweep has nothing to share out)
+static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
+    if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
+        return launch_priced(c, n_samples, stream, c->choice_leader->last_coop ? 3 : 4);
+    const uint32_t n = c->scene.n_spheres;
+    const bool open = c->coop_probe != 0 && c->coop_min > 0 && n >= kCoopProbeFrom && n < (uint32_t)c->coop_min && c->wg_waves == 0 && c->persist == 0 &&
+                      tables_fit_lds(c, n_samples);
+    if (!open) return launch_priced(c, n_samples, stream, 2);
+    c->probing_coop = true;
+    probe_poll(c, false);
+    if (c->coop_pick != 0) return launch_priced(c, n_samples, stream, c->coop_pick == 1 ? 3 : 4);
+    if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 4);     // probes in flight: what the threshold says meanwhile
+    if (may_block && n_samples >= 16) {
+        const int timed = n_samples >= 32 ? 4 : 2;
+        int done = 0;
+        while (c->probe_state < kProbeSteps) {
+            const int k = (c->probe_state & 1) ? timed : 1;
+            const int rc = launch_probe(c, k, stream);
+            if (rc != RT_OK) return rc;
+            done += k;
+        }
+        probe_poll(c, true);
+        return launch_priced(c, n_samples - done, stream, c->coop_pick == 1 ? 3 : 4);
+    }
+    return launch_probe(c, n_samples, stream);
+}
+
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
     const bool measured = c->walk_forced == 0 && c->mode < 100;
+    if (measured && n_samples > 0 && c->local_rows != 0 && c->have_scene && c->have_cam && !bvh_usable(c)) return launch_small(c, n_samples, stream, may_block);
     if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c))
         return measured ? launch_priced(c, n_samples, stream, 2) : launch_form(c, n_samples, stream, 0);
     // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
