@@ -284,13 +284,49 @@ def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
         ctx.set_scene(scenes.demo_plus(12)[0])                                 # another scene: priced again
         ctx.reset(); ctx.render_pass(30)
         assert ctx.stats()["launches"] == 2
-        ctx.set_scene(scenes.demo_plus(9)[0])                                  # ... but not for a short frame
+        ctx.set_scene(scenes.demo_plus(13)[0])                                 # ... but not for a short frame
         ctx.reset(); ctx.render_pass(20)
         assert ctx.stats()["launches"] == 1
         # progressive launches split the same way and stay the oracle's
         ctx.set_scene(sph)
         ctx.reset(); ctx.render_pass(40); ctx.render_pass(24)
         _assert_same(_state(ctx, ctx.read_pixels()), O.render(sph, cam, w, h, 64))
+
+
+def test_small_scenes_measure_cooperative_any_hit_against_plain_on_their_first_launches():
+    """Scenes of 4 to 11 spheres (no hierarchy, below the cooperative instances' threshold): the first four launches time the sweep WITH the
+    wave-ballot any-hit sharing and WITHOUT it (rt_launch.hip launch_small: coop warm, coop timed, plain warm, plain timed -- passes of the frame
+    like any other) and the faster instance renders the rest.  A blocking frame holds all four; frames, colour plane, seeds and counters are the
+    oracle's whatever is picked and however the passes are split; a threshold set by hand switches the measurement off."""
+    w, h = 200, 120
+    for maker in (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), lambda: scenes.demo_plus(10)):
+        sph, orig, target = maker()
+        cam = host.compute_camera(orig, target, w, h)
+        want = O.render(sph, cam, w, h, 40)
+        with api.RtContext(w, h) as ctx:
+            ctx.set_scene(sph); ctx.set_camera(cam)
+            _assert_same(_state(ctx, ctx.render_pass(40)), want)
+            assert ctx.stats()["launches"] == 5                                  # 1 + 4 + 1 + 4 passes of probes, then the other 30 (the probes left tile costs: no pricing launch)
+            picked = ctx.last_kernel
+            assert picked in ("rt_trace_parity_w1", "rt_trace_parity_coop_w1")
+            ctx.reset()
+            _assert_same(_state(ctx, ctx.render_pass(40)), want)
+            assert ctx.stats()["launches"] == 1 and ctx.last_kernel == picked    # decided: one launch per frame from here on
+            ctx.update_spheres(1, api.as_spheres(sph)[1:2])                      # a device-resident update keeps the verdict (the sphere count cannot change)
+            ctx.reset(); ctx.render_pass(40)
+            assert ctx.stats()["launches"] == 1 and ctx.last_kernel == picked
+            ctx.set_scene(sph[:5])                                               # another scene: measured again, here through queued one-pass launches
+            names = []
+            for _ in range(6):
+                ctx.render_async(1)
+                names.append(ctx.last_kernel)
+            assert names[:4] == ["rt_trace_parity_coop_w1", "rt_trace_parity_coop_w1", "rt_trace_parity_w1", "rt_trace_parity_w1"]
+            assert np.array_equal(ctx.read_pixels(), O.render(sph[:5], cam, w, h, 6)["pixels"])
+        with api.RtContext(w, h, diag=True) as ctx:                               # a threshold set by hand decides alone
+            ctx._check(ctx._lib.rt_debug_set_coop_min(ctx._h, 12))
+            ctx.set_scene(sph); ctx.set_camera(cam)
+            _assert_same(_state(ctx, ctx.render_pass(40)), want)
+            assert ctx.stats()["launches"] == 2 and ctx.last_kernel == "rt_trace_parity_w1"      # (pricing launch + the rest)
 
 
 def test_the_order_of_a_priced_first_frame_is_sorted_once_more_from_the_whole_frame():

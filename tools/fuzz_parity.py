@@ -95,9 +95,44 @@ def family4(seed):
     return sph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
 
 
+def family5(seed):
+    """What round 6's builders special-case, made nasty: the reference loader's pattern -- a block of zero-radius records at one point in FRONT
+    of the real ones (Utility.cpp:120,154), the point being the origin or the very spot the camera looks at --, records that repeat earlier ones
+    in centre and radius^2 with other materials / negated radius (rt_bvh.hip mark_duplicates), and spheres far SMALLER than the rest (radii down
+    to 10^-5 of the median, some exactly zero, scattered where rays pass: their boxes are grown at build time, bvh_half_width)."""
+    rng = np.random.default_rng(400000 + seed)
+    n_real = int(rng.choice([70, 120, 200, 330]))
+    n_ph = int(rng.choice([0, 8, 40, n_real]))
+    real = np.zeros(n_real, api.SPHERE_DT)
+    real["p"] = rng.uniform(-40, 40, (n_real, 3)).astype(np.float32)
+    real["rad"] = rng.uniform(0.5, 4.0, n_real).astype(np.float32)
+    real["c"] = rng.uniform(0.05, 0.95, (n_real, 3)).astype(np.float32)
+    real["refl"] = rng.choice([api.DIFF, api.DIFF, api.SPEC, api.REFR], n_real)
+    real["rad"][0], real["p"][0], real["refl"][0] = 1000.0, (0, -1040, 0), api.DIFF
+    small = rng.choice(np.arange(2, n_real), n_real // 5, replace=False)
+    real["rad"][small] = (real["rad"][small] * 10.0 ** rng.uniform(-5, -1, len(small))).astype(np.float32)
+    real["rad"][small[: len(small) // 4]] = 0.0
+    for j in rng.choice(n_real, int(rng.integers(1, 4)), replace=False):
+        real["e"][j] = rng.uniform(2.0, 25.0, 3).astype(np.float32)
+    k = max(2, n_real // 8)
+    src = rng.integers(1, n_real // 2, k)
+    dst = n_real - 1 - np.arange(k)
+    real[dst] = real[src]
+    real["refl"][dst] = rng.choice([api.DIFF, api.SPEC, api.REFR], k)
+    real["c"][dst] = rng.uniform(0.05, 0.95, (k, 3)).astype(np.float32)
+    real["rad"][dst[::3]] = -real["rad"][dst[::3]]
+    spot = np.zeros(3, np.float32) if seed % 2 else real["p"][int(rng.integers(1, n_real // 2))].copy()
+    ph = np.zeros(n_ph, api.SPHERE_DT)
+    ph["p"] = spot
+    sph = np.concatenate([ph, real])
+    orig = rng.uniform(-70, 70, 3).astype(np.float32)
+    target = spot if seed % 3 else rng.uniform(-10, 10, 3).astype(np.float32)
+    return sph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
+
+
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bvh_form = int(os.environ.get("RT_FUZZ_BVH", "0"))
-gen = {"2": family2, "3": family3, "4": family4}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
+gen = {"2": family2, "3": family3, "4": family4, "5": family5}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
 bad = []
 kernels = {}
 for seed in range(first, first + count):

@@ -22,12 +22,13 @@ if [ "$PART" = "A" ]; then
     raytracing_simple_amd/rt_inflight 1 20 | tee $O/rt_inflight.jsonl; raytracing_simple_amd/rt_inflight 2 20 | tee -a $O/rt_inflight.jsonl
     RT_BENCH_SINGLE_DEVICE=1 timeout -k 10 300 python bench.py --gpus 2 --steps 6 --warmup 2 > $O/bench_n2_rehearsal.json 2> $O/bench_n2.err; tail -c 300 $O/bench_n2_rehearsal.json
 elif [ "$PART" = "P" ]; then
-    # every shipped parity instance has a stamped record: _w1 (c2), _coop_w1 (c16, c5), _pairs (c3), _coop (box120), _pairs_g (r2048)
-    # (RT_PROF_SPECS="c2 parity;c3 parity" limits the call to some of them: all seven take about 25 minutes of box time)
+    # every shipped parity instance has a stamped record: _w1 (c2), _coop_w1 (c16, c5), _pairs (c3), _coop (box120), _pairs_m (r2048), _pairs_g (r8192),
+    # rt_trace_parity_g (nan9800) -- tests/test_abi.py holds the set to the library's build id
+    # (RT_PROF_SPECS="c2 parity;c3 parity" limits the call to some of them)
     if [ -z "${RT_PROF_SPECS:-}" ] || [ "${RT_PROF_STAGING:-0}" = "1" ]; then
         RT_STAGING_JSON=$(pwd)/$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
     fi
-    IFS=';' read -ra SPECS <<< "${RT_PROF_SPECS:-c2 parity;c2 fast;c16 parity;c3 parity;c5 parity;box120 parity;r2048 parity}"
+    IFS=';' read -ra SPECS <<< "${RT_PROF_SPECS:-c2 parity;c2 fast;c16 parity;c3 parity;c5 parity;box120 parity;r2048 parity;r8192 parity;nan9800 parity}"
     for spec in "${SPECS[@]}"; do
         set -- $spec
         bash tools/profile_gpu.sh $TAG/prof_$1_$2 $2 $1 > $O/prof_$1_$2.log 2>&1; tail -1 $O/prof_$1_$2.log
