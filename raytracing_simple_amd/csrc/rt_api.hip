@@ -391,6 +391,7 @@ RT_API int rt_reset(rt_ctx *c) {
     rc = wait_all(c);
     if (rc != RT_OK) return rc;
     c->current_sample = 0;
+    if (c->scene_launches > 0) c->scene_frames += 1;       // (a frame of the current scene has been rendered: rt_launch.hip launch_small)
     c->launches = 0;
     c->last_ms = 0.0;
     c->seeds_default = false;
@@ -409,6 +410,7 @@ RT_API int rt_reset_async(rt_ctx *c, void *hip_stream) {
     HIP_TRY(hipGetLastError());
     c->seeds_default = true;            // the next launch reads d_seeds0
     c->current_sample = 0;
+    if (c->scene_launches > 0) c->scene_frames += 1;       // (a frame of the current scene has been rendered: rt_launch.hip launch_small)
     c->launches = 0;
     c->last_ms = 0.0;
     return RT_OK;

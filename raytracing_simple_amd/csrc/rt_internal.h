@@ -74,6 +74,8 @@ struct rt_ctx {
     int coop_pick = 0;                  // 0 = not decided yet, 1 = cooperative any-hit, 2 = plain
     bool probing_coop = false;          // the probe launches in flight time coop against plain (not hierarchy against sweep)
     bool last_coop = false;             // the last launch was a cooperative any-hit instance (what a multi-device context's other shards follow)
+    uint32_t scene_frames = 0;          // resets since rt_set_scene that followed at least one launch OF THAT SCENE: frames of it already rendered
+    uint64_t scene_launches = 0;        // launches since rt_set_scene
     int coop_probe = 1;                 // diagnostics knob: 0 = the threshold alone decides (round 5's behaviour)
     uint32_t probe_tree = 0, probe_always = 0;   // the tree the verdict was measured on
     int probe_updates = 0;              // device-resident updates since the verdict (it is measured again after 256)

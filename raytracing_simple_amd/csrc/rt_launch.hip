@@ -271,6 +271,7 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
         return fail(RT_ERR_HIP, "kernel launch failed: %s (%s, grid %ux%u, lds %zu B)", hipGetErrorString(e), inst->name, grid.x, grid.y, lds_use);
     c->current_sample += n_samples;
     c->launches += 1;
+    c->scene_launches += 1;
     c->last_kernel = inst->name;
     c->last_coop = inst->role == rt::kRoleCoop || inst->role == rt::kRolePersistCoop;
     c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal || inst->tables == rt::kTabPairsLdsSlotsGlobal ||
@@ -339,6 +340,8 @@ static int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
 }
 
 void rearm_probe(rt_ctx *c) {
+    c->scene_frames = 0;
+    c->scene_launches = 0;
     c->coop_pick = 0;
     c->probing_coop = false;
     c->bvh_pick = 0;
@@ -419,6 +422,11 @@ static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_b
     if (c->coop_pick != 0) return launch_priced(c, n_samples, stream, c->coop_pick == 1 ? 3 : 4);
     if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 4);     // probes in flight: what the threshold says meanwhile
     if (may_block && n_samples >= 16) {
+        // A long blocking call would have to be SPLIT for the measurement -- four short launches in natural tile order, one arm of them the
+        // slower one: +8 % on the Demo scene's 64-pass frame (profiles/r06_coop_probe_first_frame.jsonl).  A host that renders one frame per
+        // scene (rt_render with a new scene per call) must not pay that for a verdict it never uses: the scene's FIRST frame is rendered whole,
+        // by the threshold's pick; the split happens in the second frame (after a reset), once, for hosts that come back to the scene.
+        if (c->scene_frames == 0 && c->probe_state == 0) return launch_priced(c, n_samples, stream, 2);
         const int timed = n_samples >= 32 ? 4 : 2;
         int done = 0;
         while (c->probe_state < kProbeSteps) {
@@ -430,7 +438,7 @@ static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_b
         probe_poll(c, true);
         return launch_priced(c, n_samples - done, stream, c->coop_pick == 1 ? 3 : 4);
     }
-    return launch_probe(c, n_samples, stream);
+    return launch_probe(c, n_samples, stream);          // (a short launch IS a probe: the host's own passes, nothing added)
 }
 
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {

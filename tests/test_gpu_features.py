@@ -296,8 +296,9 @@ def test_a_first_long_frame_prices_its_tiles_with_four_of_its_own_passes():
 def test_small_scenes_measure_cooperative_any_hit_against_plain_on_their_first_launches():
     """Scenes of 4 to 11 spheres (no hierarchy, below the cooperative instances' threshold): the first four launches time the sweep WITH the
     wave-ballot any-hit sharing and WITHOUT it (rt_launch.hip launch_small: coop warm, coop timed, plain warm, plain timed -- passes of the frame
-    like any other) and the faster instance renders the rest.  A blocking frame holds all four; frames, colour plane, seeds and counters are the
-    oracle's whatever is picked and however the passes are split; a threshold set by hand switches the measurement off."""
+    like any other) and the faster instance renders the rest.  Short launches are the probes themselves; a long blocking frame is split for them
+    only from the scene's SECOND frame on; frames, colour plane, seeds and counters are the oracle's whatever is picked and however the passes
+    are split; a threshold set by hand switches the measurement off."""
     w, h = 200, 120
     for maker in (lambda: (host.demo_scene(), host.DEMO_ORIG, host.DEMO_TARGET), lambda: scenes.demo_plus(10)):
         sph, orig, target = maker()
@@ -306,7 +307,11 @@ def test_small_scenes_measure_cooperative_any_hit_against_plain_on_their_first_l
         with api.RtContext(w, h) as ctx:
             ctx.set_scene(sph); ctx.set_camera(cam)
             _assert_same(_state(ctx, ctx.render_pass(40)), want)
-            assert ctx.stats()["launches"] == 5                                  # 1 + 4 + 1 + 4 passes of probes, then the other 30 (the probes left tile costs: no pricing launch)
+            # the scene's FIRST long frame is rendered whole by the threshold's pick (pricing launch + the rest): a host that renders one frame per scene pays nothing
+            assert ctx.stats()["launches"] == 2 and ctx.last_kernel == "rt_trace_parity_w1"
+            ctx.reset()
+            _assert_same(_state(ctx, ctx.render_pass(40)), want)
+            assert ctx.stats()["launches"] == 5                                  # the second frame holds the measurement: 1 + 4 + 1 + 4 passes of probes, then the other 30
             picked = ctx.last_kernel
             assert picked in ("rt_trace_parity_w1", "rt_trace_parity_coop_w1")
             ctx.reset()
@@ -315,13 +320,15 @@ def test_small_scenes_measure_cooperative_any_hit_against_plain_on_their_first_l
             ctx.update_spheres(1, api.as_spheres(sph)[1:2])                      # a device-resident update keeps the verdict (the sphere count cannot change)
             ctx.reset(); ctx.render_pass(40)
             assert ctx.stats()["launches"] == 1 and ctx.last_kernel == picked
-            ctx.set_scene(sph[:5])                                               # another scene: measured again, here through queued one-pass launches
+            fewer = np.concatenate([api.as_spheres(sph)[:4], api.as_spheres(sph)[5:]])          # (one sphere less; the light stays)
+            ctx.set_scene(fewer)                                                 # another scene: measured again, here through queued one-pass launches
+            ctx.reset()
             names = []
             for _ in range(6):
                 ctx.render_async(1)
                 names.append(ctx.last_kernel)
             assert names[:4] == ["rt_trace_parity_coop_w1", "rt_trace_parity_coop_w1", "rt_trace_parity_w1", "rt_trace_parity_w1"]
-            assert np.array_equal(ctx.read_pixels(), O.render(sph[:5], cam, w, h, 6)["pixels"])
+            assert np.array_equal(ctx.read_pixels(), O.render(fewer, cam, w, h, 6)["pixels"])
         with api.RtContext(w, h, diag=True) as ctx:                               # a threshold set by hand decides alone
             ctx._check(ctx._lib.rt_debug_set_coop_min(ctx._h, 12))
             ctx.set_scene(sph); ctx.set_camera(cam)
