@@ -309,8 +309,11 @@ void probe_poll(rt_ctx *c, bool wait) {
         return;
     }
     const double ta = (double)a / c->probe_samples[0], tb = (double)b / c->probe_samples[1];
-    if (c->probing_coop) {                      // (arm 0 = cooperative any-hit, arm 1 = plain; the plain instance keeps a tie: it is what the threshold says)
-        c->coop_pick = ta < 0.98 * tb ? 1 : 2;
+    if (c->probing_coop) {
+        // arm 0 = cooperative any-hit, arm 1 = plain.  The plain instance -- what the threshold says -- keeps anything inside 4 %: the scenes the
+        // sharing is for gain 7-14 %, the Demo scene loses 2-10 %, and a timed probe of a 1/8 shard of a 1080p frame lasts 65 microseconds (two of the
+        // eight shards of profiles/r06_shard_prediction.jsonl's first run picked the slower form on a 2 % dead band)
+        c->coop_pick = ta < 0.96 * tb ? 1 : 2;
         return;
     }
     c->probe_ms[0] = ta;
@@ -408,7 +411,7 @@ double estimate_ratio(const rt_ctx *c) {
 
 // Cooperative any-hit or not for a scene of fewer than coop_min spheres (rt_internal.h coop_pick): the four launches of the hierarchy's probe --
 // coop warm, coop timed, plain warm, plain timed; passes of the frame like any other, natural tile order -- and the faster one renders the rest.
-// A blocking call of 32 passes or more times 4 passes per arm (2 from 16): a pass of a six-sphere scene at 800x600 lasts 20 microseconds.
+// A blocking call times 8 passes per arm from 64 passes on, 4 from 32, 2 from 16.
 constexpr uint32_t kCoopProbeFrom = 4;          // (below four spheres a shadow sweep has nothing to share out)
 static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
     if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
@@ -427,7 +430,7 @@ static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_b
         // scene (rt_render with a new scene per call) must not pay that for a verdict it never uses: the scene's FIRST frame is rendered whole,
         // by the threshold's pick; the split happens in the second frame (after a reset), once, for hosts that come back to the scene.
         if (c->scene_frames == 0 && c->probe_state == 0) return launch_priced(c, n_samples, stream, 2);
-        const int timed = n_samples >= 32 ? 4 : 2;
+        const int timed = n_samples >= 64 ? 8 : (n_samples >= 32 ? 4 : 2);      // (long enough to time: a pass of a six-sphere scene at 800x600 lasts 20 microseconds)
         int done = 0;
         while (c->probe_state < kProbeSteps) {
             const int k = (c->probe_state & 1) ? timed : 1;

@@ -63,6 +63,31 @@ def test_shipped_kernels_have_no_private_segment_and_fit_their_occupancy():
         assert m["vgpr_count"] <= (96 if "_pairs" in name else 80), (name, m["vgpr_count"])
 
 
+def test_every_shipped_parity_instance_has_a_profile_of_this_library():
+    """"every shipped parity instance has a stamped profile"  -- held here: the kernels that ship are read
+    from the product library's code objects, and each parity instance (and the fast-mode headline instance) must have a profiles/*.json whose `kernel`
+    is its symbol and whose `build_id` is the id of the sources this library is built from (tools/profile_gpu.sh + tools/collect.py write them)."""
+    import glob
+    import json
+    from raytracing_simple_amd import _build
+    lib_id = _build.source_hash()
+    have = {}
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*.json")):
+        try:
+            d = json.load(open(f))
+        except ValueError:
+            continue
+        if isinstance(d, dict) and isinstance(d.get("kernel"), str) and d.get("build_id"):
+            have.setdefault(d["kernel"], {})[d["build_id"]] = os.path.basename(f)
+    shipped = sorted(k for k in _build.kernel_metadata() if k.startswith("rt_trace_parity"))
+    assert shipped == sorted(SHIPPED_PARITY)
+    missing = [k for k in shipped + ["rt_trace_fast_w1"] if lib_id not in have.get(k, {})]
+    assert not missing, "no profile of library %s for: %s (run tools/session.sh P through gpurun, then tools/collect.py)" % (lib_id, missing)
+    for k in shipped:                       # ... and the record is a real one: launches, counters
+        d = json.load(open(os.path.join(ROOT, "profiles", have[k][lib_id])))
+        assert d.get("timed_launches", 0) >= 5 and d["pmc_per_launch_avg"].get("SQ_INSTS_VALU", 0) > 0 and "launch" in d, have[k][lib_id]
+
+
 def test_no_built_binaries_are_tracked():
     """Built artefacts stay out of history (.gitignore policy): no ELF file in the index."""
     files = subprocess.run(["git", "ls-files"], cwd=ROOT, capture_output=True, text=True)
