@@ -537,12 +537,13 @@ def main():
                 c.set_camera(camera)
                 c.set_mode(mode)
                 self.ctxs.append(c)
-            # scenes large enough for a hierarchy: the library measures hierarchy against sweep on a new scene's first launches
-            # (four of them; a blocking call of 16 passes or more holds them all) -- one untimed blocking frame per context settles
-            # that before any timed region, whatever --warmup says
+            # The library measures per scene what it cannot know: hierarchy against sweep on a large scene's first launches (a blocking call of
+            # 16 passes or more holds them all), cooperative any-hit against plain on a scene of 4-11 spheres' second and third whole frames
+            # (rt_launch.hip launch_small).  Four untimed blocking frames per context settle both before any timed region, whatever --warmup says
             for c in self.ctxs:
-                c.reset_async()
-                c.render_pass(max(spp, 16), copy=False)
+                for _ in range(4):
+                    c.reset_async()
+                    c.render_pass(max(spp, 16), copy=False)
             self.streams = [torch.cuda.ExternalStream(c.stream, device=dev) for c in self.ctxs]
             self.gather, self.want_dev, self.mismatch, self.whole_kernel_ms = None, None, None, None
             self.frame_no, self.frames_checked = 0, 0

@@ -68,7 +68,7 @@ struct rt_ctx {
     int use_estimate = 1;               // diagnostics knob: 0 = every undecided scene is measured
     double est_ratio = 0.0;             // the estimate's predicted walk / sweep time (0 = none made)
     int probe_state = 0;                // probe launches issued (0..4)
-    // ... and for a scene WITHOUT a hierarchy and fewer spheres than coop_min: cooperative any-hit or not, by the same four launches (rt_launch.hip).
+    // ... and for a scene WITHOUT a hierarchy and fewer spheres than coop_min: cooperative any-hit or not, timed on the host's own launches (rt_launch.hip launch_small).
     // Below 12 spheres the threshold alone picks wrongly either way -- the Demo scene is 2 % faster without the sharing, the reference's simple.scn,
     // caustic.scn and caustic3.scn (6 and 10 records) 7-11 % faster with it (profiles/r06_reference_scenes.jsonl) -- so it is measured.
     int coop_pick = 0;                  // 0 = not decided yet, 1 = cooperative any-hit, 2 = plain
@@ -76,6 +76,7 @@ struct rt_ctx {
     bool last_coop = false;             // the last launch was a cooperative any-hit instance (what a multi-device context's other shards follow)
     uint32_t scene_frames = 0;          // resets since rt_set_scene that followed at least one launch OF THAT SCENE: frames of it already rendered
     uint64_t scene_launches = 0;        // launches since rt_set_scene
+    int probe_acc = 0;                  // passes launched so far inside the timed step of the coop / plain measurement that is open
     int coop_probe = 1;                 // diagnostics knob: 0 = the threshold alone decides (round 5's behaviour)
     uint32_t probe_tree = 0, probe_always = 0;   // the tree the verdict was measured on
     int probe_updates = 0;              // device-resident updates since the verdict (it is measured again after 256)

@@ -345,6 +345,7 @@ static int launch_probe(rt_ctx *c, int n_samples, hipStream_t stream) {
 void rearm_probe(rt_ctx *c) {
     c->scene_frames = 0;
     c->scene_launches = 0;
+    c->probe_acc = 0;
     c->coop_pick = 0;
     c->probing_coop = false;
     c->bvh_pick = 0;
@@ -409,10 +410,18 @@ double estimate_ratio(const rt_ctx *c) {
     return (kEstPair * c->bvh_est_pairs + kEstAlways * (double)c->bvh.n_always) / ((double)c->scene.n_spheres + kEstSweepFixed);
 }
 
-// Cooperative any-hit or not for a scene of fewer than coop_min spheres (rt_internal.h coop_pick): the four launches of the hierarchy's probe --
-// coop warm, coop timed, plain warm, plain timed; passes of the frame like any other, natural tile order -- and the faster one renders the rest.
-// A blocking call times 8 passes per arm from 64 passes on, 4 from 32, 2 from 16.
+// Cooperative any-hit or not for a scene of fewer than coop_min spheres (rt_internal.h coop_pick): MEASURED, on the host's own launches as they
+// come -- never split, never reordered, scheduled like any other (heavy tiles first): the sharing's worth depends on the order the tiles run in, so
+// it is timed under the order the frames will run in.  Four steps: coop warm, coop timed, plain warm, plain timed; a step takes whole launches and
+// ends once it holds enough passes -- a warm step one launch, a timed step 16 passes between its two events; a launch of 16 passes or more needs no
+// warm step (it warms itself), so a host that renders whole frames spends its second frame on the cooperative instance, its third on the plain
+// one, and has the verdict for the fourth; a host that queues a pass per call has it after 34 passes.  A scene's FIRST long blocking frame is not
+// part of it (a new scene's first frame prices its tiles and runs partly in image order: it measures neither form's steady state), so a host that
+// renders one frame per scene never runs the form the threshold would not have picked.  (The first version of this round split a long call into
+// four short probe launches in natural tile order, as the hierarchy's probe does: +6 ... +8 % on that frame, and on shards of a frame, 65
+// microseconds per timed probe, it picked the slower form on two shards of eight -- profiles/r06_coop_probe_first_frame.jsonl.)
 constexpr uint32_t kCoopProbeFrom = 4;          // (below four spheres a shadow sweep has nothing to share out)
+constexpr int kCoopTimedPasses = 16;
 static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
     if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
         return launch_priced(c, n_samples, stream, c->choice_leader->last_coop ? 3 : 4);
@@ -423,25 +432,29 @@ static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_b
     c->probing_coop = true;
     probe_poll(c, false);
     if (c->coop_pick != 0) return launch_priced(c, n_samples, stream, c->coop_pick == 1 ? 3 : 4);
-    if (c->probe_state == kProbeSteps) return launch_form(c, n_samples, stream, 4);     // probes in flight: what the threshold says meanwhile
-    if (may_block && n_samples >= 16) {
-        // A long blocking call would have to be SPLIT for the measurement -- four short launches in natural tile order, one arm of them the
-        // slower one: +8 % on the Demo scene's 64-pass frame (profiles/r06_coop_probe_first_frame.jsonl).  A host that renders one frame per
-        // scene (rt_render with a new scene per call) must not pay that for a verdict it never uses: the scene's FIRST frame is rendered whole,
-        // by the threshold's pick; the split happens in the second frame (after a reset), once, for hosts that come back to the scene.
-        if (c->scene_frames == 0 && c->probe_state == 0) return launch_priced(c, n_samples, stream, 2);
-        const int timed = n_samples >= 64 ? 8 : (n_samples >= 32 ? 4 : 2);      // (long enough to time: a pass of a six-sphere scene at 800x600 lasts 20 microseconds)
-        int done = 0;
-        while (c->probe_state < kProbeSteps) {
-            const int k = (c->probe_state & 1) ? timed : 1;
-            const int rc = launch_probe(c, k, stream);
-            if (rc != RT_OK) return rc;
-            done += k;
-        }
-        probe_poll(c, true);
-        return launch_priced(c, n_samples - done, stream, c->coop_pick == 1 ? 3 : 4);
+    if (c->probe_state == kProbeSteps) return launch_priced(c, n_samples, stream, 4);   // both timings queued, not back yet: what the threshold says meanwhile
+    const bool whole_frame = may_block && n_samples >= kCoopTimedPasses;
+    if (whole_frame && c->scene_frames == 0 && c->probe_state == 0) return launch_priced(c, n_samples, stream, 2);
+    if (whole_frame && (c->probe_state & 1) == 0) c->probe_state += 1;                  // (a long launch warms itself)
+    const int k = c->probe_state, arm = k >> 1;
+    const bool timed = (k & 1) != 0;
+    int rc = chain(c, stream);
+    if (rc != RT_OK) return rc;
+    if (timed && c->probe_acc == 0) HIP_TRY(hipEventRecord(c->probe_ev[2 * arm], stream));
+    rc = launch_priced(c, n_samples, stream, arm == 0 ? 3 : 4);
+    if (rc != RT_OK) return rc;
+    if (!timed) {
+        c->probe_state = k + 1;
+        return RT_OK;
     }
-    return launch_probe(c, n_samples, stream);          // (a short launch IS a probe: the host's own passes, nothing added)
+    c->probe_acc += n_samples;
+    if (c->probe_acc >= kCoopTimedPasses) {
+        HIP_TRY(hipEventRecord(c->probe_ev[2 * arm + 1], stream));
+        c->probe_samples[arm] = c->probe_acc;
+        c->probe_acc = 0;
+        c->probe_state = k + 1;
+    }
+    return RT_OK;
 }
 
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {

@@ -52,7 +52,7 @@ def load_scene(name):
     return sph, tuple(float(v) for v in cam[0:3]), tuple(float(v) for v in cam[3:6])
 
 
-def steady(ctx, spp, frames=5, warm=2):
+def steady(ctx, spp, frames=5, warm=3):
     ms = []
     for k in range(warm + frames):
         ctx.reset()
@@ -91,8 +91,9 @@ def alternatives(api, sph, cam, picked_kernel, base_ms):
                 ("hierarchy read from HBM / L2 (rt_trace_parity_pairs_g)", dict(bvh=(56, 1024), walk=1))]
     else:
         coop = "_coop" in picked_kernel
-        arms = [("cooperative any-hit %s" % ("off" if coop else "on"), dict(coop_min=(0 if coop else 1))),
-                ("4-wavefront workgroups" if "_w1" in picked_kernel else "1-wavefront workgroups", dict(wg=(4 if "_w1" in picked_kernel else 1)))]
+        arms = [("the library's pick, forced the same way (cooperative any-hit %s)" % ("on" if coop else "off"), dict(coop_min=(1 if coop else 0))),
+                ("cooperative any-hit %s" % ("off" if coop else "on"), dict(coop_min=(0 if coop else 1))),
+                ("4-wavefront workgroups" if "_w1" in picked_kernel else "1-wavefront workgroups", dict(wg=(4 if "_w1" in picked_kernel else 1), coop_min=(1 if coop else 0)))]
         if len(sph) >= 56:
             arms.append(("hierarchy forced", dict(walk=1)))
     want = None
@@ -113,7 +114,9 @@ def alternatives(api, sph, cam, picked_kernel, base_ms):
                 c.set_scene(sph); c.set_camera(cam)
                 c.reset()
                 px = c.render_pass(SPP)
-                ms = steady(c, SPP, frames=3, warm=1)
+                ms = steady(c, SPP, frames=5, warm=2)
+                if label.startswith("the library's pick"):
+                    base_ms = ms            # (the alternatives are compared with the pick measured the same way, in the same process)
                 out.append({"form": label, "kernel": c.last_kernel, "kernel_ms": round(ms, 4), "vs_pick": round(ms / base_ms, 3),
                             "same_frame": bool(np.array_equal(px, want))})
         except api.RtError as e:

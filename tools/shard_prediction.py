@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 TILE_ROWS = 8
+WARM = 4                              # untimed frames per context: a scene of 4-11 spheres has its instance measured on frames 2 and 3 (rt_launch.hip launch_small)
 XGMI_LINK_GBS = 153.0                 # MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, point to point
 
 
@@ -60,10 +61,10 @@ def predict(api, mode, spheres, cam, w, h, spp, nranks=(2, 4, 8), frames=3, devi
         with api.RtContext(w, h, device=device) as c:
             c.set_scene(spheres); c.set_camera(cam); c.set_mode(mode)
             ms = []
-            for k in range(2 + frames):
+            for k in range(WARM + frames):
                 c.reset()
                 px = c.render_pass(spp)
-                if k >= 2:
+                if k >= WARM:
                     ms.append(c.stats()["last_kernel_ms"])
             whole_ms, whole_pixels = statistics.median(ms), px
     whole = np.asarray(whole_pixels, np.uint32).reshape(h, w)
@@ -74,10 +75,10 @@ def predict(api, mode, spheres, cam, w, h, spp, nranks=(2, 4, 8), frames=3, devi
             with api.RtContext(w, h, device=device, rank=r, nranks=n, tile_rows=TILE_ROWS) as c:
                 c.set_scene(spheres); c.set_camera(cam); c.set_mode(mode)
                 ms = []
-                for k in range(2 + frames):         # two untimed frames: tile costs, then the heavy-first order, as in the timed regions of bench.py
+                for k in range(WARM + frames):      # untimed frames first: tile costs, the heavy-first order, the library's own choice of instance (bench.py does the same)
                     c.reset()
                     px = c.render_pass(spp)
-                    if k >= 2:
+                    if k >= WARM:
                         ms.append(c.stats()["last_kernel_ms"])
                 rows = c.local_row_map()
                 equal = equal and bool(np.array_equal(px.reshape(-1, w)[: len(rows)], whole[rows]))
