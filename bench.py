@@ -870,13 +870,14 @@ def main():
     # every shard of a 2 / 4 / 8-way split rendered ALONE on this GPU (tools/shard_prediction.py): what each GPU of an N-GPU run
     # would spend on the frame, imbalance and under-filled GPU included -- for this line's workload and for C4
     shards = None
-    if world == 1 and not args.no_extras:
+    if not args.no_extras:              # (at N > 1 too: rank 0's GPU, alone by now -- the prediction stands beside the measurement it predicts)
         try:
             from tools import shard_prediction
-            shards = {args.workload: shard_prediction.predict(api, mode, spheres, cam, W, H, SPP, whole_ms=kernel_ms, whole_pixels=last_pixels, bound=bound)}
+            shards = {args.workload: shard_prediction.predict(api, mode, spheres, cam, W, H, SPP, whole_ms=kernel_ms if world == 1 else None,
+                                                              whole_pixels=last_pixels, bound=bound, device=local_rank)}
             if args.workload == "c2":
                 cam4 = host.compute_camera(host.DEMO_ORIG, host.DEMO_TARGET, 3840, 2160)
-                shards["c4"] = shard_prediction.predict(api, mode, host.demo_scene(), cam4, 3840, 2160, 256, frames=2)
+                shards["c4"] = shard_prediction.predict(api, mode, host.demo_scene(), cam4, 3840, 2160, 256, frames=2, device=local_rank)
             shards["what"] = ("per N: each shard of the interleaved 8-row-tile split rendered alone on this GPU, steady state (kernel ms from the context's events); "
                               "predicted_ms_per_frame = slowest shard + measured de-interleave kernel + all packed pixels over one 153 GB/s xGMI link")
         except Exception as e:       # noqa: BLE001 -- a diagnostics figure never takes the headline down
