@@ -351,6 +351,7 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     if (count) memcpy(c->h_spheres.data() + first, spheres, (size_t)count * sizeof(rt_sphere));
     // the last frame's costs still predict this one (moving spheres): the order stays in use and the next long launch sorts it again from them
     c->order_stale = true;
+    if (c->cost_window) c->cost_passes = 0;         // (a window of short launches' costs starts again from the changed scene)
     rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream, false);
     if (rc == RT_OK) rearm_probe_if_changed(c);
     return rc;
@@ -361,6 +362,7 @@ RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {
     if (c->multi) return rt::multi_set_camera(c, cam);
     if (!c->have_cam || memcmp(&c->cam, cam, sizeof *cam) != 0) {
         c->order_stale = true;             // a moved camera: the order stays in use, the next long launch sorts it again from the last frame's costs
+        if (c->cost_window) c->cost_passes = 0;     // (... or the next window of short launches, which starts again)
     }
     c->cam = *cam;                      // a kernel argument: nothing to upload
     c->have_cam = true;

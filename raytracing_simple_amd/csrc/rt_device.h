@@ -106,7 +106,8 @@ struct LaunchParams {
     int regen_gate;         // lanes that must be waiting before finished lanes start new paths (1 = free-running)
     int coop_kmax;          // cooperative any-hit: with more pending shadow rays than this in the wavefront the lanes sweep for themselves (0 = no limit)
     float inv_w, inv_h;     // 1.f / w, 1.f / h (.cl:503-504), divided once on the host: kernel arguments live in SGPRs
-    int skip_pixels;        // this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0))
+    int skip_pixels;        // launch flags.  bit 0: this launch leaves the packed pixels alone (rt_set_pixel_write(ctx, 0)); bit 1: it ADDS its per-tile costs
+                            // to the ones in `tile_cost` instead of replacing them (a short launch inside an accumulation window, rt_launch.hip)
     const uint32_t *order;  // heavy-first walk of the 32x8 tiles (tile id = by * gridDim.x + bx), or null = natural order
     uint32_t *tile_cost;    // per tile: wall-clock ticks (10 ns) of its slowest wavefront, written by every launch (or null)
     // diagnostics build only (null in the product library): launch sequence number and the buffers the

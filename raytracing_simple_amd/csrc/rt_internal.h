@@ -92,6 +92,8 @@ struct rt_ctx {
     uint32_t cost_tiles = 0;            // tile count of the launch the costs come from
     int wg_waves = 0;                   // diagnostics knob: 0 = automatic, 1 / 4 = force the workgroup shape
     bool cost_valid = false, order_valid = false;
+    uint32_t cost_passes = 0;           // passes behind the costs now in d_tile_cost
+    bool cost_window = false;           // ... which come from a window of SHORT launches (fewer than 8 passes each) adding up, not from one long launch
     bool order_stale = false;           // scene or camera have changed since the order was sorted: it stays in use until a long launch sorts it again
     int use_order = 1;
     rt_sphere *h_stage = nullptr;       // page-locked staging ring for sphere uploads

@@ -232,20 +232,37 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
 
     const int tile_w = 8 * inst->waves * ((inst->flags & rt::kInstTwoRays) ? 2 : 1);
     dim3 grid((unsigned)((c->w + tile_w - 1) / tile_w), (unsigned)((c->local_rows + rt::kTileH - 1) / rt::kTileH));
-    // heavy tiles first: every launch leaves per-tile costs; once a long launch has, the next long launch of the
-    // same scene, camera and tile shape walks the tiles in descending order of cost (sorted on the device, once)
+    // heavy tiles first: launches leave per-tile costs, and a launch of the same scene, camera and tile shape walks the tiles in descending order of
+    // cost (sorted on the device, once per change of scene or camera).  A LONG launch (8 passes and more) replaces the costs with its own and sorts
+    // from the last long launch's.  SHORT launches -- the reference's own regime is a pass per call, the adapter's display loop about a millisecond's
+    // worth -- used to get nothing of this: no costs from fewer than 4 passes, no sort below 8.  Yet once the order exists it is worth as much to them
+    // (complex.scn 12 %, C3 8-13 %, 8192 spheres 12-22 % on launches of 1 / 2 / 4 passes: profiles/r06_order_short_launches.jsonl).  So while the order is
+    // missing or stale, short launches ADD their costs up in a window (launch flag bit 1: the kernel's epilogue adds instead of stores), and the short
+    // launch that finds 16 passes' worth there sorts from them; with a valid order short launches do not touch the costs at all.
+    constexpr int kLongLaunch = 8, kShortWindow = 16;
     const uint32_t n_tiles = grid.x * grid.y;
     const bool instance_logs_cost = (inst->flags & rt::kInstNoTileCost) == 0;
+    const bool short_launch = n_samples < kLongLaunch;
+    bool accumulate = false;
     if (c->use_order && c->d_tile_cost && n_tiles <= c->n_tiles && instance_logs_cost) {
-        if (c->cost_tiles != n_tiles) c->cost_valid = c->order_valid = false;      // another tile shape: start over
-        p.tile_cost = c->d_tile_cost;
-        if (c->cost_valid && (!c->order_valid || c->order_stale) && n_samples >= 8 && !natural_order) {
+        if (c->cost_tiles != n_tiles) {                                            // another tile shape: start over
+            c->cost_valid = c->order_valid = false;
+            c->cost_passes = 0;
+        }
+        const bool order_wanted = !c->order_valid || c->order_stale;
+        if (c->cost_valid && order_wanted && !natural_order && (!short_launch || (c->cost_window && c->cost_passes >= (uint32_t)kShortWindow))) {
             hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
             c->order_stale = false;
+            if (short_launch) c->cost_passes = 0;                                   // (the window's costs are spent)
         }
         if (c->order_valid && !natural_order) p.order = c->d_order;
+        if (!short_launch || !c->order_valid || c->order_stale) {                   // (a short launch under a valid order leaves the costs alone)
+            p.tile_cost = c->d_tile_cost;
+            accumulate = short_launch && c->cost_window && c->cost_passes > 0;
+            if (accumulate) p.skip_pixels |= 2;
+        }
     }
     if (persist) {
         // just enough workgroups to fill the machine; the tile queue (counters[30]) does the rest
@@ -276,8 +293,17 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
     c->last_coop = inst->role == rt::kRoleCoop || inst->role == rt::kRolePersistCoop;
     c->last_form = (inst->tables == rt::kTabPairsLds || inst->tables == rt::kTabPairsGlobal || inst->tables == rt::kTabPairsLdsSlotsGlobal ||
                     inst->tables == rt::kTabPairsTopLds || inst->tables == rt::kTabPairsPacked) ? 1 : 2;
-    if (p.tile_cost && n_samples >= 4) {
-        c->cost_valid = true;
+    if (p.tile_cost) {
+        if (!short_launch) {
+            c->cost_window = false;
+            c->cost_passes = (uint32_t)n_samples;
+        } else if (accumulate) {
+            c->cost_passes += (uint32_t)n_samples;
+        } else {                                    // a short launch has replaced the costs with its own: a new window
+            c->cost_window = true;
+            c->cost_passes = (uint32_t)n_samples;
+        }
+        c->cost_valid = c->cost_passes >= 4;        // (fewer than four passes' worth orders nothing)
         c->cost_tiles = n_tiles;
     }
     c->seeds_default = false;           // this launch has written every seed pair the context renders

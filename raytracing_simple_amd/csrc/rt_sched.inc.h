@@ -347,7 +347,7 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads, RT_OPT_MINWAVES)
         P.colors[3 * ci] = acc.x;
         P.colors[3 * ci + 1] = acc.y;
         P.colors[3 * ci + 2] = acc.z;
-        if (!P.skip_pixels)
+        if (!(P.skip_pixels & 1))
             P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         P.seeds[2 * gid] = s0;

@@ -678,7 +678,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                     P.colors[3 * ci] = acc.x;
                     P.colors[3 * ci + 1] = acc.y;
                     P.colors[3 * ci + 2] = acc.z;
-                    if (!P.skip_pixels)
+                    if (!(P.skip_pixels & 1))
                         P.pixels[(size_t)lrow * (size_t)P.w + (size_t)x] =
                             (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
                     P.seeds[2 * gid] = s0;
@@ -1014,7 +1014,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         colors[3 * ci] = acc.x;
         colors[3 * ci + 1] = acc.y;
         colors[3 * ci + 2] = acc.z;
-        if (!Q.skip_pixels)                                                // (wave-uniform)
+        if (!(Q.skip_pixels & 1))                                          // (wave-uniform)
             Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =               // .cl:594-596
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);   // .cl:598-599
@@ -1054,7 +1054,9 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     }
     __syncthreads();
 #if !RT_OPT_PERSIST
-    if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
+    // (bit 1 of the launch flags: a SHORT launch inside an accumulation window -- its cost is added to what the window's launches before it left,
+    // so that a host which only ever launches a pass or two at a time gets its tiles ordered from 16 passes' worth of costs: rt_launch.hip)
+    if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = (Q.skip_pixels & 2) ? Q.tile_cost[tile_id] + s_tile_cost : s_tile_cost;
 #endif
     if (tid < 5) {
 #if RT_OPT_PERSIST

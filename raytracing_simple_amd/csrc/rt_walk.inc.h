@@ -966,7 +966,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         colors[3 * ci] = acc.x;
         colors[3 * ci + 1] = acc.y;
         colors[3 * ci + 2] = acc.z;
-        if (!Q.skip_pixels)
+        if (!(Q.skip_pixels & 1))
             Q.pixels[(size_t)le * (size_t)Q.w + (size_t)xe] =
                 (uint32_t)(to_int(acc.x) | (to_int(acc.y) << 8) | (to_int(acc.z) << 16));
         *reinterpret_cast<uint2 *>(Q.seeds + 2 * gid) = make_uint2(s0, s1);
@@ -994,7 +994,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         atomicAdd(&s_stat[4], (unsigned long long)t_draws);
     }
     __syncthreads();
-    if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = s_tile_cost;
+    if (tid == 5 && Q.tile_cost) Q.tile_cost[tile_id] = (Q.skip_pixels & 2) ? Q.tile_cost[tile_id] + s_tile_cost : s_tile_cost;       // (as in rt_trace.inc.h)
     if (tid < 5) atomicAdd(&Q.stats[(block_linear % (unsigned)kStatReplicas) * 8u + (unsigned)tid], s_stat[tid]);
 }
 
