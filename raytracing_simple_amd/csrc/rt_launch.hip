@@ -250,12 +250,13 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
             c->cost_passes = 0;
         }
         const bool order_wanted = !c->order_valid || c->order_stale;
-        if (c->cost_valid && order_wanted && !natural_order && (!short_launch || (c->cost_window && c->cost_passes >= (uint32_t)kShortWindow))) {
+        // (a short launch sorts from a long launch's costs whenever the order is stale -- they still predict the next frame -- and from a window's once it is full)
+        if (c->cost_valid && order_wanted && !natural_order && (!short_launch || !c->cost_window || c->cost_passes >= (uint32_t)kShortWindow)) {
             hipLaunchKernelGGL(rt_order_tiles_kernel, dim3(1), dim3(1024), 0, stream, c->d_tile_cost, c->d_order, n_tiles);
             HIP_TRY(hipGetLastError());
             c->order_valid = true;
             c->order_stale = false;
-            if (short_launch) c->cost_passes = 0;                                   // (the window's costs are spent)
+            if (short_launch && c->cost_window) c->cost_passes = 0;                 // (the window's costs are spent)
         }
         if (c->order_valid && !natural_order) p.order = c->d_order;
         if (!short_launch || !c->order_valid || c->order_stale) {                   // (a short launch under a valid order leaves the costs alone)

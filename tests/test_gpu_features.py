@@ -337,6 +337,52 @@ def test_small_scenes_measure_cooperative_any_hit_against_plain_on_their_own_lau
                 assert ctx.last_kernel == "rt_trace_parity_w1"
 
 
+def test_short_launches_build_their_own_tile_order_from_a_window_of_costs():
+    """The reference's regime is a pass per call: launches too short to price tiles one by one.  While the order is missing, short launches ADD their
+    per-tile costs up (the kernel's epilogue adds instead of stores) and the launch that finds 16 passes' worth sorts from them; from then on short
+    launches walk that order and leave the costs alone; a moved camera starts the window again.  Frames are the oracle's throughout."""
+    lib = api.load_library(diag=True)
+    w, h = 200, 120
+    sph, orig, target = scenes.demo_plus(16)
+    cam = host.compute_camera(orig, target, w, h)
+
+    def order_state(ctx):
+        n, valid = C.c_uint32(), C.c_int()
+        order, cost = np.zeros(4096, np.uint32), np.zeros(4096, np.uint32)
+        api._check(lib.rt_debug_read_tile_order(ctx._h, order.ctypes.data_as(C.c_void_p), cost.ctypes.data_as(C.c_void_p), 4096, C.byref(n), C.byref(valid)), lib)
+        return order[: n.value], cost[: n.value], bool(valid.value)
+
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx.set_scene(sph); ctx.set_camera(cam)
+        sums = []
+        for k in range(16):                                                    # 16 launches of one pass: the window fills, nothing is sorted yet
+            ctx.render_pass(1)
+            assert not order_state(ctx)[2]
+            sums.append(int(order_state(ctx)[1].astype(np.uint64).sum()))
+        assert all(b > a for a, b in zip(sums, sums[1:]))                      # the costs add up launch by launch
+        window = order_state(ctx)[1].copy()
+        ctx.render_pass(1)                                                     # the 17th finds 16 passes' worth: sorted, and walked from here on
+        order, cost, valid = order_state(ctx)
+        assert valid and sorted(order.tolist()) == list(range(len(order))) and np.array_equal(cost, window)
+        capped = np.minimum(window, 0x1FFFFF).astype(np.uint64)
+        cls = 1023 - (capped * 1023 // int(capped.max())).astype(np.int64)
+        assert np.all(np.diff(cls[order]) >= 0)                                # most expensive class first
+        for _ in range(7):
+            ctx.render_pass(1)
+        assert np.array_equal(order_state(ctx)[1], window)                     # (a valid order: short launches leave the costs alone)
+        assert np.array_equal(ctx.read_pixels(), O.render(sph, cam, w, h, 24)["pixels"])
+        cam2 = host.compute_camera((30.0, 90.0, 110.0), target, w, h)
+        ctx.set_camera(cam2)                                                   # stale: the window starts again at the new camera, the old order stays in use meanwhile
+        ctx.reset()
+        for k in range(17):
+            ctx.render_pass(1)
+            assert order_state(ctx)[2]
+            if k == 0:
+                assert int(order_state(ctx)[1].astype(np.uint64).sum()) < int(window.astype(np.uint64).sum()) // 4     # (one pass' worth: the window was restarted)
+        assert not np.array_equal(order_state(ctx)[0], order)                  # sorted again from the new window
+        assert np.array_equal(ctx.read_pixels(), O.render(sph, cam2, w, h, 17)["pixels"])
+
+
 def test_the_order_of_a_priced_first_frame_is_sorted_once_more_from_the_whole_frame():
     """The first frame's order comes from 4 passes' worth of costs; the frame itself leaves the costs of all its passes, and the second
     frame sorts from those -- once: the third frame walks the second's order.  Frames are the oracle's throughout."""
@@ -396,19 +442,23 @@ def test_heavy_first_tile_order_is_a_permutation_sorted_by_cost_and_changes_no_b
         capped = np.minimum(cost, 0x1FFFFF).astype(np.uint64)
         cls = 1023 - (capped * 1023 // int(capped.max())).astype(np.int64)                    # the kernel's cost classes
         assert np.all(np.diff(cls[order]) >= 0)                                # most expensive class first
-        # short launches neither sort nor need an order
+        # short launches under a valid order neither sort nor touch the costs
+        costs_before = order_state(ctx)[1].copy()
         ctx.reset(); ctx.render_pass(2); ctx.render_pass(6)
         _assert_same(_state(ctx, ctx.read_pixels()), want)
-        # a moved camera keeps the last frame's costs (they still predict the next frame) and sorts them again
+        assert np.array_equal(order_state(ctx)[1], costs_before)
+        # a moved camera keeps the last long frame's costs (they still predict the next frame): the order stays in use, stale, and the NEXT launch --
+        # short or long -- sorts it again from them
         cam2 = host.compute_camera((30.0, 90.0, 110.0), target, w, h)
         ctx.set_camera(cam2)
-        assert order_state(ctx)[2]                                             # stale, but still in use: short launches need no fresh one
-        ctx.reset(); ctx.render_pass(2)
         assert order_state(ctx)[2]
         stale = order_state(ctx)[0].copy()
-        ctx.reset()
-        _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))      # a long launch: sorted again from the last costs
+        ctx.reset(); ctx.render_pass(2)
         assert order_state(ctx)[2] and not np.array_equal(order_state(ctx)[0], stale)
+        fresh = order_state(ctx)[0].copy()
+        ctx.reset()
+        _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))      # (sorted already: this long launch walks that order and leaves its own costs)
+        assert order_state(ctx)[2] and np.array_equal(order_state(ctx)[0], fresh)
         ctx.set_scene(sph)                                                     # the identical scene: nothing changes
         ctx.reset()
         _assert_same(_state(ctx, ctx.render_pass(spp)), O.render(sph, cam2, w, h, spp))
