@@ -21,6 +21,8 @@ for cfg in r8192 r65536; do
     timeout -k 10 300 python tools/walk_ab.py $cfg base tail=2 tail=4 tail=8 tail=16 gate=8 gate=32 round=2 round=8 >> $O/l2_walk_knobs.jsonl 2>> $O/l2_walk_knobs.err
 done
 timeout -k 10 300 python tools/walk_ab.py r262144 base tail=4 tail=16 gate=32 round=8 >> $O/l2_walk_knobs.jsonl 2>> $O/l2_walk_knobs.err
+run order_short_launches.jsonl python tools/order_short_launches.py
+python tools/order_short_launches.py --long-first >> $O/order_short_launches.jsonl 2>> $O/order_short_launches.jsonl.err
 run lds_budget_ab.jsonl python tools/lds_budget_ab.py --sizes 1200,1600,2048,2400,3000 --scn complex
 : > $O/coop_threshold_ab.jsonl
 for cm in 0 1; do
