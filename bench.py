@@ -6,13 +6,19 @@ per pixel (= 64 passes of the reference's Config::updateRendering()), from the d
 stream, rendered by the HIP path through the C ABI.  Inputs (seeds, scene tables, camera) are
 resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode parity|fast] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode parity|fast] [--no-cpu] [--workload c2|c16|c3|c4|c5|...|scn:<scene>]
 
 N > 1: one process per GPU (torch.distributed over RCCL); the image is sharded by interleaved 8-row
 tiles and each frame ends with one gather of the packed pixels to rank 0 and the library's
 de-interleave kernel there.  Started as the driver starts it (torch.distributed.run, WORLD_SIZE set)
 this file is one rank; started plainly (`python bench.py --gpus 8`) it launches the N ranks itself, as
 child processes, before anything touches a GPU.  Total work is fixed, so scaling is "strong".
+
+At N > 1 the line also carries a `c4` block: BASELINE configs[3] (Demo, 3840x2160, 256 spp -- the configuration built for the 1/2/4/8 curve), a few
+frames one at a time, every gathered frame compared with the unsharded one; and at any N `config.predicted_from_shards`: every shard of a 2 / 4 / 8-way
+split of the workload (and of C4) rendered ALONE on rank 0's GPU (tools/shard_prediction.py) -- what each GPU of an N-GPU run will spend on the frame.
+Other blocks of the N = 1 line: `host_inclusive` (the one-shot rt_render() call with the frame read back, wall clock), `first_frame`, `unseen_passes`,
+`north_star_target` (16 spheres), `large_scene` (C3), `other_mode`, `cpu_baseline` (the reference's kernel as host C++ on the host cores).
 
 Prints ONE JSON line (rank 0).  The headline -- `value`, `ms_per_step` -- is ONE FRAME AT A TIME: frame
 k+1 starts when frame k is complete (at N > 1: gathered and assembled on rank 0), which is the
