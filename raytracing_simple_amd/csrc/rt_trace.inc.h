@@ -329,12 +329,53 @@ RT_DEV HitRoots hit_roots(HitPre p) {
     const float t2 = p.b + sq;
     return HitRoots{ t1 > RT_EPS ? t1 : t2, (p.det >= 0.f) && (t2 > RT_EPS) };
 }
+#if RT_OPT_GLOBAL_TABLES && !RT_OPT_WALK
+// Records of a table in HBM / L2 at a wave-uniform address -- the kernel's argument plus a loop counter -- fetched through the SCALAR cache into scalar
+// registers: one s_load_dwordx16 per four records, no vector-memory instruction, no address per lane, no vector register, and the test takes the record's
+// words as scalar operands.  Written as the instruction: left to itself the compiler issues the same load, but sinks it to where its result is first used,
+// behind the tests it was meant to overlap (the use is the loop's back edge).  So the request and the wait are two statements: request_four_uniform leaves
+// the registers pending, arrived() is the s_waitcnt before anything may read them -- on EVERY way out of a trip: a pending load writes its registers
+// whoever owns them by then.  The tables are written by an earlier kernel on the stream (rt_build_tables_kernel); the scalar cache is invalidated at the
+// start of every kernel.
+typedef float F16 __attribute__((ext_vector_type(16)));
+RT_DEV F16 request_four_uniform(const float4 *p) {
+    F16 r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(r) : "s"(p));
+    return r;
+}
+RT_DEV F16 arrived(F16 v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
+    return v;
+}
+RT_DEV float4 record_of(F16 v, int k) { return make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]); }
+#endif
 // true when some active lane needs the roots (NaN discriminants never hit: .cl:185-200)
 RT_DEV bool wave_any_nonneg(float det) { return __builtin_amdgcn_ballot_w64(det >= 0.f) != 0ull; }
 // closest hit over spheres [0, n): .cl:215-232
 RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t, uint32_t &id,
                           unsigned long long &roots) {
     uint32_t i = 0;
+#if RT_OPT_GLOBAL_TABLES && !RT_OPT_WALK
+    // The table lies in HBM / L2 (rt_trace_*_g: more records than LDS holds and no hierarchy).  Every lane tests the SAME record, so the table goes through
+    // the scalar cache, the next four records requested before these four are tested.  (As per-lane loads of one address the sweep was bound by the
+    // texture-address unit, 16 cycles per record and CU against the 8 its four SIMDs need for the test: vector ALU 15 % busy,
+    // profiles/r06y_nan9800_parity.md of library 4db11d7e46874b1f.)  The same tests in the same order.
+    if (n >= 4) {
+        F16 a = arrived(request_four_uniform(s_geom));
+        for (;;) {
+            const bool more = i + 8 <= n;
+            const F16 b = request_four_uniform(s_geom + (more ? i + 4 : i));      // (the last group asks for itself again: no read beyond the table)
+            const HitPre p0 = hit_pre(record_of(a, 0), o, d), p1 = hit_pre(record_of(a, 1), o, d), p2 = hit_pre(record_of(a, 2), o, d), p3 = hit_pre(record_of(a, 3), o, d);
+            if (wave_any_nonneg(p0.det)) { roots += 1; const HitRoots h = hit_roots(p0); if (h.hit && h.t < t) { t = h.t; id = i; } }
+            if (wave_any_nonneg(p1.det)) { roots += 1; const HitRoots h = hit_roots(p1); if (h.hit && h.t < t) { t = h.t; id = i + 1; } }
+            if (wave_any_nonneg(p2.det)) { roots += 1; const HitRoots h = hit_roots(p2); if (h.hit && h.t < t) { t = h.t; id = i + 2; } }
+            if (wave_any_nonneg(p3.det)) { roots += 1; const HitRoots h = hit_roots(p3); if (h.hit && h.t < t) { t = h.t; id = i + 3; } }
+            i += 4;
+            a = arrived(b);
+            if (!more) break;
+        }
+    }
+#endif
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
@@ -365,6 +406,24 @@ RT_DEV uint32_t sweep_any(const float4 *s_geom, uint32_t n, V3 o, V3 d, float ma
                           unsigned long long &roots) {
     uint32_t first = n;
     uint32_t i = 0;
+#if RT_OPT_GLOBAL_TABLES && !RT_OPT_WALK
+    if (n >= 4) {                   // (as in sweep_closest: four records per scalar load, the next four in flight meanwhile)
+        F16 a = arrived(request_four_uniform(s_geom));
+        for (;;) {
+            const bool more = i + 8 <= n;
+            const F16 b = request_four_uniform(s_geom + (more ? i + 4 : i));
+            const HitPre p0 = hit_pre(record_of(a, 0), o, d), p1 = hit_pre(record_of(a, 1), o, d), p2 = hit_pre(record_of(a, 2), o, d), p3 = hit_pre(record_of(a, 3), o, d);
+            if (__builtin_amdgcn_ballot_w64(first == n && p0.det >= 0.f) != 0ull) { roots += 1; const HitRoots h = hit_roots(p0); if (first == n && h.hit && h.t < max_t) first = i; }
+            if (__builtin_amdgcn_ballot_w64(first == n && p1.det >= 0.f) != 0ull) { roots += 1; const HitRoots h = hit_roots(p1); if (first == n && h.hit && h.t < max_t) first = i + 1; }
+            if (__builtin_amdgcn_ballot_w64(first == n && p2.det >= 0.f) != 0ull) { roots += 1; const HitRoots h = hit_roots(p2); if (first == n && h.hit && h.t < max_t) first = i + 2; }
+            if (__builtin_amdgcn_ballot_w64(first == n && p3.det >= 0.f) != 0ull) { roots += 1; const HitRoots h = hit_roots(p3); if (first == n && h.hit && h.t < max_t) first = i + 3; }
+            a = arrived(b);
+            if (__builtin_amdgcn_ballot_w64(first == n) == 0ull) return first;
+            i += 4;
+            if (!more) break;
+        }
+    }
+#endif
     for (; i + 2 <= n; i += 2) {
         const float4 g0 = s_geom[i], g1 = s_geom[i + 1];
         const HitPre p0 = hit_pre(g0, o, d), p1 = hit_pre(g1, o, d);
@@ -531,10 +590,6 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
     const uint32_t n_lights = P.scene.n_lights;
 #if RT_OPT_GLOBAL_TABLES
     const float4 *s_geom = P.scene.geom;     // nothing staged but the reciprocals of the running average
-    const float4 *s_lightA = P.scene.lightA;
-    const float4 *s_lightB = P.scene.lightB;
-    float4 *s_emis = lds;                    // (never read: the host keeps mat_in_lds off)
-    float4 *s_colr = lds;
 #else
     float4 *s_geom = lds;
     float4 *s_lightA = s_geom + n;           // {centre, radius}
@@ -544,7 +599,11 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
 #endif
     // 1/(s+1) of the running average (.cl:585), one IEEE division per sample index per
     // workgroup instead of one per lane per sample
+#if RT_OPT_GLOBAL_TABLES
+    float *s_k2 = reinterpret_cast<float *>(lds);       // (rt_launch.hip bind_tables: an instance over tables in HBM / L2 never has mat_in_lds)
+#else
     float *s_k2 = reinterpret_cast<float *>(P.mat_in_lds ? s_colr + n : s_emis);
+#endif
     const bool k2_in_lds = P.n_samples <= kMaxK2Table;
 
     const int tid = threadIdx.x;
@@ -565,12 +624,14 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         s_lightB[i] = P.scene.lightB[i];
     }
 #endif
+#if !RT_OPT_GLOBAL_TABLES
     if (P.mat_in_lds) {
         for (uint32_t i = tid; i < n; i += kBlockThreads) {
             s_emis[i] = P.scene.emis[i];
             s_colr[i] = P.scene.colr[i];
         }
     }
+#endif
     if (k2_in_lds)
         for (int i = tid; i < P.n_samples; i += kBlockThreads)
             s_k2[i] = rt_rcp((float)(P.first_sample + i) + 1.f);
@@ -800,6 +861,16 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
             RT_STAMP(2);
             const float4 ge = s_geom[id];
             float4 em4, co4;
+#if RT_OPT_GLOBAL_TABLES
+            {
+                // (rt_trace_*_g: the two pointers are read from the kernel-argument segment HERE, once per hit, as the camera is once per sample:
+                // the sweep keeps two pairs of records in scalar registers, and these four would be spilled to hold them)
+                const volatile __attribute__((address_space(4))) LaunchParams *mp =
+                    (const volatile __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+                em4 = mp->scene.emis[id];
+                co4 = mp->scene.colr[id];
+            }
+#else
             if (P.mat_in_lds) {                 // wave-uniform: ds_read / global_load, not flat_load
                 em4 = s_emis[id];
                 co4 = s_colr[id];
@@ -808,6 +879,7 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
                 em4 = P.scene.emis[id];
                 co4 = P.scene.colr[id];
             }
+#endif
             const V3 em = mk(em4.x, em4.y, em4.z);
             col = mk(co4.x, co4.y, co4.z);
             refl = __float_as_int(em4.w);
@@ -885,10 +957,18 @@ extern "C" __global__ void __launch_bounds__(64 * RT_OPT_WG_WAVES, RT_OPT_MINWAV
         if (is_diff) {
             for (uint32_t j = 0; j < n_lights; ++j) {
                 RT_STAMP(3);
+#if RT_OPT_GLOBAL_TABLES
+                const volatile __attribute__((address_space(4))) LaunchParams *lp =           // (as the material pointers above: once per light)
+                    (const volatile __attribute__((address_space(4))) LaunchParams *)__builtin_amdgcn_kernarg_segment_ptr();
+                const float4 lb = lp->scene.lightB[j];
+                const float4 la = lp->scene.lightA[j];
+#else
                 const float4 lb = s_lightB[j];
+                const float4 la = s_lightA[j];
+#endif
                 V3 sd;
                 float len, numer;
-                if (!sample_light(s_lightA[j], lb, s0, s1, c_draws, hp, nl, sd, len, numer)) continue;
+                if (!sample_light(la, lb, s0, s1, c_draws, hp, nl, sd, len, numer)) continue;
                 // ---- shadow ray, any hit, .cl:234-247 ----
                 c_shadow += 1;
                 RT_STAMP(4);

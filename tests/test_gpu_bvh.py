@@ -554,6 +554,34 @@ def test_scenes_beyond_lds(n):
         _same(got, want)
 
 
+@pytest.mark.parametrize("n", [9729, 9730, 9731, 9732, 12001])
+def test_plain_sweep_through_the_scalar_cache(n):
+    """rt_trace_parity_g (round 6): the plain sweep over a table beyond LDS reads it four records per scalar load, the next four in flight
+    while these are tested, then two and one for what is left -- every residue of the table size modulo 4, records that are not numbers or
+    infinite among the spheres (they are tested like the others and never hit), three lights (shadow sweeps that leave early, at every
+    position of a group), a pass continued by a second launch."""
+    sph, orig, target = _many_spheres(n, seed=n)
+    rng = np.random.default_rng(n)
+    odd = rng.choice(np.arange(2, n), 600, replace=False)
+    sph["p"][odd[:200], 0] = np.float32("nan")
+    sph["rad"][odd[200:400]] = np.float32("inf")
+    sph["p"][odd[400:], 1] = np.float32("-inf")
+    for k, at in enumerate(((-30, 40, 20), (45, 25, -30))):        # two more lights, one of them late in the table
+        i = (5, n - 2)[k]
+        sph["rad"][i], sph["p"][i], sph["e"][i], sph["refl"][i] = 4.0, at, (9, 8, 7), api.DIFF
+    w, h = 40, 24
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, 3, threads=16)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))           # no hierarchy: the fallback form
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.render_pass(1)
+        got = {"pixels": ctx.render_pass(2), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        assert ctx.last_kernel == "rt_trace_parity_g"
+        _same(got, want)
+
+
 def test_the_scene_size_limit():
     too_many = np.zeros(262144 + 1, api.SPHERE_DT)
     with api.RtContext(32, 32) as ctx:
