@@ -358,8 +358,9 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
 #if RT_OPT_GLOBAL_TABLES && !RT_OPT_WALK
     // The table lies in HBM / L2 (rt_trace_*_g: more records than LDS holds and no hierarchy).  Every lane tests the SAME record, so the table goes through
     // the scalar cache, the next four records requested before these four are tested.  (As per-lane loads of one address the sweep was bound by the
-    // texture-address unit, 16 cycles per record and CU against the 8 its four SIMDs need for the test: vector ALU 15 % busy,
-    // profiles/r06y_nan9800_parity.md of library 4db11d7e46874b1f.)  The same tests in the same order.
+    // texture-address unit, 16 cycles per record and CU against the 8 its four SIMDs need for the test: vector ALU 15 % busy; that form, two records per
+    // scalar load and a per-wavefront LDS window filled by all 64 lanes were measured against this one: profiles/r06_g_sweep_forms.jsonl.)  The same
+    // tests in the same order.
     if (n >= 4) {
         F16 a = arrived(request_four_uniform(s_geom));
         for (;;) {
