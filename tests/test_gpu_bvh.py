@@ -582,6 +582,34 @@ def test_plain_sweep_through_the_scalar_cache(n):
         _same(got, want)
 
 
+def test_plain_sweep_through_the_scalar_cache_sees_device_resident_updates():
+    """The table rt_trace_parity_g reads through the scalar cache is rewritten on the stream between launches (rt_update_spheres_async ->
+    rt_build_tables_kernel): every launch must see the records as they are then -- five frames of spheres moving and a light changing,
+    queued without a host wait in between, each against the oracle."""
+    n = 9740
+    sph, orig, target = _many_spheres(n, seed=5)
+    w, h, spp = 40, 24, 2
+    cam = host.compute_camera(orig, target, w, h)
+    rng = np.random.default_rng(5)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        for f in range(5):
+            who = np.sort(rng.choice(np.arange(2, n), 40, replace=False))
+            sph["p"][who] += rng.uniform(-2, 2, (40, 3)).astype(np.float32)
+            sph["rad"][who] *= np.float32(1.5)
+            sph["p"][1] += np.float32([3.0, -1.0, 2.0])                        # the light
+            for i in who:
+                ctx.update_spheres(int(i), sph[int(i):int(i) + 1], ctx.stream)
+            ctx.update_spheres(1, sph[1:2], ctx.stream)
+            ctx.reset_async(ctx.stream)
+            ctx.render_async(spp, ctx.stream)
+            got = {"pixels": ctx.read_pixels(), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            assert ctx.last_kernel == "rt_trace_parity_g"
+            _same(got, O.render(sph, cam, w, h, spp, threads=16))
+
+
 def test_the_scene_size_limit():
     too_many = np.zeros(262144 + 1, api.SPHERE_DT)
     with api.RtContext(32, 32) as ctx:
