@@ -3,6 +3,7 @@
 #include "HipConfig.hpp"
 
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,8 +100,9 @@ void HipConfig::setArguments() {}                        // OpenCLConfig.cpp:517
 // device, not the microsecond it takes to count it:
 //   * the queue is bounded -- after a launch the call waits until at most two launches are unfinished (rt_throttle),
 //     which also returns the device time per pass of the launch that finished last;
-//   * every call then lasts at least 0.9 x that time (a short spin: this is the compute thread, which the reference
-//     blocks in clFinish), so the host runs at the device's pace, a fraction ahead; the launching call takes up the slack.
+//   * every call then lasts at least 0.9 x that time (this is the compute thread, which the reference blocks in clFinish: a
+//     spin of tens of microseconds for the usual pass, a sleep with a 150 us spin at its end for passes beyond 0.3 ms), so
+//     the host runs at the device's pace, a fraction ahead; the launching call takes up the slack.
 // The frame that is due is copied asynchronously into pPixels (page-locked) behind the passes -- the window reads that
 // buffer unsynchronised in the reference too -- so a due pass costs a launch, not a drain of the queue.
 void HipConfig::execute() {                              // OpenCLConfig.cpp:407-515
@@ -133,6 +135,10 @@ void HipConfig::execute() {                              // OpenCLConfig.cpp:407
     }
     if (passMs > 0.0) {
         const auto until = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double, std::milli>(0.9 * passMs));
+        // Passes of tens of microseconds are spun out; a pass that costs the device a millisecond does not hold a core for it: the thread
+        // sleeps through all but the last 150 us (a wake-up comes some tens of microseconds late) and spins only those.
+        const auto left = until - std::chrono::steady_clock::now();
+        if (left > std::chrono::microseconds(300)) std::this_thread::sleep_for(left - std::chrono::microseconds(150));
         while (std::chrono::steady_clock::now() < until) { /* spin: tens of microseconds */ }
     }
 }
