@@ -509,8 +509,8 @@ def main():
         "r8192": ("8192 random spheres (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(8192), 1920, 1080, 4),
         "r65536": ("65536 random spheres (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(65536), 1920, 1080, 4),
         "r262144": ("262144 random spheres = RT_MAX_SPHERES (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(262144), 1920, 1080, 4),
-        "nan9800": ("the Demo scene + 9794 records whose centre is not a number: more than 9700 records of which fewer than 56 are finite spheres -- no hierarchy, "
-                    "and a table beyond LDS: the plain sweep over a table in HBM / L2 (rt_trace_*_g), the fallback that keeps every input renderable", lambda: nan_scene(9800), 640, 360, 1),
+        "nan9800": ("the Demo scene + 9794 records whose centre is not a number: thousands of records of which fewer than 56 are finite small spheres -- no hierarchy, "
+                    "and a table beyond the sweep's LDS budget: the plain sweep over a table in HBM / L2 through the scalar cache (rt_trace_*_g), the fallback that keeps every input renderable", lambda: nan_scene(9800), 640, 360, 1),
         "nan9800hd": ("the nan9800 scene at 1920x1080: 32 400 wavefronts instead of 3 600 (640x360 leaves the GPU's 6 144 wavefront slots under-filled; the small size is the "
                       "one whose CPU check takes seconds -- run this one with --no-cpu)", lambda: nan_scene(9800), 1920, 1080, 1),
     }

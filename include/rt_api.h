@@ -94,7 +94,8 @@ enum rt_mode {
 #define RT_MAX_SPHERES 262144u /* (the hierarchy numbers its leaves of 8 spheres with 15 bits.  Its tables are staged in LDS while
                                  * five workgroups of that size fit a CU -- 31 KiB, about 1 100 spheres; to about 3 200 spheres its
                                  * pairs still are and only the leaves' spheres are read from HBM / L2 ("..._pairs_m"); beyond,
-                                 * everything is ("..._pairs_g"); the plain sweep's table fits LDS up to about 9 700 spheres)     */
+                                 * everything is ("..._pairs_g"); the plain sweep stages its tables while four workgroups fit a CU
+                                 * -- 40 KiB, about 2 500 records -- and reads them through the scalar cache beyond ("..._g"))        */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -285,7 +286,7 @@ RT_API int rt_get_stats(rt_ctx *ctx, rt_stats *out);
  * (12 and more: wave-ballot any-hit sharing; with 4 to 11 spheres whichever of the two the scene's first launches timed
  * faster -- coop warm, coop timed, plain warm, plain timed: passes of the frame like any other), "..._pairs" (hundreds of
  * small spheres: a hierarchy, where it measured faster than the sweep on this scene; "..._pairs_m" / "..._pairs_g" when its
- * tables outgrow LDS), "..._g" (a plain sweep over a table beyond LDS), the same with "fast".  "" before the first launch.
+ * tables outgrow LDS), "..._g" (a plain sweep over a table beyond its LDS budget, read through the scalar cache), the same with "fast".  "" before the first launch.
  * Frames do not depend on it. */
 RT_API const char *rt_last_kernel(const rt_ctx *ctx);
 /* Hierarchy or plain sweep for the current scene (scenes with 56 to 1500 small spheres; larger ones always walk the

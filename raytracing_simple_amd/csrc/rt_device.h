@@ -157,7 +157,7 @@ enum InstanceRole : uint8_t {
     kRolePairs,             // large scenes through the hierarchy
     kRolePairsGlobal,       // ... tables beyond the LDS budget
     kRolePairsMixed,        // ... whose pairs still fit it (rt_trace_*_pairs_m)
-    kRoleSweepGlobal,       // no hierarchy (or it lost the measurement) and a table beyond LDS
+    kRoleSweepGlobal,       // no hierarchy (or it lost the measurement) and a table beyond the sweep's LDS budget (rt_internal.h sweep_lds_limit)
     kRolePersist,           // diagnostics: persistent wavefronts (rt_debug_set_persist)
     kRolePersistCoop,
     kRoleTimelog,           // diagnostics: the shipped shape + device wall-clock logging

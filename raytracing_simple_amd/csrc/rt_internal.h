@@ -107,6 +107,10 @@ struct rt_ctx {
     int mode = RT_MODE_PARITY;
     int regen_gate = 0;                 // 0 = choose from the scene size
     int mat_lds_limit = 24 * 1024;
+    int sweep_lds_limit = 40 * 1024;    // the plain / cooperative sweep stages its tables while four workgroups of that size fit a CU; beyond, the table is read through the
+                                        // scalar cache at six wavefronts per SIMD whatever its size (rt_trace_*_g).  Measured at 1080p on scenes without a hierarchy
+                                        // (profiles/r06_g_threshold.jsonl): at 48 KB (3 per CU) rt_trace_*_g takes 0.62 / 0.92 x the staged sweep's time (NaN records / a closed
+                                        // box of mirrors), at 64 KB (2) 0.41 / 0.63, at 96 KB and more (1) 0.19; at 32 KB (4) 0.80 / 1.12, below that 0.9 ... 1.3
     int coop_kmax = 0;                  // cooperative any-hit only while no more than this many shadow rays are pending in the wavefront (0 = no limit)
     int coop_min = 12;                  // scenes with at least this many spheres use the cooperative any-hit instance (0 = never)
     int persist = 0;                    // diagnostics: persistent-wavefront instances

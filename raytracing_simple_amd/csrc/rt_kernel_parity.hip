@@ -3,8 +3,8 @@
 // Shipped (librt_hip.so): rt_trace_parity_w1 (fewer than 12 spheres: single-wavefront workgroups), rt_trace_parity_coop_w1 / _coop
 // (12 spheres and more: cooperative any-hit, single- / 4-wavefront workgroups), rt_trace_parity_pairs (many small spheres: the
 // hierarchy, rt_walk.inc.h), rt_trace_parity_pairs_m / _pairs_g (its tables beyond LDS), rt_trace_parity_g (the plain sweep over a table
-// beyond LDS: more than about 9 700 records of which fewer than 56 are finite spheres -- the fallback that keeps every input
-// renderable).  The 4-wavefront PLAIN sweep (rt_trace_parity) is not shipped since round 6: a scene of fewer than 12 spheres never
+// beyond the sweep's LDS budget, read through the scalar cache: more than about 2 500 records of which fewer than 56 are finite small spheres -- the
+// fallback that keeps every input renderable).  The 4-wavefront PLAIN sweep (rt_trace_parity) is not shipped since round 6: a scene of fewer than 12 spheres never
 // outgrows the single-wavefront workgroup's LDS budget, so nothing selected it (rt_launch.hip).  Everything else exists only in the
 // diagnostics build (librt_hip_diag.so, -DRT_DIAGNOSTICS=1): verification, census and A/B shapes of the same arithmetic
 // and the exhaustive device-side checks of the lean square root / reciprocal.  The table at the end of this file is

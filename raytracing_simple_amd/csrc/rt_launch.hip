@@ -105,6 +105,11 @@ static size_t pairs_lds(const rt_ctx *c, bool mat, int n_samples, int waves = 4)
 bool tables_fit_lds(const rt_ctx *c, int n_samples) {
     return rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, false, n_samples) <= kLdsMax;
 }
+// ... and are staged there: while at least four workgroups of that size fit a CU.  Larger tables go through the scalar cache (rt_trace_*_g), which
+// keeps six wavefronts per SIMD at any size: a sweep over 96 KB of staged tables runs ONE workgroup per CU and takes five times as long (rt_internal.h)
+static bool sweep_stages_tables(const rt_ctx *c, int n_samples) {
+    return rt::lds_bytes(c->scene.n_spheres, c->scene.n_lights, false, n_samples) <= (size_t)(c->sweep_lds_limit < (int)kLdsMax ? c->sweep_lds_limit : (int)kLdsMax);
+}
 
 // the hierarchy's tables fit the LDS budget given to them; otherwise the walk reads them from HBM / L2
 static bool bvh_fits_lds(const rt_ctx *c, int n_samples) { return pairs_lds(c, false, n_samples) <= (size_t)c->bvh_lds_limit; }
@@ -202,8 +207,8 @@ static int launch_form(rt_ctx *c, int n_samples, hipStream_t stream, int form, b
         role = bvh_fits_lds(c, n_samples) ? rt::kRolePairs : (bvh_pairs_fit_lds(c, n_samples) ? rt::kRolePairsMixed : rt::kRolePairsGlobal);
         waves = 4;
         if (c->regen_gate <= 0) p.regen_gate = c->walk_gate;
-    } else if (!tables_fit_lds(c, n_samples)) {
-        // no hierarchy (or it lost the measurement) and a table beyond LDS: the plain sweep over the table in HBM / L2
+    } else if (!sweep_stages_tables(c, n_samples)) {
+        // no hierarchy (or it lost the measurement) and a table beyond the sweep's LDS budget: the plain sweep over the table in HBM / L2
         role = rt::kRoleSweepGlobal;
         waves = 4;
     }
@@ -491,7 +496,7 @@ int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
         return measured ? launch_priced(c, n_samples, stream, 2) : launch_form(c, n_samples, stream, 0);
     // no probe where the answer is known and asking is dear: from 1500 spheres in the tree on the hierarchy won on every
     // scene measured, open or packed, and one pass of the sweep at 1080p costs 2.6 ms at 1024 spheres,
-    // 28 ms at 4096, 138 ms at 8192, seconds beyond LDS
+    // 28 ms at 4096, 138 ms at 8192 from staged tables (through the scalar cache, round 6: a fifth of that at 8192 -- still tens of milliseconds a pass)
     if (c->bvh_n_tree >= kAlwaysWalkFrom || !tables_fit_lds(c, n_samples)) return launch_priced(c, n_samples, stream, 1);
     if (c->choice_leader)                       // a shard of a multi-device context: the form the first shard just launched
         return launch_priced(c, n_samples, stream, c->choice_leader->last_form == 2 ? 2 : 1);

@@ -44,7 +44,7 @@
 //                         2: verification instance, the sequential sweep runs beside it (diagnostics)
 //   RT_OPT_WALK           1: large scenes -- the small spheres hang in a hierarchy that each lane walks for its own ray
 //                         (rt_walk.inc.h, its own kernel body); 2: the same with a census of its steps (diagnostics)
-//   RT_OPT_GLOBAL_TABLES  tables that do not fit LDS are read where they lie in HBM / L2
+//   RT_OPT_GLOBAL_TABLES  tables beyond the LDS budget are read where they lie in HBM / L2 (the plain sweep: through the scalar cache)
 //   RT_OPT_MINWAVES       launch bound: wavefronts per SIMD the register allocation must allow
 // Diagnostics build only:
 //   RT_OPT_PERSIST        persistent wavefronts: the grid only fills the machine, each wavefront pulls 8x8 pixel tiles
@@ -356,7 +356,7 @@ RT_DEV void sweep_closest(const float4 *s_geom, uint32_t n, V3 o, V3 d, float &t
                           unsigned long long &roots) {
     uint32_t i = 0;
 #if RT_OPT_GLOBAL_TABLES && !RT_OPT_WALK
-    // The table lies in HBM / L2 (rt_trace_*_g: more records than LDS holds and no hierarchy).  Every lane tests the SAME record, so the table goes through
+    // The table lies in HBM / L2 (rt_trace_*_g: no hierarchy and more records than the sweep stages -- 40 KB, four workgroups per CU: rt_launch.hip).  Every lane tests the SAME record, so the table goes through
     // the scalar cache, the next four records requested before these four are tested.  (As per-lane loads of one address the sweep was bound by the
     // texture-address unit, 16 cycles per record and CU against the 8 its four SIMDs need for the test: vector ALU 15 % busy; that form, two records per
     // scalar load and a per-wavefront LDS window filled by all 64 lanes were measured against this one: profiles/r06_g_sweep_forms.jsonl.)  The same

@@ -524,7 +524,7 @@ def _many_spheres(n, seed=7):
 
 @pytest.mark.parametrize("n", [2000, 5000, 9500, 30000])
 def test_scenes_beyond_lds(n):
-    """More spheres than the LDS budget holds (the hierarchy's whole tables stop at ~1100 spheres, the sweep's at ~9700): while the PAIRS
+    """More spheres than the LDS budget holds (the hierarchy's whole tables stop at ~1100 spheres, the sweep's at ~2500: four workgroups per CU): while the PAIRS
     still fit (to ~3200 spheres) they are staged and only the slots read from HBM / L2 (rt_trace_parity_pairs_m, round 5); beyond, the
     walk reads pairs and slots from HBM / L2 (rt_trace_parity_pairs_g); beyond 8192 spheres in the tree the tables are built on the
     host.  Frames, seeds and counters are still the oracle's."""
@@ -550,7 +550,7 @@ def test_scenes_beyond_lds(n):
         ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
         ctx.reset()
         got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
-        assert ctx.last_kernel == ("rt_trace_parity_coop" if 16 * n + 64 <= 152 * 1024 else "rt_trace_parity_g")
+        assert ctx.last_kernel == ("rt_trace_parity_coop" if 16 * n + 128 <= 40 * 1024 else "rt_trace_parity_g")      # (staged while 4 workgroups fit a CU)
         _same(got, want)
 
 

@@ -613,19 +613,24 @@ def test_random_operation_sequences_keep_the_running_average_exact():
 
 
 def test_largest_scene_with_its_tables_in_lds():
-    """8192 spheres: 128 KiB of geometry in LDS for the plain sweep, one workgroup per CU (the hierarchy, which
-    a scene of this size normally renders through, is switched off here); larger scenes: tests/test_gpu_bvh.py."""
+    """8192 spheres: 128 KiB of geometry in LDS for the sweep, one workgroup per CU (the hierarchy, which a scene of this size normally
+    renders through, is switched off here).  Since round 6 the library itself leaves LDS at 40 KB of tables -- four workgroups per CU --
+    for the sweep through the scalar cache (rt_trace_parity_g, five times as fast at this size: profiles/r06_g_threshold.jsonl); the staged
+    form is still an instance any scene up to 152 KB may be rendered with by name.  Larger scenes: tests/test_gpu_bvh.py."""
     sph, orig, target = scenes.random_spheres(8192)
     cam = host.compute_camera(orig, target, 64, 40)
     want = O.render(sph, cam, 64, 40, 2, threads=16)
     _assert_same(_gpu(sph, cam, 64, 40, 2), want)
-    with api.RtContext(64, 40, diag=True) as ctx:
-        ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
-        ctx.set_scene(sph)
-        ctx.set_camera(cam)
-        got = {"pixels": ctx.render_pass(2), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
-        assert ctx.last_kernel == "rt_trace_parity_coop"
-    _assert_same(got, want)
+    for inst, kernel in ((None, "rt_trace_parity_g"), ("rt_trace_parity_coop", "rt_trace_parity_coop")):
+        with api.RtContext(64, 40, diag=True) as ctx:
+            ctx._check(ctx._lib.rt_debug_set_bvh(ctx._h, 0, 0))
+            ctx.set_scene(sph)
+            ctx.set_camera(cam)
+            if inst:
+                ctx.set_mode(api.instance_mode(inst))
+            got = {"pixels": ctx.render_pass(2), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            assert ctx.last_kernel == kernel
+        _assert_same(got, want)
 
 
 def test_long_accumulation_both_reciprocal_paths():
