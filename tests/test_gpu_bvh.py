@@ -582,6 +582,44 @@ def test_plain_sweep_through_the_scalar_cache(n):
         _same(got, want)
 
 
+def _two_size_classes(n_small, n_large, seed=3):
+    """Dust among objects fifty times its size, a ground sphere and a light (tools/always_list_probe.py)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import always_list_probe
+    return always_list_probe.two_classes(n_small, n_large, seed)
+
+
+@pytest.mark.parametrize("n_small,n_large,by_area", [(700, 300, 1), (3000, 600, 1), (3000, 600, 2), (9000, 1500, 1), (300, 700, 1)])
+def test_two_size_classes_both_hang_in_the_tree(n_small, n_large, by_area):
+    """Round 6: the cut between the tree and the always-list is never below an eighth of the scene's extent, so the larger class of a scene of
+    two size classes -- more than 16 x the median radius, yet nowhere near the scene's size -- hangs in the tree instead of being swept by every
+    ray (only the ground sphere stays outside).  Host-shaped and device-shaped trees, LDS and L2 walks; frames, seeds and counters are the
+    oracle's, the tables a valid hierarchy."""
+    sph, orig, target = _two_size_classes(n_small, n_large)
+    w, h, spp = 48, 32, 2
+    cam = host.compute_camera(orig, target, w, h)
+    want = O.render(sph, cam, w, h, spp, threads=16)
+    with api.RtContext(w, h, diag=True) as ctx:
+        ctx._check(ctx._lib.rt_debug_set_tree_shape(ctx._h, by_area))
+        ctx._check(ctx._lib.rt_debug_set_walk(ctx._h, 0, 0, 1))
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        got = {"pixels": ctx.render_pass(spp), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        assert "_pairs" in ctx.last_kernel
+        _same(got, want)
+        b = bvh_check.read_bvh(ctx)
+        assert b["n_always"] == 1, b["n_always"]                 # the ground; the light (9) and the larger class are in the tree
+        assert bvh_check.check_structure(api.as_spheres(sph), b) == []
+        # ... and after a device-resident update of some of the larger spheres (the cut is formed again from the mirror)
+        sph["p"][-5:] += np.float32([1.0, 0.0, -1.0])
+        ctx.update_spheres(len(sph) - 5, sph[-5:], ctx.stream)
+        ctx.reset_async(ctx.stream)
+        ctx.render_async(spp, ctx.stream)
+        got = {"pixels": ctx.read_pixels(), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+        _same(got, O.render(sph, cam, w, h, spp, threads=16))
+        assert bvh_check.check_structure(api.as_spheres(sph), bvh_check.read_bvh(ctx)) == []
+
+
 def test_plain_sweep_through_the_scalar_cache_sees_device_resident_updates():
     """The table rt_trace_parity_g reads through the scalar cache is rewritten on the stream between launches (rt_update_spheres_async ->
     rt_build_tables_kernel): every launch must see the records as they are then -- five frames of spheres moving and a light changing,
