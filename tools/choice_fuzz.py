@@ -4,7 +4,7 @@ three decades), layouts (a slab over a ground sphere, clusters, a closed box) an
 library's own pick, with the hierarchy forced and with the sweep forced; a line per scene, `worse_than_best` = pick's time over the best form's.
 `python tools/choice_fuzz.py FIRST COUNT [directory of another build of the libraries]` (diagnostics library);
 RT_CHOICE_FUZZ_FAMILY=small: scenes of 4 ... 250 spheres with 1 ... 12 lights, pick against the hierarchy forced and the plain / cooperative sweep
-with one / four wavefronts per workgroup.  Frames are compared bit for bit on the way."""
+with one / four wavefronts per workgroup; RT_CHOICE_FUZZ_FAMILY=lights: 50 ... 3000 spheres of which 10 ... 300 are lights.  Frames are compared bit for bit on the way."""
 import json
 import os
 import statistics
@@ -83,6 +83,23 @@ def small_scene(seed):
     return sph, host.DEMO_ORIG, host.DEMO_TARGET, {"n": int(n + 1), "lights": int(len(lights)), "materials": len(mix), "family": "small"}
 
 
+def lights_scene(seed):
+    """50 ... 3000 spheres of one size class over a ground sphere, 10 ... 300 of them lights: every diffuse hit asks every light."""
+    rng = np.random.default_rng(920000 + seed)
+    n = int(10 ** rng.uniform(1.7, 3.5))
+    sph = np.zeros(n + 1, api.SPHERE_DT)
+    r = rng.uniform(0.5, 2.0, n)
+    sph["rad"][:n] = r.astype(np.float32)
+    sph["p"][:n] = np.stack([rng.uniform(-60, 60, n), r + rng.uniform(0, 15, n), rng.uniform(-60, 60, n)], 1).astype(np.float32)
+    sph["c"][:n] = rng.uniform(0.2, 0.9, (n, 3)).astype(np.float32)
+    sph["refl"][:n] = rng.choice([api.DIFF, api.DIFF, api.SPEC, api.REFR], n)
+    lights = rng.choice(n, min(n // 2, int(10 ** rng.uniform(1.0, 2.5))), replace=False)
+    sph["e"][lights] = rng.uniform(1, 6, (len(lights), 3)).astype(np.float32)
+    sph["refl"][lights] = api.DIFF
+    sph["rad"][n], sph["p"][n], sph["c"][n] = 1000.0, (0, -1000, 0), (.75, .75, .75)
+    return sph, host.DEMO_ORIG, host.DEMO_TARGET, {"n": int(n + 1), "lights": int(len(lights)), "family": "lights"}
+
+
 def run(sph, cam, w, h, spp, how):
     with api.RtContext(w, h, diag=True) as ctx:
         if how == "sweep":
@@ -111,8 +128,9 @@ def main():
         api.lib_path = lambda diag=False: os.path.join(alt, "librt_hip_diag.so" if diag else "librt_hip.so")
     w, h, spp = 640, 360, 2
     small = os.environ.get("RT_CHOICE_FUZZ_FAMILY") == "small"
+    many_lights = os.environ.get("RT_CHOICE_FUZZ_FAMILY") == "lights"
     for seed in range(first, first + count):
-        sph, orig, target, what = small_scene(seed) if small else scene(seed)
+        sph, orig, target, what = small_scene(seed) if small else (lights_scene(seed) if many_lights else scene(seed))
         cam = host.compute_camera(orig, target, w, h)
         res = {}
         px0 = None
