@@ -171,13 +171,14 @@ RT_API int rt_set_scene(rt_ctx *ctx, const rt_sphere *spheres, uint32_t count);
 
 /* Device-resident scene update: replace spheres [first, first+count) of the scene set
  * by rt_set_scene -- moving spheres, changed materials, lights switched on or off -- without a
- * host wait: the records are staged through page-locked memory, copied and the tables rebuilt by the
- * device-side kernel, all asynchronously on `hip_stream` (a hipStream_t; NULL = the default stream, as
- * for rt_render_async); launches issued later on this context see the new scene (tables and, for large scenes, the
- * hierarchy are rebuilt behind the copy -- up to 8192 spheres inside the tree by the device's own build by surface area,
- * with no host wait; beyond that the host builds the fixed (halved) shape from its mirror of the records and the call waits
- * for the previous such build's upload to have left its staging buffer; the choice between hierarchy and sweep is kept).  The sphere count
- * does not change.  `spheres` may be reused as soon as the call returns.                        */
+ * host wait: the records are staged through page-locked memory and copied asynchronously on `hip_stream` (a hipStream_t;
+ * NULL = the default stream, as for rt_render_async); launches issued later on this context see the new scene.  The tables and,
+ * for large scenes, the hierarchy are rebuilt ONCE, by the device-side kernels on the stream of the next launch, however many
+ * updates precede it (a host that moves 200 scattered spheres by 200 calls pays one rebuild, as for one call over the whole
+ * range) -- up to 8192 spheres inside the tree by the device's own build by surface area, with no host wait; beyond that the
+ * host builds the fixed (halved) shape from its mirror of the records and that launch waits for the previous such build's
+ * upload to have left its staging buffer; the choice between hierarchy and sweep is kept.  The sphere count does not change.
+ * `spheres` may be reused as soon as the call returns.                                          */
 RT_API int rt_update_spheres_async(rt_ctx *ctx, uint32_t first, uint32_t count, const rt_sphere *spheres,
                                    void *hip_stream);
 

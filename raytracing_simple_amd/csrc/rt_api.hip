@@ -352,9 +352,8 @@ RT_API int rt_update_spheres_async(rt_ctx *c, uint32_t first, uint32_t count, co
     // the last frame's costs still predict this one (moving spheres): the order stays in use and the next long launch sorts it again from them
     c->order_stale = true;
     if (c->cost_window) c->cost_passes = 0;         // (a window of short launches' costs starts again from the changed scene)
-    rc = upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream, false);
-    if (rc == RT_OK) rearm_probe_if_changed(c);
-    return rc;
+    // (the records go now; tables and hierarchy are rebuilt once, by the next launch -- rt_scene.hip refresh_tables -- however many updates precede it)
+    return upload_spheres(c, first, count, spheres, n, (hipStream_t)hip_stream, false);
 }
 
 RT_API int rt_set_camera(rt_ctx *c, const rt_camera *cam) {

@@ -136,11 +136,16 @@ RT_API const char *rt_debug_shard_kernel(rt_ctx *c, int shard) {
     if (!c || !c->multi || shard < 0 || shard >= rt::multi_shards(c)) return "";
     return rt::multi_shard(c, shard)->last_kernel;
 }
+// (readers of the tables and the hierarchy: device-resident updates leave them stale until something asks -- rt_scene.hip refresh_tables)
+static int fresh_tables(rt_ctx *c) { return c->tables_stale ? rt::refresh_tables(c, c->stream) : RT_OK; }
+
 // The render kernels' table staging alone (rt_stage_probe_kernel), `repeats` launches of the grid and workgroup shape the library
 // would use for `n_samples` passes of the current scene: for a profiler run that isolates the L2 behaviour of those reads.
 RT_API int rt_debug_stage_tables(rt_ctx *c, int n_samples, int repeats) {
     if (!c || c->multi || !c->have_scene) return fail(RT_ERR_ARG, "null / multi-device context, or no scene");
     int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = fresh_tables(c);
     if (rc != RT_OK) return rc;
     rc = chain(c, c->stream);
     if (rc != RT_OK) return rc;
@@ -239,6 +244,8 @@ static int dbg_set_bvh_min(rt_ctx *c, int v) {
     if (!c->have_scene) return RT_OK;
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
+    rc = fresh_tables(c);
+    if (rc != RT_OK) return rc;
     rc = chain(c, c->stream);
     return rc != RT_OK ? rc : rt::build_bvh(c, c->scene.n_spheres, c->stream, true);
 }
@@ -280,9 +287,11 @@ RT_API int rt_debug_set_walk(rt_ctx *c, int steps, int gate, int forced) {
 // blocking index, 0)
 RT_API int rt_debug_walk_rays(rt_ctx *c, const float *rays8, uint32_t n_rays, uint32_t *out4) {
     if (!c || c->multi || !rays8 || !out4) return fail(RT_ERR_ARG, "null / multi-device context");
-    if (!c->bvh_ok) return fail(RT_ERR_STATE, "the scene has no hierarchy (rt_debug_set_bvh)");
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
+    rc = fresh_tables(c);
+    if (rc != RT_OK) return rc;
+    if (!c->bvh_ok) return fail(RT_ERR_STATE, "the scene has no hierarchy (rt_debug_set_bvh)");
     rc = wait_all(c);
     if (rc != RT_OK) return rc;
     if (!c->have_cam) c->cam = rt_camera{};
@@ -309,6 +318,7 @@ RT_API int rt_debug_walk_rays(rt_ctx *c, const float *rays8, uint32_t n_rays, ui
 // scene is then measured (the calibration's way of getting both timings).
 RT_API int rt_debug_tree_estimate(rt_ctx *c, double *out4) {
     if (!c || c->multi || !out4) return fail(RT_ERR_ARG, "null / multi-device context");
+    if (c->tables_stale && select_device(c) == RT_OK) (void)fresh_tables(c);
     out4[0] = c->bvh_est_pairs;
     out4[1] = c->bvh_est_leaves;
     out4[2] = c->bvh_est_valid && c->bvh_ok ? estimate_ratio(c) : 0.0;
@@ -335,6 +345,8 @@ RT_API int rt_debug_read_packed_pairs(rt_ctx *c, void *out, uint32_t cap_bytes, 
     if (!c || c->multi || !n_pairs) return fail(RT_ERR_ARG, "null / multi-device context");
     int rc = select_device(c);
     if (rc != RT_OK) return rc;
+    rc = fresh_tables(c);
+    if (rc != RT_OK) return rc;
     rc = wait_all(c);
     if (rc != RT_OK) return rc;
     *n_pairs = 0;
@@ -353,6 +365,8 @@ RT_API int rt_debug_read_packed_pairs(rt_ctx *c, void *out, uint32_t cap_bytes, 
 RT_API int rt_debug_read_bvh(rt_ctx *c, float *blob_out, uint32_t cap_float4, uint32_t *counts4) {
     if (!c || c->multi || !counts4) return fail(RT_ERR_ARG, "null / multi-device context");
     int rc = select_device(c);
+    if (rc != RT_OK) return rc;
+    rc = fresh_tables(c);
     if (rc != RT_OK) return rc;
     rc = wait_all(c);
     if (rc != RT_OK) return rc;

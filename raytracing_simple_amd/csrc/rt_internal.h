@@ -107,6 +107,9 @@ struct rt_ctx {
     int mode = RT_MODE_PARITY;
     int regen_gate = 0;                 // 0 = choose from the scene size
     int mat_lds_limit = 24 * 1024;
+    bool tables_stale = false;          // rt_update_spheres_async has changed records since the tables and the hierarchy were built: refresh_tables() builds them
+                                        // ONCE, on the stream of whatever reads them next, however many updates went by (200 moved spheres by 200 calls cost 200
+                                        // rebuilds before: 353 ms a frame at 8192 spheres against 4.9 in one call -- profiles/r06_update_calls.jsonl)
     int sweep_lds_limit = 40 * 1024;    // the plain / cooperative sweep stages its tables while four workgroups of that size fit a CU; beyond, the table is read through the
                                         // scalar cache at six wavefronts per SIMD whatever its size (rt_trace_*_g).  Measured at 1080p on scenes without a hierarchy
                                         // (profiles/r06_g_threshold.jsonl): at 48 KB (3 per CU) rt_trace_*_g takes 0.62 / 0.92 x the staged sweep's time (NaN records / a closed
@@ -172,6 +175,7 @@ bool tables_fit_lds(const rt_ctx *c, int n_samples);
 void probe_poll(rt_ctx *c, bool wait);              // hierarchy against sweep: the measurement's verdict, if its events have completed
 void rearm_probe(rt_ctx *c);                        // a new scene: undecided again
 void rearm_probe_if_changed(rt_ctx *c);             // after a device-resident update rebuilt the hierarchy
+int refresh_tables(rt_ctx *c, hipStream_t stream);     // rt_scene.hip: tables and hierarchy from the records as they are now, if updates made them stale
 double estimate_ratio(const rt_ctx *c);             // predicted walk / sweep time per ray from the uploaded tree's surface areas
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block = false);
 

@@ -490,6 +490,10 @@ static int launch_small(rt_ctx *c, int n_samples, hipStream_t stream, bool may_b
 }
 
 int launch(rt_ctx *c, int n_samples, hipStream_t stream, bool may_block) {
+    if (c->tables_stale) {              // records updated on the device since the tables were built: build them now, once
+        const int rc = refresh_tables(c, stream);
+        if (rc != RT_OK) return rc;
+    }
     const bool measured = c->walk_forced == 0 && c->mode < 100;
     if (measured && n_samples > 0 && c->local_rows != 0 && c->have_scene && c->have_cam && !bvh_usable(c)) return launch_small(c, n_samples, stream, may_block);
     if (!measured || n_samples <= 0 || c->local_rows == 0 || !c->have_scene || !c->have_cam || !bvh_usable(c))

@@ -134,6 +134,7 @@ static int ensure_stage_capacity(rt_ctx *c, uint32_t count) {
 // records [first, first+count) -> device, then the tables, all on `stream`.  `full_upload` is said by the caller, never inferred
 // from the range: only rt_set_scene (which blocks anyway) may take the host-side build of the hierarchy; an update --
 // whatever range it rewrites -- stays on the stream (rt_api.h: rt_update_spheres_async waits for nothing).
+static int build_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload);
 int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *spheres, uint32_t n_total, hipStream_t stream, bool full_upload) {
     int rc = chain(c, stream);
     if (rc != RT_OK) return rc;
@@ -150,6 +151,18 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
         c->stage_used[slot] = true;
         for (uint32_t i = 0; i < count; ++i) c->is_light[first + i] = light_test(spheres[i]) ? 1 : 0;
     }
+    if (!full_upload && c->have_scene) {
+        // a device-resident update: the records are on their way; the tables and the hierarchy are built from them when something reads them next
+        // (refresh_tables: launch(), the diagnostics' readers) -- once for all the updates queued until then
+        c->tables_stale = true;
+        return RT_OK;
+    }
+    return build_tables(c, n_total, stream, full_upload);
+}
+
+// the scene tables (rt_build_tables_kernel) and the hierarchy from the records in c->d_spheres, on `stream`
+static int build_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
+    c->tables_stale = false;
     uint32_t nl = 0;
     for (uint32_t i = 0; i < n_total; ++i) nl += c->is_light[i];
     const size_t cap = c->scene_cap;
@@ -162,6 +175,15 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, n_total, nl };
     return rt::build_bvh(c, n_total, stream, full_upload);
+}
+
+int refresh_tables(rt_ctx *c, hipStream_t stream) {
+    if (!c->tables_stale || !c->have_scene) return RT_OK;
+    int rc = chain(c, stream);          // (behind the copies of the records, whatever streams the updates were given)
+    if (rc != RT_OK) return rc;
+    rc = build_tables(c, c->scene.n_spheres, stream, false);
+    if (rc == RT_OK) rearm_probe_if_changed(c);
+    return rc;
 }
 
 }  // namespace rt

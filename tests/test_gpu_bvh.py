@@ -582,6 +582,38 @@ def test_plain_sweep_through_the_scalar_cache(n):
         _same(got, want)
 
 
+def test_many_scattered_updates_then_one_launch():
+    """Round 6: rt_update_spheres_async sends its records at once and leaves the tables and the hierarchy to the next reader, which builds them
+    ONCE (rt_scene.hip refresh_tables) -- 120 scattered spheres moved by 120 calls on two streams, a light switched off and another on; the
+    hierarchy read back BEFORE any launch (the diagnostics' reader refreshes too) is a valid tree of the moved scene, the frame the oracle's;
+    then more updates and a launch with no reader in between."""
+    sph, orig, target = scenes.random_spheres(1024)
+    sph = sph.copy()
+    w, h, spp = 64, 40, 2
+    cam = host.compute_camera(orig, target, w, h)
+    rng = np.random.default_rng(8)
+    with api.RtContext(w, h, diag=True) as ctx, api.RtContext(8, 8, diag=True) as other:      # (the second context lends its stream)
+        side = other.stream
+        ctx.set_scene(sph)
+        ctx.set_camera(cam)
+        ctx.render_pass(spp)
+        for rnd in range(2):
+            who = rng.choice(np.arange(2, len(sph)), 120, replace=False)
+            sph["p"][who] += rng.uniform(-3, 3, (120, 3)).astype(np.float32)
+            sph["rad"][who[:10]] *= np.float32(1.7)
+            sph["e"][who[10]] = (5.0, 4.0, 3.0)                                # a second light appears ...
+            sph["e"][who[11]] = (0.0, 0.0, 0.0)
+            for k, i in enumerate(who):
+                ctx.update_spheres(int(i), sph[int(i):int(i) + 1], side if k % 2 else ctx.stream)
+            if rnd == 0:
+                assert bvh_check.check_structure(api.as_spheres(sph), bvh_check.read_bvh(ctx)) == []
+            ctx.reset_async(ctx.stream)
+            ctx.render_async(spp, ctx.stream)
+            got = {"pixels": ctx.read_pixels(), "colors": ctx.read_colors(), "seeds": ctx.read_seeds(), "stats": ctx.stats()}
+            _same(got, O.render(sph, cam, w, h, spp, threads=16))
+        assert bvh_check.check_structure(api.as_spheres(sph), bvh_check.read_bvh(ctx)) == []
+
+
 def _two_size_classes(n_small, n_large, seed=3):
     """Dust among objects fifty times its size, a ground sphere and a light (tools/always_list_probe.py)."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
