@@ -85,6 +85,11 @@ def nan_scene(count):
     return sph, host.DEMO_ORIG, host.DEMO_TARGET
 
 
+def two_classes(n_small, n_large):
+    from tools import always_list_probe
+    return always_list_probe.two_classes(n_small, n_large)
+
+
 def library_build_id():
     """rt_build_id() of the product library this run renders with (a hash of csrc/, the public headers and the compiler flags)."""
     try:
@@ -452,7 +457,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--workload", default="c2",
                     help="c2 = the headline (default; what the driver measures); c16 / c3 / c4 / c5 = the other BASELINE configurations; box120 / r2048 / r8192 / "
-                         "r65536 / r262144 / nan9800 / nan9800hd = scenes that run on the shipped instances no BASELINE configuration reaches (rt_trace_*_coop, _pairs_m, _pairs_g, "
+                         "r65536 / r262144 / nan9800 / nan9800hd / dust10k = scenes that run on the shipped instances no BASELINE configuration reaches (rt_trace_*_coop, _pairs_m, _pairs_g, "
                          "rt_trace_*_g), for their profiles; scn:<scene> = one of the reference's own scenes (demo, simple, cornell, cornell_large, caustic, "
                          "caustic3, demo_scn, complex, cornell_test, complex_test: sphere array and camera from tests/golden/) at the reference's 800x600, 64 spp")
     ap.add_argument("--frames-in-flight", type=int, default=0,
@@ -511,6 +516,8 @@ def main():
         "r262144": ("262144 random spheres = RT_MAX_SPHERES (hierarchy read from HBM / L2)", lambda: scenes.random_spheres(262144), 1920, 1080, 4),
         "nan9800": ("the Demo scene + 9794 records whose centre is not a number: thousands of records of which fewer than 56 are finite small spheres -- no hierarchy, "
                     "and a table beyond the sweep's LDS budget: the plain sweep over a table in HBM / L2 through the scalar cache (rt_trace_*_g), the fallback that keeps every input renderable", lambda: nan_scene(9800), 640, 360, 1),
+        "dust10k": ("6 000 small spheres (radius 0.02-0.05) among 4 000 objects fifty times their size, a ground sphere, a light: two size classes, both in the hierarchy since "
+                    "round 6 (tools/always_list_probe.py; run with --no-cpu: the CPU check of 10 002 spheres at this size takes an hour)", lambda: two_classes(6000, 4000), 1920, 1080, 4),
         "nan9800hd": ("the nan9800 scene at 1920x1080: 32 400 wavefronts instead of 3 600 (640x360 leaves the GPU's 6 144 wavefront slots under-filled; the small size is the "
                       "one whose CPU check takes seconds -- run this one with --no-cpu)", lambda: nan_scene(9800), 1920, 1080, 1),
     }
