@@ -1212,7 +1212,15 @@ static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, boo
     // spheres under the first term, along the widest axis (quantiles: one record far away does not stretch it).  Nothing else depends on it: the
     // builders take the radius range for the walk's pad from what is IN the tree.
     float r_cut = 16.f * r_median;
-    {
+    // (asked only when the first term would put MORE THAN 32 spheres outside: a ground plane, six walls and a few lights are swept at no cost worth a
+    // hierarchy, and every scene that has no more than those -- every BASELINE and reference scene -- pays nothing for the question)
+    uint32_t n_over = 0;
+    for (uint32_t i = 0; i < n_total && n_over <= 32; ++i) {
+        const rt_sphere &s = c->h_spheres[i];
+        const float ar = fabsf(s.rad);
+        n_over += (ar > r_cut && ar <= 3.0e38f && fabsf(s.p.x) <= 3.0e38f && fabsf(s.p.y) <= 3.0e38f && fabsf(s.p.z) <= 3.0e38f && !repeated(i)) ? 1u : 0u;
+    }
+    if (n_over > 32) {
         std::vector<float> axis[3];
         for (uint32_t i = 0; i < n_total; ++i) {
             const rt_sphere &s = c->h_spheres[i];
