@@ -1212,15 +1212,16 @@ static int build_bvh_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, boo
     // spheres under the first term, along the widest axis (quantiles: one record far away does not stretch it).  Nothing else depends on it: the
     // builders take the radius range for the walk's pad from what is IN the tree.
     float r_cut = 16.f * r_median;
-    // (asked only when the first term would put MORE THAN 32 spheres outside: a ground plane, six walls and a few lights are swept at no cost worth a
-    // hierarchy, and every scene that has no more than those -- every BASELINE and reference scene -- pays nothing for the question)
+    // (asked only when the first term would put MORE THAN 8 spheres outside: a ground plane, six walls, a light are swept at no cost worth a hierarchy,
+    // and every scene that has no more than those -- every BASELINE and reference scene -- pays nothing for the question.  Not more than 8: in a scene of
+    // 150 spheres with radii over three decades, 15 above the first term cost the walk as much as its tree -- 0.50 against 0.20 ms, profiles/r06_choice_fuzz.jsonl)
     uint32_t n_over = 0;
-    for (uint32_t i = 0; i < n_total && n_over <= 32; ++i) {
+    for (uint32_t i = 0; i < n_total && n_over <= 8; ++i) {
         const rt_sphere &s = c->h_spheres[i];
         const float ar = fabsf(s.rad);
         n_over += (ar > r_cut && ar <= 3.0e38f && fabsf(s.p.x) <= 3.0e38f && fabsf(s.p.y) <= 3.0e38f && fabsf(s.p.z) <= 3.0e38f && !repeated(i)) ? 1u : 0u;
     }
-    if (n_over > 32) {
+    if (n_over > 8) {
         std::vector<float> axis[3];
         for (uint32_t i = 0; i < n_total; ++i) {
             const rt_sphere &s = c->h_spheres[i];
