@@ -162,7 +162,6 @@ int upload_spheres(rt_ctx *c, uint32_t first, uint32_t count, const rt_sphere *s
 
 // the scene tables (rt_build_tables_kernel) and the hierarchy from the records in c->d_spheres, on `stream`
 static int build_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool full_upload) {
-    c->tables_stale = false;
     uint32_t nl = 0;
     for (uint32_t i = 0; i < n_total; ++i) nl += c->is_light[i];
     const size_t cap = c->scene_cap;
@@ -174,7 +173,9 @@ static int build_tables(rt_ctx *c, uint32_t n_total, hipStream_t stream, bool fu
         HIP_TRY(hipGetLastError());
     }
     c->scene = rt::SceneTables{ d_geom, d_emis, d_colr, d_la, d_lb, n_total, nl };
-    return rt::build_bvh(c, n_total, stream, full_upload);
+    const int rc = rt::build_bvh(c, n_total, stream, full_upload);
+    if (rc == RT_OK) c->tables_stale = false;       // (a build that failed half-way is tried again by the next reader)
+    return rc;
 }
 
 int refresh_tables(rt_ctx *c, hipStream_t stream) {
