@@ -2,7 +2,8 @@
 """Many fuzzed scenes (the generator of tests/test_gpu_parity.py) through the HIP path and the oracle:
 python tools/fuzz_parity.py FIRST COUNT [FAMILY] -- prints the seeds that differ (none expected).
 RT_FUZZ_BVH=1|2 forces the hierarchy of large scenes on every scene (1 = walk per call, 2 = walk as lane state;
-diagnostics library); family 4 = hundreds of spheres in clusters, radii over three orders of magnitude."""
+diagnostics library); family 4 = hundreds of spheres in clusters, radii over three orders of magnitude; family 6 = two size
+classes / radii over three decades at hundreds to thousands of spheres (the cut between tree and always-list)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -130,9 +131,54 @@ def family5(seed):
     return sph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
 
 
+def family6(seed):
+    """What round 6's CUT special-cases (rt_bvh.hip build_bvh_tables: the always-list holds only spheres of the scene's own size): scenes of two
+    size classes -- 200 ... 4000 small spheres among 9 ... 800 spheres 20 ... 100 times their size, either class the majority --, or radii over
+    three decades; a ground sphere and walls far larger than both; some of the large ones exact repeats, not finite, or far away (the extent is
+    a quantile: they must not stretch it); the camera anywhere, also inside a large sphere."""
+    rng = np.random.default_rng(600000 + seed)
+    n_small = int(10 ** rng.uniform(2.3, 3.6))
+    n_large = int(rng.choice([9, 12, 40, 150, 400, 800]))
+    r0 = float(10 ** rng.uniform(-2, 0))
+    ratio = float(rng.uniform(20, 100))
+    n = n_small + n_large + 3
+    sph = np.zeros(n, api.SPHERE_DT)
+    if seed % 5 == 4:
+        sph["rad"][:n - 3] = (r0 * 10.0 ** rng.uniform(0, 3, n - 3)).astype(np.float32)
+    else:
+        sph["rad"][:n_small] = (r0 * rng.uniform(0.6, 1.6, n_small)).astype(np.float32)
+        sph["rad"][n_small:n - 3] = (r0 * ratio * rng.uniform(0.6, 1.6, n_large)).astype(np.float32)
+    span = r0 * ratio * float(rng.uniform(8, 40))
+    sph["p"][:n - 3] = np.stack([rng.uniform(-span, span, n - 3), rng.uniform(0, span / 4, n - 3), rng.uniform(-span, span, n - 3)], 1).astype(np.float32)
+    sph["c"] = rng.uniform(0.05, 0.95, (n, 3)).astype(np.float32)
+    sph["refl"] = rng.choice([api.DIFF, api.DIFF, api.SPEC, api.REFR], n)
+    sph["rad"][n - 3], sph["p"][n - 3], sph["refl"][n - 3] = 1000.0 * span, (0, -1000.0 * span, 0), api.DIFF          # ground
+    sph["rad"][n - 2], sph["p"][n - 2], sph["refl"][n - 2] = 500.0 * span, (-501.0 * span - span, 0, 0), api.DIFF      # a wall
+    sph["rad"][n - 1], sph["p"][n - 1], sph["e"][n - 1] = span / 6, (0, span, 0), (9, 9, 9)                            # the light
+    big = np.arange(n_small, n - 3)
+    if len(big) >= 12:
+        sph[big[:3]] = sph[big[3:6]]                                            # exact repeats among the large ones, other materials
+        sph["refl"][big[:3]] = rng.choice([api.DIFF, api.SPEC, api.REFR], 3)
+        with np.errstate(all="ignore"):
+            sph["p"][big[6], 0] = np.float32("nan")
+            sph["rad"][big[7]] = np.float32("inf")
+        sph["p"][big[8:11]] += np.float32(1e4 * span)                           # far away
+    for j in rng.choice(n - 3, int(rng.integers(0, 3)), replace=False):
+        sph["e"][j] = rng.uniform(2.0, 25.0, 3).astype(np.float32)
+    perm = rng.permutation(n)
+    sph = sph[perm]
+    if seed % 4 == 1 and n_large:
+        j = int(np.argmax(np.where(np.isfinite(sph["rad"]) & (sph["rad"] < span), sph["rad"], 0)))
+        orig = sph["p"][j] + np.float32(0.3) * sph["rad"][j]
+    else:
+        orig = np.float32([rng.uniform(-span, span), rng.uniform(span / 8, span / 2), rng.uniform(-span, span)])
+    target = np.float32([rng.uniform(-span / 4, span / 4), 0, rng.uniform(-span / 4, span / 4)])
+    return sph, tuple(float(v) for v in orig), tuple(float(v) for v in target)
+
+
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bvh_form = int(os.environ.get("RT_FUZZ_BVH", "0"))
-gen = {"2": family2, "3": family3, "4": family4, "5": family5}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
+gen = {"2": family2, "3": family3, "4": family4, "5": family5, "6": family6}.get(sys.argv[3] if len(sys.argv) > 3 else "1", ns["_fuzz_scene"])
 bad = []
 kernels = {}
 for seed in range(first, first + count):

@@ -10,7 +10,7 @@ O=gpurun_out/$TAG; mkdir -p $O; F=$O/validation.txt
 echo "# validation, build $(python3 -c 'import sys; sys.path.insert(0, "."); from raytracing_simple_amd import api; print(api.build_id())')" > $F
 echo "## tools/full_size_parity.py" >> $F
 timeout -k 10 600 python tools/full_size_parity.py c1,c2,c16,c3,c5,c4 >> $F 2>&1; echo "full size done"
-for fam in 1 2 3 4 5; do
+for fam in 1 2 3 4 5 6; do
     echo "## fuzz family $fam, $N seeds from $S: the library's choice / hierarchy forced (host shape) / hierarchy forced, shaped on the device" >> $F
     timeout -k 10 900 python tools/fuzz_parity.py $S $N $fam 2>&1 | tail -3 >> $F
     RT_FUZZ_BVH=1 timeout -k 10 900 python tools/fuzz_parity.py $((S + 10000)) $N $fam 2>&1 | tail -3 >> $F
