@@ -13,11 +13,12 @@ KERNEL = {("c2", "parity"): "rt_trace_parity_w1", ("c2", "fast"): "rt_trace_fast
 LABEL = {"c2": "C2: Demo, 1920x1080, 64 spp", "c16": "north-star target: 16 spheres, 1920x1080, 64 spp", "c3": "C3: 1024 spheres, 1920x1080, 16 spp",
          "c5": "C5: 64-sphere mirror box, 1920x1080, 64 spp"}
 KERNEL.update({("box120", "parity"): "rt_trace_parity_coop", ("r2048", "parity"): "rt_trace_parity_pairs_m", ("r8192", "parity"): "rt_trace_parity_pairs_g",
-               ("nan9800", "parity"): "rt_trace_parity_g", ("nan9800hd", "parity"): "rt_trace_parity_g"})
+               ("nan9800", "parity"): "rt_trace_parity_g", ("nan9800hd", "parity"): "rt_trace_parity_g", ("dust10k", "parity"): "rt_trace_parity_pairs_g"})
 LABEL.update({"box120": "closed box of 120 mirror / glass spheres, 1920x1080, 8 spp", "r2048": "2048 random spheres, 1920x1080, 8 spp",
               "r8192": "8192 random spheres, 1920x1080, 4 spp (hierarchy read from HBM / L2)",
               "nan9800": "Demo scene + 9794 records with a NaN centre, 640x360, 1 spp (no hierarchy, table beyond LDS: the plain sweep over HBM / L2)",
-              "nan9800hd": "Demo scene + 9794 records with a NaN centre, 1920x1080, 1 spp (the plain sweep over a table beyond LDS on a filled GPU)"})
+              "nan9800hd": "Demo scene + 9794 records with a NaN centre, 1920x1080, 1 spp (the plain sweep over a table beyond LDS on a filled GPU)",
+              "dust10k": "6000 small spheres among 4000 objects fifty times their size, 1920x1080, 4 spp (two size classes, both in the hierarchy)"})
 
 
 def kernel_of(src, default):

@@ -28,7 +28,7 @@ elif [ "$PART" = "P" ]; then
     if [ -z "${RT_PROF_SPECS:-}" ] || [ "${RT_PROF_STAGING:-0}" = "1" ]; then
         RT_STAGING_JSON=$(pwd)/$O/pmc_staging.json bash tools/pmc_staging.sh c2,c16,c5,box120 > $O/pmc_staging.log 2>&1; tail -4 $O/pmc_staging.log
     fi
-    IFS=';' read -ra SPECS <<< "${RT_PROF_SPECS:-c2 parity;c2 fast;c16 parity;c3 parity;c5 parity;box120 parity;r2048 parity;r8192 parity;nan9800 parity;nan9800hd parity}"
+    IFS=';' read -ra SPECS <<< "${RT_PROF_SPECS:-c2 parity;c2 fast;c16 parity;c3 parity;c5 parity;box120 parity;r2048 parity;r8192 parity;nan9800 parity;nan9800hd parity;dust10k parity}"
     for spec in "${SPECS[@]}"; do
         set -- $spec
         bash tools/profile_gpu.sh $TAG/prof_$1_$2 $2 $1 > $O/prof_$1_$2.log 2>&1; tail -1 $O/prof_$1_$2.log
